@@ -1,0 +1,133 @@
+"""dazimsurftomo_amd -- host-side mirror of the DAzimSurfTomo hot-path interface over libdazim_hip.so.
+
+The functions keep the reference's names and argument meaning (depthkernel, gridder+travel as
+`fmm_batch`, CalSurfG, aprod, LSMR; reference files cited in include/dazim.h) and call the
+hand-written gfx950 kernels through the C ABI.  Arrays may be numpy arrays (staged over PCIe by the
+library) or torch CUDA tensors (used in place).  Nothing here computes on the CPU: without the
+built library and a GPU every call raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Geom, RefBox, build, load
+
+RMAX = 129
+PI_F32 = np.float32(3.1415926535898)  # inv/CalSurfG.f90:166
+
+
+class DazimError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"dazim error {code}: {msg}")
+        self.code = code
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x, dtype=None):
+    """raw pointer of a numpy array or torch tensor (None -> NULL)"""
+    if x is None:
+        return None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        if dtype is not None:
+            import torch
+            want = {np.float32: torch.float32, np.float64: torch.float64, np.int32: torch.int32,
+                    np.int64: torch.int64}[dtype]
+            assert x.dtype == want, (x.dtype, want)
+        return C.c_void_p(x.data_ptr())
+    assert isinstance(x, np.ndarray) and x.flags.c_contiguous
+    if dtype is not None:
+        assert x.dtype == dtype, (x.dtype, dtype)
+    return C.c_void_p(x.ctypes.data)
+
+
+def to_radians(lat_deg, lon_deg):
+    """colatitude/longitude in fp32 radians exactly as inv/Main_Jt.f90:289-292 forms them"""
+    lat = np.asarray(lat_deg, np.float32)
+    lon = np.asarray(lon_deg, np.float32)
+    return ((np.float32(90.0) - lat) * PI_F32 / np.float32(180.0)).astype(np.float32), \
+        (lon * PI_F32 / np.float32(180.0)).astype(np.float32)
+
+
+def geometry(nx, ny, goxd, gozd, dvxd, dvzd):
+    g = Geom()
+    rc = load().dazim_geometry(nx, ny, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd), C.c_float(dvzd), C.byref(g))
+    if rc:
+        raise DazimError(rc, "bad geometry")
+    return g
+
+
+class Context:
+    """One GPU context (`dazim_ctx`).  Raises if no GPU / no library: there is no CPU path."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self._h = C.c_void_p()
+        rc = self.lib.dazim_create(C.byref(self._h), int(device))
+        if rc:
+            raise DazimError(rc, "dazim_create failed (no GPU visible?)")
+
+    def close(self):
+        if self._h:
+            self.lib.dazim_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise DazimError(rc, self.lib.dazim_last_error(self._h).decode())
+
+    def kernel_seconds(self, name):
+        return self.lib.dazim_last_kernel_seconds(self._h, name.encode())
+
+    def sync(self):
+        self._check(self.lib.dazim_sync(self._h))
+
+    # ---- K2+K3 -----------------------------------------------------------------------------
+    def fmm_batch(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, period_idx,
+                  veln=None, ttn=None, ttnr=None, nstsr=None, boxes=None, status=None,
+                  want_refined=True):
+        """gridder + bsplrefine + travel x2 for a batch of (source, period) fields
+        (body of the source loop inv/CalSurfG.f90:1146-1314).  Returns a dict of outputs; numpy
+        in -> numpy out, torch-cuda in -> the given output tensors are filled in place."""
+        g = geometry(nx, ny, goxd, gozd, dvxd, dvzd)
+        kmax = pv.shape[0]
+        nfield = int(scx.shape[0])
+        if not _is_torch(pv):
+            pv = np.ascontiguousarray(pv, np.float64)
+            scx = np.ascontiguousarray(scx, np.float32)
+            scz = np.ascontiguousarray(scz, np.float32)
+            period_idx = np.ascontiguousarray(period_idx, np.int32)
+            if ttn is None:
+                ttn = np.zeros((nfield, g.nnx, g.nnz), np.float32)
+            if veln is None:
+                veln = np.zeros((kmax, g.nnx, g.nnz), np.float32)
+            if want_refined and ttnr is None:
+                ttnr = np.zeros((nfield, RMAX, RMAX), np.float32)
+                nstsr = np.zeros((nfield, RMAX, RMAX), np.int32)
+            if boxes is None:
+                boxes = (RefBox * max(nfield, 1))()
+            if status is None:
+                status = np.zeros(nfield, np.int32)
+        bptr = None
+        if boxes is not None:
+            bptr = C.c_void_p(boxes.data_ptr()) if _is_torch(boxes) else C.cast(boxes, C.c_void_p)
+        rc = self.lib.dazim_fmm_batch(self._h, nx, ny, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
+                                      C.c_float(dvzd), kmax, _ptr(pv), nfield, _ptr(scx), _ptr(scz),
+                                      _ptr(period_idx), _ptr(veln), _ptr(ttn), _ptr(ttnr), _ptr(nstsr),
+                                      bptr, _ptr(status))
+        out = dict(geom=g, veln=veln, ttn=ttn, ttnr=ttnr, nstsr=nstsr, boxes=boxes, status=status, rc=rc)
+        if rc:
+            err = DazimError(rc, self.lib.dazim_last_error(self._h).decode())
+            err.partial = out
+            raise err
+        return out

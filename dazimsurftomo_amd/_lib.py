@@ -1,0 +1,67 @@
+"""Loader for the product library libdazim_hip.so (C ABI declared in include/dazim.h).
+
+There is no CPU fallback: if the library or a GPU is missing, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB_PATH = os.path.join(HERE, "lib", "libdazim_hip.so")
+CSRC = os.path.join(HERE, "csrc")
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               # the reference arithmetic has no FMA; contraction would reorder FMM acceptance
+               "-ffp-contract=off"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into lib/libdazim_hip.so (cross-compiles without a GPU)."""
+    srcs = sources()
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    deps.append(os.path.join(ROOT, "include", "dazim.h"))
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    if any(open(s).read().find("rccl.h") >= 0 for s in srcs):
+        cmd += ["-lrccl"]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+class RefBox(C.Structure):
+    _fields_ = [("vnl", C.c_int), ("vnr", C.c_int), ("vnt", C.c_int), ("vnb", C.c_int),
+                ("nnxr", C.c_int), ("nnzr", C.c_int), ("isx", C.c_int), ("isz", C.c_int),
+                ("goxr", C.c_float), ("gozr", C.c_float), ("dnxr", C.c_float), ("dnzr", C.c_float)]
+
+
+class Geom(C.Structure):
+    _fields_ = [("nvx", C.c_int), ("nvz", C.c_int), ("nnx", C.c_int), ("nnz", C.c_int),
+                ("gox", C.c_float), ("goz", C.c_float), ("dnx", C.c_float), ("dnz", C.c_float),
+                ("dvx", C.c_float), ("dvz", C.c_float)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the product library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    lib = C.CDLL(LIB_PATH)
+    lib.dazim_last_error.restype = C.c_char_p
+    lib.dazim_last_kernel_seconds.restype = C.c_double
+    lib.dazim_stream.restype = C.c_void_p
+    _lib = lib
+    return lib

@@ -1,0 +1,126 @@
+// ctx.hip -- context, memory helpers and host-side geometry of libdazim_hip.so.
+#include "dazim_internal.h"
+
+int dz_fail(dazim_ctx *c, int code, const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  return code;
+}
+
+bool dz_is_device_ptr(const void *p) {
+  hipPointerAttribute_t a;
+  memset(&a, 0, sizeof a);
+  hipError_t e = hipPointerGetAttributes(&a, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'ed host memory: clear the sticky error
+    return false;
+  }
+  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
+  auto &s = ctx->scratch[name];
+  if (s.second < bytes) {
+    if (s.first) {
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      DZ_HIP(hipFree(s.first));
+    }
+    s.first = nullptr;
+    s.second = 0;
+    size_t want = bytes + bytes / 8;  // a little slack so slowly growing batches do not thrash
+    DZ_HIP(hipMalloc(&s.first, want));
+    s.second = want;
+  }
+  *out = s.first;
+  return 0;
+}
+
+extern "C" {
+
+int dazim_create(dazim_ctx **out, int device) {
+  if (!out) return DAZIM_E_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return -1;  // no GPU: the product path refuses to run
+  if (device < 0 || device >= n) return DAZIM_E_BAD_ARG;
+  dazim_ctx *ctx = new dazim_ctx;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return -2;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  *out = ctx;
+  return 0;
+}
+
+void dazim_destroy(dazim_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &kv : ctx->scratch)
+    if (kv.second.first) (void)hipFree(kv.second.first);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *dazim_last_error(const dazim_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes) {
+  DZ_HIP(hipSetDevice(ctx->device));
+  DZ_HIP(hipMalloc(dptr, bytes));
+  return 0;
+}
+int dazim_free(dazim_ctx *ctx, void *dptr) {
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  DZ_HIP(hipFree(dptr));
+  return 0;
+}
+int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+int dazim_sync(dazim_ctx *ctx) {
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+void *dazim_stream(dazim_ctx *ctx) { return (void *)ctx->stream; }
+
+double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name) {
+  auto it = ctx->ksec.find(name);
+  return it == ctx->ksec.end() ? -1.0 : it->second;
+}
+
+// inv/CalSurfG.f90:1005-1038 (gdx = gdz = 5, fp32 pi = 3.1415926535898 as in MODULE globalp :166)
+int dazim_geometry(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, dazim_geom *g) {
+  if (!g || nx < 4 || ny < 4) return DAZIM_E_BAD_ARG;
+  const float pi = 3.1415926535898f;
+  g->nvx = nx - 2;
+  g->nvz = ny - 2;
+  g->dvx = dvxd * pi / 180.0f;
+  g->dvz = dvzd * pi / 180.0f;
+  g->gox = (90.0f - goxd) * pi / 180.0f;
+  g->goz = gozd * pi / 180.0f;
+  g->nnx = (g->nvx - 1) * 5 + 1;
+  g->nnz = (g->nvz - 1) * 5 + 1;
+  g->dnx = g->dvx / 5;
+  g->dnz = g->dvz / 5;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,88 @@
+// dazim_internal.h -- shared plumbing of libdazim_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dazim.h"
+
+struct dazim_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  std::map<std::string, double> ksec;  // last measured kernel seconds by name
+  int num_cu = 256;
+  // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
+  std::map<std::string, std::pair<void *, size_t>> scratch;
+};
+
+int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
+
+#define DZ_HIP(call)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return dz_fail(ctx, -(int)e_ - 1000, "%s:%d %s -> %s", __FILE__, __LINE__, #call,       \
+                     hipGetErrorString(e_));                                                   \
+  } while (0)
+
+// named scratch buffer of at least `bytes` bytes
+int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
+
+bool dz_is_device_ptr(const void *p);
+
+// Staging helper: wraps a user pointer that may live on the host or on the device.
+template <class T>
+struct DzBuf {
+  dazim_ctx *ctx = nullptr;
+  T *user = nullptr;
+  T *dev = nullptr;
+  size_t n = 0;
+  bool staged = false, out = false;
+  int init(dazim_ctx *c, const T *p, size_t count, bool copy_in, bool copy_out) {
+    ctx = c;
+    user = const_cast<T *>(p);
+    n = count;
+    out = copy_out;
+    if (!p || count == 0) return 0;
+    if (dz_is_device_ptr(p)) {
+      dev = user;
+      return 0;
+    }
+    staged = true;
+    DZ_HIP(hipMalloc((void **)&dev, n * sizeof(T)));
+    if (copy_in) DZ_HIP(hipMemcpyAsync(dev, user, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+  }
+  int finish() {
+    if (staged && out && dev)
+      DZ_HIP(hipMemcpyAsync(user, dev, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+  }
+  ~DzBuf() {
+    if (staged && dev) {
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(dev);
+    }
+  }
+};
+
+// time a region on the ctx stream with HIP events and record it under `name`
+struct DzTimer {
+  dazim_ctx *ctx;
+  const char *name;
+  DzTimer(dazim_ctx *c, const char *n) : ctx(c), name(n) { (void)hipEventRecord(ctx->ev0, ctx->stream); }
+  void stop() {
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    (void)hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->ksec[name] = ms * 1e-3;
+  }
+};

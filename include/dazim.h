@@ -1,0 +1,98 @@
+/* dazim.h -- C ABI of the MI355X-native DAzimSurfTomo hot path (libdazim_hip.so).
+ *
+ * The reference (Chuanming-Liu/DAzimSurfTomo) has no FFI; its seams are Fortran procedure calls
+ * with module-global state.  Each entry point below replaces one seam and
+ * cites it as inv/<file>:<line> (inv/ = src/src_inv_iso_joint/).  The Fortran host binds them
+ * through ISO_C_BINDING (host/dazim_mod.f90).
+ *
+ * Conventions
+ *  - every function returns 0 on success, >0 for a reference-STOP-equivalent condition
+ *    (DAZIM_E_*), <0 for a HIP/RCCL runtime failure; dazim_last_error(ctx) holds the message.
+ *  - every bulk pointer may be a HOST pointer or a DEVICE (hipMalloc) pointer; the library
+ *    detects which.  Host pointers are staged through device buffers (PCIe-inclusive); device
+ *    pointers are used in place (zero-copy, what bench.py times).
+ *  - 2-D grids keep the reference's Fortran memory order: node (iz,ix) of an nnz x nnx grid is at
+ *    [(ix-1)*nnz + (iz-1)], i.e. "[ix][iz]" in C terms.  Model cubes are vel(nx,ny,nz) =
+ *    [k][j][i] in C terms.  Indices that cross the ABI (period_idx, COO/CSR columns) are 1-based
+ *    exactly where the reference's are, and say so.
+ *  - no global state: everything hangs off dazim_ctx; one ctx per GPU / per host thread.
+ */
+#ifndef DAZIM_H
+#define DAZIM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAZIM_RMAX 129 /* refined source grid is at most (2*sgs*sgdl+1)^2, inv/CalSurfG.f90:1187-1196 */
+
+enum {
+  DAZIM_OK = 0,
+  DAZIM_E_SOURCE_OUTSIDE = 1,   /* inv/CalSurfG.f90:287-293, 1174-1180 */
+  DAZIM_E_RECEIVER_OUTSIDE = 2, /* inv/CalSurfG.f90:1649-1655, 1863-1869 */
+  DAZIM_E_NNZ_OVERFLOW = 4,     /* inv/Main_Jt.f90:523 "increase sparsity fraction" */
+  DAZIM_E_BAD_ARG = 5,
+  DAZIM_E_ROOT_NOT_FOUND = 6    /* inv/surfdisp96.f:307-348 (warning there; count returned here) */
+};
+
+typedef struct dazim_ctx dazim_ctx;
+
+/* propagation-grid geometry derived from the inversion grid, inv/CalSurfG.f90:1017-1038 */
+typedef struct {
+  int nvx, nvz;             /* B-spline vertices nx-2, ny-2                      */
+  int nnx, nnz;             /* propagation nodes (nvx-1)*5+1, (nvz-1)*5+1         */
+  float gox, goz, dnx, dnz; /* origin (colatitude, longitude; rad) and node step  */
+  float dvx, dvz;           /* vertex step (rad)                                  */
+} dazim_geom;
+
+/* refined source box of one field, inv/CalSurfG.f90:1187-1206,1266-1271 */
+typedef struct {
+  int vnl, vnr, vnt, vnb; /* box bounds in coarse node indices, 1-based */
+  int nnxr, nnzr;         /* refined grid size                           */
+  int isx, isz;           /* coarse source cell                          */
+  float goxr, gozr, dnxr, dnzr;
+} dazim_refbox;
+
+/* ---- context / memory ---------------------------------------------------------------------- */
+int dazim_create(dazim_ctx **ctx, int device);
+void dazim_destroy(dazim_ctx *ctx);
+const char *dazim_last_error(const dazim_ctx *ctx);
+int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes);
+int dazim_free(dazim_ctx *ctx, void *dptr);
+int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
+int dazim_sync(dazim_ctx *ctx);
+void *dazim_stream(dazim_ctx *ctx); /* the hipStream_t every kernel of this ctx is launched on */
+/* seconds spent in the last call's kernels, measured with HIP events on the ctx stream; name
+ * selects the kernel ("fmm", "gridder", "disp", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
+double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
+
+/* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */
+int dazim_geometry(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, dazim_geom *g);
+
+/* ---- K2+K3: batched eikonal fields -----------------------------------------------------------
+ * = gridder (inv/CalSurfG.f90:1423) once per period + per (source,period): bsplrefine (:1525),
+ *   travel on the refined box (:258, urg=1), injection + band completion (:1246-1308) and
+ *   travel on the coarse grid (urg=2), i.e. the body of the source loop inv/CalSurfG.f90:1146-1314.
+ *  pv         [kmax][(nvz+2)*(nvx+2)] phase velocity per period and inversion cell (= pvRc(:,k))
+ *  period_idx [nfield] 1-based period of each field (= periods(srcnum,knumi))
+ *  scx, scz   [nfield] source colatitude / longitude in radians (fp32, as the reference holds them)
+ *  veln       [kmax][nnx][nnz]  out, nullable: gridded velocity per period
+ *  ttn        [nfield][nnx][nnz] out: coarse traveltime field
+ *  ttnr       [nfield][129][129] out, nullable: refined field (0 where the node is not alive/close)
+ *  nstsr      [nfield][129][129] out, nullable: refined node status (-1 far, 0 alive, >0 close,
+ *             -9 outside the nnzr x nnxr box)
+ *  boxes      [nfield] out, nullable
+ *  status     [nfield] out, nullable: DAZIM_OK or DAZIM_E_SOURCE_OUTSIDE per field; the call
+ *             returns the first non-zero status (the reference STOPs there)                    */
+int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd,
+                    int kmax, const double *pv, int nfield, const float *scx, const float *scz,
+                    const int *period_idx, float *veln, float *ttn, float *ttnr, int *nstsr,
+                    dazim_refbox *boxes, int *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,91 @@
+"""-m gpu: the HIP eikonal path (dazim_fmm_batch) against the CPU oracle, bit for bit.
+
+Tolerance: NONE.  The eikonal arithmetic is fp32 without FMA on both sides and the heap is
+emulated exactly, so veln, ttn, ttnr and nstsr must be identical ("target
+bit-identical with contraction off").
+"""
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_case(ctx, orc, nx, ny, kmax, nsrc, seed, goxd=30.0, gozd=100.0, dv=0.25, edge_sources=False):
+    pv = synth.phase_velocity_maps(nx, ny, kmax, seed)
+    lat, lon = synth.stations(nx, ny, goxd, gozd, dv, dv, nsrc, seed + 1, shrink=0.02 if edge_sources else 0.3)
+    if edge_sources:  # corners and exact node positions exercise the clipped refined boxes
+        lat[:4] = [goxd, goxd, goxd - (nx - 3) * dv, goxd - (nx - 3) * dv]
+        lon[:4] = [gozd, gozd + (ny - 3) * dv, gozd, gozd + (ny - 3) * dv]
+        lat[4], lon[4] = goxd - 5 * dv, gozd + 7 * dv
+    sx, sz = synth.radians(lat, lon)
+    scx = np.tile(sx, kmax)
+    scz = np.tile(sz, kmax)
+    per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
+    out = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    g = orc.geometry(nx, ny, goxd, gozd, dv, dv)
+    assert (g.nnx, g.nnz) == (out["geom"].nnx, out["geom"].nnz)
+    for k in range(kmax):
+        veln = orc.gridder(g, pv[k])
+        assert np.array_equal(veln, out["veln"][k]), f"veln period {k}"
+        for s in range(nsrc):
+            f = k * nsrc + s
+            rc, ttn, ttnr, nstsr, velnr, box = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
+            assert rc == 0 and out["status"][f] == 0
+            b = out["boxes"][f]
+            assert (b.vnl, b.vnr, b.vnt, b.vnb, b.nnxr, b.nnzr, b.isx, b.isz) == \
+                (box.vnl, box.vnr, box.vnt, box.vnb, box.nnxr, box.nnzr, box.isx, box.isz)
+            assert (b.goxr, b.gozr, b.dnxr, b.dnzr) == (box.goxr, box.gozr, box.dnxr, box.dnzr)
+            assert np.array_equal(out["nstsr"][f], nstsr), f"nstsr field {f}"
+            live = nstsr >= 0
+            assert np.array_equal(out["ttnr"][f][live], ttnr[live]), f"ttnr field {f}"
+            assert np.array_equal(out["ttn"][f], ttn), f"ttn field {f}: max diff {np.abs(out['ttn'][f]-ttn).max()}"
+
+
+def test_fmm_test1_scale(ctx, orc):
+    """17x17 inversion grid -> 71x71 nodes (the reference's test1-3 size), sources incl. corners"""
+    _run_case(ctx, orc, 17, 17, 3, 12, seed=3, goxd=26.5, gozd=101.25, edge_sources=True)
+
+
+def test_fmm_rectangular(ctx, orc):
+    """non-square grid 12x23 -> 46x101 nodes"""
+    _run_case(ctx, orc, 12, 23, 2, 9, seed=11, edge_sources=True)
+
+
+def test_fmm_256(ctx, orc):
+    """BASELINE S-256 geometry: 54x54 -> 256x256 nodes"""
+    _run_case(ctx, orc, 54, 54, 2, 6, seed=5)
+
+
+def test_fmm_source_outside(ctx):
+    import dazimsurftomo_amd as dz
+    pv = synth.phase_velocity_maps(17, 17, 1)
+    sx, sz = synth.radians([26.0, 40.0], [102.0, 102.0])
+    with pytest.raises(dz.DazimError) as e:
+        ctx.fmm_batch(17, 17, 26.5, 101.25, 0.25, 0.25, pv, sx, sz, np.array([1, 1], np.int32))
+    assert e.value.code == 1  # DAZIM_E_SOURCE_OUTSIDE, inv/CalSurfG.f90:1174-1180
+    assert list(e.value.partial["status"]) == [0, 1]
+
+
+def test_fmm_properties_full_size(ctx):
+    """size-independent checks at the bench size: causality (T>0 except near source, finite),
+    every field's minimum sits at its source cell, and identical fields for identical inputs"""
+    nx = ny = 54
+    kmax, nsrc = 2, 40
+    pv = synth.phase_velocity_maps(nx, ny, kmax)
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc)
+    sx, sz = synth.radians(lat, lon)
+    scx = np.concatenate([sx, sx]); scz = np.concatenate([sz, sz])
+    per = np.repeat(np.arange(1, 3, dtype=np.int32), nsrc)
+    out = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx, scz, per, want_refined=False)
+    out2 = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx[::-1].copy(), scz[::-1].copy(), per[::-1].copy(), want_refined=False)
+    ttn = out["ttn"]
+    assert np.isfinite(ttn).all() and (ttn >= 0).all()
+    assert np.array_equal(ttn, out2["ttn"][::-1]), "result must not depend on the field's queue position"
+    for f in range(2 * nsrc):
+        b = out["boxes"][f]
+        ix, iz = np.unravel_index(np.argmin(ttn[f]), ttn[f].shape)
+        assert abs(ix + 1 - b.isx) <= 1 and abs(iz + 1 - b.isz) <= 1
+        # eikonal sanity: time to the far corner is bounded by distance / vmin, vmax
+        assert ttn[f].max() < 14.0 * 111.2 * 1.5 / 2.5
