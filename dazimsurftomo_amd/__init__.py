@@ -131,3 +131,55 @@ class Context:
             err.partial = out
             raise err
         return out
+
+    # ---- K6/K7 -----------------------------------------------------------------------------
+    def csr_from_coo(self, m, n, irow, icol, rw):
+        """COO triplets as the reference holds them (1-based rows iw(2:nar+1), cols, values rw;
+        inv/aprod.f90:20-24) -> device CSR + CSC handle"""
+        if not _is_torch(rw):
+            irow = np.ascontiguousarray(irow, np.int32)
+            icol = np.ascontiguousarray(icol, np.int32)
+            rw = np.ascontiguousarray(rw, np.float32)
+        h = C.c_void_p()
+        rc = self.lib.dazim_csr_from_coo(self._h, C.c_int64(m), C.c_int64(n), C.c_int64(int(rw.shape[0])),
+                                         _ptr(irow), _ptr(icol), _ptr(rw), C.byref(h))
+        self._check(rc)
+        return SparseMatrix(self, h, m, n, int(rw.shape[0]))
+
+    def aprod(self, mode, A, x, y):
+        """aprod (inv/aprod.f90:7): mode 1: y += A x ; mode 2: x += A^T y (in place)"""
+        self._check(self.lib.dazim_aprod(self._h, int(mode), A._h, _ptr(x, np.float32), _ptr(y, np.float32)))
+
+    def lsmr(self, A, b, damp, atol, btol, conlim, itnlim, localSize, x=None):
+        """LSMR (inv/lsmrModule.f90:36) -> x, info dict (istop, itn, normA, condA, normr, normAr, normx)"""
+        if x is None:
+            if _is_torch(b):
+                import torch
+                x = torch.zeros(A.n, dtype=torch.float32, device=b.device)
+            else:
+                x = np.zeros(A.n, np.float32)
+        if not _is_torch(b):
+            b = np.ascontiguousarray(b, np.float32)
+        istop, itn = C.c_int(0), C.c_int(0)
+        sc = [C.c_float(0) for _ in range(5)]
+        rc = self.lib.dazim_lsmr(self._h, A._h, _ptr(b, np.float32), C.c_float(damp), C.c_float(atol), C.c_float(btol),
+                                 C.c_float(conlim), int(itnlim), int(localSize), _ptr(x, np.float32),
+                                 C.byref(istop), C.byref(itn), *[C.byref(s) for s in sc])
+        self._check(rc)
+        return x, dict(istop=istop.value, itn=itn.value, normA=sc[0].value, condA=sc[1].value,
+                       normr=sc[2].value, normAr=sc[3].value, normx=sc[4].value)
+
+
+class SparseMatrix:
+    """device-resident G (dazim_csr)"""
+
+    def __init__(self, ctx, handle, m, n, nnz):
+        self.ctx, self._h, self.m, self.n, self.nnz = ctx, handle, m, n, nnz
+
+    def scale_rows(self, w):
+        self.ctx._check(self.ctx.lib.dazim_csr_scale_rows(self.ctx._h, self._h, _ptr(w, np.float32)))
+
+    def free(self):
+        if self._h:
+            self.ctx.lib.dazim_csr_free(self.ctx._h, self._h)
+            self._h = None

@@ -1,0 +1,578 @@
+// sparse.hip -- K6/K7 of SURVEY.md: the sensitivity matrix on the device (CSR + stable transpose)
+// its two products (aprod, inv/aprod.f90:7) and the fp32 LSMR solver (inv/lsmrModule.f90:36).
+//
+// The products are HBM-bound: 8 B per stored entry (fp32 value + int32 index) are streamed once per
+// product with 16-byte loads, one wavefront per row (CSR, A*x) or per column (CSC, A^T*y), and a
+// 64-lane shuffle reduction; the gathered vector stays in L2.  Both products write their result in
+// a fixed order (no atomics) so that LSMR is reproducible run to run.
+#include "dazim_internal.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+struct dazim_csr {
+  int64_t m = 0, n = 0, nnz = 0;
+  int64_t *rowptr = nullptr, *colptr = nullptr;  // [m+1], [n+1]
+  int *col = nullptr, *row = nullptr;            // CSR column / CSC row of each entry, 0-based
+  float *val = nullptr, *tval = nullptr;         // CSR / CSC values
+  unsigned *tperm = nullptr;                     // CSC entry -> CSR entry (for value rescaling)
+};
+
+namespace {
+
+constexpr int WPB = 4;  // wavefronts per workgroup in the row kernels
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// out[r] = beta*out[r] + sum_k val[k]*x[idx[k]], k in [ptr[r], ptr[r+1]) ; one wavefront per row.
+// If sumsq != nullptr the workgroup also writes its partial sum of out[r]^2 (double) for a norm.
+__global__ __launch_bounds__(64 * WPB) void spmv_rows(int64_t nrows, const int64_t *__restrict__ ptr,
+                                                        const int *__restrict__ idx,
+                                                        const float *__restrict__ val,
+                                                        const float *__restrict__ x, float *__restrict__ out,
+                                                        const float *__restrict__ beta_p, float beta_sign,
+                                                        double *__restrict__ sumsq) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
+  double sq = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * WPB + w; r < nrows; r += (int64_t)gridDim.x * WPB) {
+    const int64_t s = ptr[r], e = ptr[r + 1];
+    float acc = 0.0f;
+    int64_t s4 = (s + 3) & ~(int64_t)3;
+    if (s4 > e) s4 = e;
+    for (int64_t i = s + lane; i < s4; i += 64) acc += val[i] * x[idx[i]];
+    const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
+    for (int64_t i = s4 + 4 * lane; i < e4; i += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(val + i);
+      const int4 c = *reinterpret_cast<const int4 *>(idx + i);
+      acc += v.x * x[c.x];
+      acc += v.y * x[c.y];
+      acc += v.z * x[c.z];
+      acc += v.w * x[c.w];
+    }
+    for (int64_t i = e4 + lane; i < e; i += 64) acc += val[i] * x[idx[i]];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float o = beta * out[r] + acc;
+      out[r] = o;
+      sq += (double)o * (double)o;
+    }
+  }
+  if (sumsq) {
+    __shared__ double s_sq[WPB];
+    if (lane == 0) s_sq[w] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int i = 0; i < WPB; i++) t += s_sq[i];
+      sumsq[blockIdx.x] = t;
+    }
+  }
+}
+
+// ---- small vector kernels (all O(m+n), negligible next to the products) ----------------------
+constexpr int VB = 256;   // threads per block
+constexpr int NPART = 256;  // partial sums per reduction
+
+__device__ __forceinline__ void block_partial(double v, double *part) {
+  __shared__ double s[VB / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < VB / 64; i++) t += s[i];
+    part[blockIdx.x] = t;
+  }
+}
+// res[0] = sqrt(sum part[0..np)) as fp32 (the reference's dnrm2 result type), res[1] = the sum
+__global__ void finish_norm(const double *part, int np, float *res, double *res_d) {
+  double t = 0.0;
+  for (int i = threadIdx.x; i < np; i += 64) t += part[i];
+  t = wave_sum(t);
+  if (threadIdx.x == 0) {
+    res[0] = (float)sqrt(t);
+    if (res_d) res_d[0] = t;
+  }
+}
+__global__ void k_sumsq(int64_t n, const float *x, double *part) {
+  double v = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) v += (double)x[i] * x[i];
+  block_partial(v, part);
+}
+// x *= sign/ (*d)   or  x *= sign * (*d)
+__global__ void k_scal_inv(int64_t n, float *x, const float *d, float sign) {
+  const float a = sign * (1.0f / d[0]);
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) x[i] = a * x[i];
+}
+__global__ void k_copy(int64_t n, const float *a, float *b) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) b[i] = a[i];
+}
+// hbar = h - f1*hbar ; x = x + f2*hbar ; h = v - f3*h ; partial of ||x||^2   (inv/lsmrModule.f90:539-541,590)
+__global__ void k_update(int64_t n, float f1, float f2, float f3, float *h, float *hbar, float *x,
+                         const float *v, double *part) {
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    const float hb = h[i] - f1 * hbar[i];
+    const float xn = x[i] + f2 * hb;
+    hbar[i] = hb;
+    x[i] = xn;
+    h[i] = v[i] - f3 * h[i];
+    sq += (double)xn * xn;
+  }
+  block_partial(sq, part);
+}
+// local reorthogonalisation step q (localVOrtho, inv/lsmrModule.f90:733-748), modified Gram-Schmidt:
+// d = sum(part_in) (the dot of v with lv_prev computed by the previous launch); v -= d*lv_prev;
+// part_out = partial dots of the updated v with lv_next.  lv_prev / lv_next may be null.
+__global__ void k_reorth(int64_t n, float *v, const float *lv_prev, const double *part_in, int np,
+                         const float *lv_next, double *part_out) {
+  __shared__ float s_d;
+  if (lv_prev) {
+    if (threadIdx.x < 64) {
+      double t = 0.0;
+      for (int i = threadIdx.x; i < np; i += 64) t += part_in[i];
+      t = wave_sum(t);
+      if (threadIdx.x == 0) s_d = (float)t;
+    }
+    __syncthreads();
+  }
+  const float d = lv_prev ? s_d : 0.0f;
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    float vi = v[i];
+    if (lv_prev) {
+      vi = vi - d * lv_prev[i];
+      v[i] = vi;
+    }
+    if (lv_next) acc += (double)vi * lv_next[i];
+  }
+  if (lv_next) block_partial(acc, part_out);
+}
+__global__ void k_scale_rows(int64_t nrows, const int64_t *ptr, float *val, const float *w) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * WPB + wv; r < nrows; r += (int64_t)gridDim.x * WPB) {
+    const float a = w[r];
+    for (int64_t i = ptr[r] + lane; i < ptr[r + 1]; i += 64) val[i] *= a;
+  }
+}
+__global__ void k_gather_f(int64_t n, const unsigned *perm, const float *src, float *dst) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]];
+}
+__global__ void k_gather_i(int64_t n, const unsigned *perm, const int *src, int *dst, int add) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]] + add;
+}
+__global__ void k_iota_keys(int64_t n, const int *one_based, unsigned *keys, unsigned *iota) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    keys[i] = (unsigned)(one_based[i] - 1);
+    iota[i] = (unsigned)i;
+  }
+}
+// ptr[r] = first position in the sorted key array whose key >= r  (r = 0..nrows)
+__global__ void k_lower_bound(int64_t nrows, int64_t nnz, const unsigned *keys, int64_t *ptr) {
+  for (int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x; r <= nrows; r += (int64_t)gridDim.x * VB) {
+    int64_t lo = 0, hi = nnz;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)keys[mid] < r) lo = mid + 1; else hi = mid;
+    }
+    ptr[r] = lo;
+  }
+}
+__global__ void k_check_range(int64_t n, const int *a, int lo, int hi, int *bad) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+    if (a[i] < lo || a[i] > hi) atomicOr(bad, 1);
+}
+
+inline int nblk(int64_t n, int cap = 2048) {
+  int64_t b = (n + VB - 1) / VB;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+int launch_spmv(dazim_ctx *ctx, int64_t nrows, const int64_t *ptr, const int *idx, const float *val,
+                const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
+                int nblocks) {
+  hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
+                     beta_p, beta_sign, sumsq);
+  DZ_HIP(hipGetLastError());
+  return 0;
+}
+int spmv_blocks(dazim_ctx *ctx, int64_t nrows) {
+  int64_t b = (nrows + WPB - 1) / WPB;
+  const int64_t cap = (int64_t)ctx->num_cu * 8;  // 8 workgroups (32 waves) per CU, grid-stride the rest
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
+  if (!A) return 0;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm};
+  for (void *p : ps)
+    if (p) (void)hipFree(p);
+  delete A;
+  return 0;
+}
+
+int dazim_csr_dims(const dazim_csr *A, int64_t *m, int64_t *n, int64_t *nnz) {
+  if (!A) return DAZIM_E_BAD_ARG;
+  if (m) *m = A->m;
+  if (n) *n = A->n;
+  if (nnz) *nnz = A->nnz;
+  return 0;
+}
+
+int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int *irow_u,
+                       const int *icol_u, const float *rw_u, dazim_csr **out) {
+  if (!ctx || !out || m < 1 || n < 1 || nnz < 0 || nnz > 0xfffffff0ll || m > 0x7ffffff0 || n > 0x7ffffff0)
+    return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_from_coo");
+  DZ_HIP(hipSetDevice(ctx->device));
+  DzBuf<int> irow, icol;
+  DzBuf<float> rw;
+  int rc;
+  if ((rc = irow.init(ctx, irow_u, nnz, true, false))) return rc;
+  if ((rc = icol.init(ctx, icol_u, nnz, true, false))) return rc;
+  if ((rc = rw.init(ctx, rw_u, nnz, true, false))) return rc;
+  dazim_csr *A = new dazim_csr;
+  A->m = m;
+  A->n = n;
+  A->nnz = nnz;
+  const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+  DZ_HIP(hipMalloc((void **)&A->rowptr, (m + 1) * 8));
+  DZ_HIP(hipMalloc((void **)&A->colptr, (n + 1) * 8));
+  DZ_HIP(hipMalloc((void **)&A->col, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->row, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->val, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->tval, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->tperm, nz * 4));
+  unsigned *k0, *k1, *v0, *perm;
+  int *bad;
+  void *p;
+  if ((rc = dz_scratch(ctx, "csr.k0", nz * 4, &p))) return rc;
+  k0 = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.k1", nz * 4, &p))) return rc;
+  k1 = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.v0", nz * 4, &p))) return rc;
+  v0 = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.perm", nz * 4, &p))) return rc;
+  perm = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.bad", 16, &p))) return rc;
+  bad = (int *)p;
+  DZ_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+  const int nb = nblk(nnz);
+  if (nnz > 0) {
+    hipLaunchKernelGGL(k_check_range, dim3(nb), dim3(VB), 0, ctx->stream, nnz, irow.dev, 1, (int)m, bad);
+    hipLaunchKernelGGL(k_check_range, dim3(nb), dim3(VB), 0, ctx->stream, nnz, icol.dev, 1, (int)n, bad);
+    int hbad = 0;
+    DZ_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (hbad) {
+      dazim_csr_free(ctx, A);
+      return dz_fail(ctx, DAZIM_E_BAD_ARG, "COO index outside 1..m / 1..n");
+    }
+    int rbits = 1, cbits = 1;
+    while (((int64_t)1 << rbits) < m) rbits++;
+    while (((int64_t)1 << cbits) < n) cbits++;
+    // ---- CSR: stable sort by row keeps the reference's within-row append order ----
+    hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, irow.dev, k0, v0);
+    size_t tb = 0;
+    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, perm, (size_t)nnz, 0, rbits, ctx->stream));
+    void *tmp;
+    if ((rc = dz_scratch(ctx, "csr.tmp", tb + 256, &tmp))) return rc;
+    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, perm, (size_t)nnz, 0, rbits, ctx->stream));
+    hipLaunchKernelGGL(k_lower_bound, dim3(nblk(m + 1)), dim3(VB), 0, ctx->stream, m, nnz, k1, A->rowptr);
+    hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, rw.dev, A->val);
+    hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, icol.dev, A->col, -1);
+    // row index of each CSR entry (0-based) = sorted keys k1
+    // ---- CSC: stable sort of the CSR-ordered entries by column -> rows ascend inside a column ----
+    unsigned *ck = k0;  // reuse: keys = CSR column
+    DZ_HIP(hipMemcpyAsync(ck, A->col, nz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    size_t tb2 = 0;
+    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb2, ck, perm, v0, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
+    if ((rc = dz_scratch(ctx, "csr.tmp", tb2 + 256, &tmp))) return rc;
+    // v0 is still iota (radix_sort_pairs does not modify its inputs)
+    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb2, ck, perm, v0, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
+    hipLaunchKernelGGL(k_lower_bound, dim3(nblk(n + 1)), dim3(VB), 0, ctx->stream, n, nnz, perm, A->colptr);
+    hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, A->val, A->tval);
+    hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, (const int *)k1, A->row, 0);
+    DZ_HIP(hipGetLastError());
+  } else {
+    DZ_HIP(hipMemsetAsync(A->rowptr, 0, (m + 1) * 8, ctx->stream));
+    DZ_HIP(hipMemsetAsync(A->colptr, 0, (n + 1) * 8, ctx->stream));
+  }
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  *out = A;
+  return 0;
+}
+
+int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
+  if (!ctx || !A || !w_u) return DAZIM_E_BAD_ARG;
+  DzBuf<float> w;
+  int rc;
+  if ((rc = w.init(ctx, w_u, A->m, true, false))) return rc;
+  hipLaunchKernelGGL(k_scale_rows, dim3(spmv_blocks(ctx, A->m)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, A->val, w.dev);
+  hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
+  DZ_HIP(hipGetLastError());
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// aprod, inv/aprod.f90:7
+int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float *y_u) {
+  if (!ctx || !A || !x_u || !y_u || (mode != 1 && mode != 2)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_aprod");
+  DZ_HIP(hipSetDevice(ctx->device));
+  DzBuf<float> x, y;
+  int rc;
+  if ((rc = x.init(ctx, x_u, A->n, true, mode == 2))) return rc;
+  if ((rc = y.init(ctx, y_u, A->m, true, mode == 1))) return rc;
+  if (mode == 1) {
+    DzTimer t(ctx, "spmv");
+    if ((rc = launch_spmv(ctx, A->m, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m)))) return rc;
+    t.stop();
+  } else {
+    DzTimer t(ctx, "spmvt");
+    if ((rc = launch_spmv(ctx, A->n, A->colptr, A->row, A->tval, y.dev, x.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->n)))) return rc;
+    t.stop();
+  }
+  if ((rc = x.finish()) || (rc = y.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// LSMR, inv/lsmrModule.f90:36-750.  Vectors live on the device; the scalar recurrences (plane
+// rotations, norm estimates, stopping rules) run on the host in fp32 exactly as written there.
+int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,
+               float conlim, int itnlim, int localSize, float *x_u, int *istop_o, int *itn_o,
+               float *normA_o, float *condA_o, float *normr_o, float *normAr_o, float *normx_o) {
+  if (!ctx || !A || !b_u || !x_u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_lsmr");
+  DZ_HIP(hipSetDevice(ctx->device));
+  const int64_t m = A->m, n = A->n;
+  DzBuf<float> b, x;
+  int rc;
+  if ((rc = b.init(ctx, b_u, m, true, false))) return rc;
+  if ((rc = x.init(ctx, x_u, n, false, true))) return rc;
+  int localVecs = localSize < 0 ? 0 : localSize;
+  if (m < localVecs) localVecs = (int)m;
+  if (n < localVecs) localVecs = (int)n;
+  void *p;
+  float *u, *v, *h, *hbar, *localV = nullptr, *d_scal;
+  double *part, *part2;
+  if ((rc = dz_scratch(ctx, "lsmr.u", m * 4, &p))) return rc;
+  u = (float *)p;
+  if ((rc = dz_scratch(ctx, "lsmr.v", n * 4, &p))) return rc;
+  v = (float *)p;
+  if ((rc = dz_scratch(ctx, "lsmr.h", n * 4, &p))) return rc;
+  h = (float *)p;
+  if ((rc = dz_scratch(ctx, "lsmr.hbar", n * 4, &p))) return rc;
+  hbar = (float *)p;
+  if (localVecs > 0) {
+    if ((rc = dz_scratch(ctx, "lsmr.localV", (size_t)n * localVecs * 4, &p))) return rc;
+    localV = (float *)p;
+  }
+  const int gm = spmv_blocks(ctx, m), gn = spmv_blocks(ctx, n);
+  const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
+  if ((rc = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return rc;
+  part = (double *)p;
+  if ((rc = dz_scratch(ctx, "lsmr.part2", (size_t)NPART * 8 * 2, &p))) return rc;
+  part2 = (double *)p;
+  if ((rc = dz_scratch(ctx, "lsmr.scal", 64, &p))) return rc;
+  d_scal = (float *)p;  // [0] = last norm (beta or alpha), kept on the device for the next kernel
+  float *h_scal;
+  DZ_HIP(hipHostMalloc((void **)&h_scal, 64));
+  auto norm_to_host = [&](const double *pp, int np, float *res) -> int {
+    hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, (double *)nullptr);
+    DZ_HIP(hipMemcpyAsync(h_scal, d_scal, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    *res = h_scal[0];
+    return 0;
+  };
+  const int bn = nblk(n, NPART), bm = nblk(m, NPART);
+  hipEvent_t e0, e1;
+  DZ_HIP(hipEventCreate(&e0));
+  DZ_HIP(hipEventCreate(&e1));
+  DZ_HIP(hipEventRecord(e0, ctx->stream));
+  double t_spmv = 0, t_spmvt = 0;
+  int n_spmv = 0, n_spmvt = 0;
+  auto timed_spmv = [&](bool transpose, const float *beta_p, float sign) -> int {
+    hipEvent_t a = ctx->ev0, bq = ctx->ev1;
+    DZ_HIP(hipEventRecord(a, ctx->stream));
+    int r;
+    if (!transpose)
+      r = launch_spmv(ctx, m, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
+    else
+      r = launch_spmv(ctx, n, A->colptr, A->row, A->tval, u, v, beta_p, sign, part, gn);
+    if (r) return r;
+    DZ_HIP(hipEventRecord(bq, ctx->stream));
+    DZ_HIP(hipEventSynchronize(bq));
+    float ms = 0;
+    DZ_HIP(hipEventElapsedTime(&ms, a, bq));
+    if (transpose) { t_spmvt += ms * 1e-3; n_spmvt++; } else { t_spmv += ms * 1e-3; n_spmv++; }
+    return 0;
+  };
+
+  int istop = 0, itn = 0;
+  float normA = 0, condA = 0, normr = 0, normAr = 0, normx = 0;
+  // u = b ; beta = ||u|| ; u /= beta ; v = A^T u ; alpha = ||v|| ; v /= alpha   (:355-372)
+  hipLaunchKernelGGL(k_copy, dim3(bm), dim3(VB), 0, ctx->stream, m, b.dev, u);
+  DZ_HIP(hipMemsetAsync(v, 0, n * 4, ctx->stream));
+  DZ_HIP(hipMemsetAsync(x.dev, 0, n * 4, ctx->stream));
+  DZ_HIP(hipMemsetAsync(hbar, 0, n * 4, ctx->stream));
+  hipLaunchKernelGGL(k_sumsq, dim3(bm), dim3(VB), 0, ctx->stream, m, u, part);
+  float alpha = 0.0f, beta = 0.0f;
+  if ((rc = norm_to_host(part, bm, &beta))) return rc;
+  if (beta > 0.0f) {
+    hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
+    if ((rc = timed_spmv(true, nullptr, 1.0f))) return rc;  // v = 1*v(=0) + A^T u
+    if ((rc = norm_to_host(part, gn, &alpha))) return rc;
+  }
+  if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
+  normAr = alpha * beta;
+  if (normAr != 0.0f) {
+    bool localOrtho = false, localVQueueFull = false;
+    int localPointer = 0;
+    if (localVecs > 0) {
+      localPointer = 1;
+      localOrtho = true;
+      hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, localV);
+    }
+    float zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, h);
+    float betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
+    float normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e+30f, normb = beta, ctol = 0;
+    if (conlim > 0.0f) ctol = 1.0f / conlim;
+    normr = beta;
+    auto d2norm = [](float a, float bb) -> float {  // :708-721
+      const float scale = fabsf(a) + fabsf(bb);
+      if (scale == 0.0f) return 0.0f;
+      return scale * sqrtf((a / scale) * (a / scale) + (bb / scale) * (bb / scale));
+    };
+    for (;;) {
+      itn++;
+      // u = A v - alpha u ; beta = ||u||   (:484-487; d_scal[0] holds alpha)
+      if ((rc = timed_spmv(false, d_scal, -1.0f))) return rc;
+      if ((rc = norm_to_host(part, gm, &beta))) return rc;
+      if (beta > 0.0f) {
+        hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
+        if (localOrtho) {  // localVEnqueue :723-731
+          if (localPointer < localVecs)
+            localPointer++;
+          else {
+            localPointer = 1;
+            localVQueueFull = true;
+          }
+          hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, localV + (size_t)(localPointer - 1) * n);
+        }
+        // v = A^T u - beta v   (:496-497; d_scal[0] holds beta)
+        if ((rc = timed_spmv(true, d_scal, -1.0f))) return rc;
+        if (localOrtho) {  // localVOrtho :733-748 (modified Gram-Schmidt, one launch per vector)
+          const int lim = localVQueueFull ? localVecs : localPointer;
+          for (int q = 0; q <= lim; q++) {
+            const float *prev = q > 0 ? localV + (size_t)(q - 1) * n : nullptr;
+            const float *next = q < lim ? localV + (size_t)q * n : nullptr;
+            hipLaunchKernelGGL(k_reorth, dim3(bn), dim3(VB), 0, ctx->stream, n, v, prev, part2 + ((q + 1) & 1) * NPART, bn,
+                               next, part2 + (q & 1) * NPART);
+          }
+          hipLaunchKernelGGL(k_sumsq, dim3(bn), dim3(VB), 0, ctx->stream, n, v, part);
+          if ((rc = norm_to_host(part, bn, &alpha))) return rc;
+        } else {
+          if ((rc = norm_to_host(part, gn, &alpha))) return rc;
+        }
+        if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
+      }
+      if (!(beta > 0.0f) || !(alpha > 0.0f)) {  // keep the device copy of alpha valid for the next product
+        h_scal[8] = alpha;
+        DZ_HIP(hipMemcpyAsync(d_scal, h_scal + 8, 4, hipMemcpyHostToDevice, ctx->stream));
+      }
+      // ---- scalar recurrences, verbatim order of :506-588 ----
+      const float alphahat = d2norm(alphabar, damp);
+      const float chat = alphabar / alphahat, shat = damp / alphahat;
+      const float rhoold = rho;
+      rho = d2norm(alphahat, beta);
+      const float c = alphahat / rho, s = beta / rho;
+      const float thetanew = s * alpha;
+      alphabar = c * alpha;
+      const float rhobarold = rhobar, zetaold = zeta;
+      const float thetabar = sbar * rho, rhotemp = cbar * rho;
+      rhobar = d2norm(cbar * rho, thetanew);
+      cbar = cbar * rho / rhobar;
+      sbar = thetanew / rhobar;
+      zeta = cbar * zetabar;
+      zetabar = -sbar * zetabar;
+      const float f1 = thetabar * rho / (rhoold * rhobarold), f2 = zeta / (rho * rhobar), f3 = thetanew / rho;
+      hipLaunchKernelGGL(k_update, dim3(bn), dim3(VB), 0, ctx->stream, n, f1, f2, f3, h, hbar, x.dev, v, part);
+      // k_update must not clobber d_scal (alpha) before the next product reads it: keep normx separately
+      hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, part, bn, d_scal + 4, (double *)nullptr);
+      DZ_HIP(hipMemcpyAsync(h_scal + 4, d_scal + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
+      const float betaacute = chat * betadd, betacheck = -shat * betadd;
+      const float betahat = c * betaacute;
+      betadd = -s * betaacute;
+      const float thetatildeold = thetatilde;
+      const float rhotildeold = d2norm(rhodold, thetabar);
+      const float ctildeold = rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
+      thetatilde = stildeold * rhobar;
+      rhodold = ctildeold * rhobar;
+      betad = -stildeold * betad + ctildeold * betahat;
+      tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+      const float taud = (zeta - thetatilde * tautildeold) / rhodold;
+      d = d + betacheck * betacheck;
+      normr = sqrtf(d + (betad - taud) * (betad - taud) + betadd * betadd);
+      normA2 = normA2 + beta * beta;
+      normA = sqrtf(normA2);
+      normA2 = normA2 + alpha * alpha;
+      maxrbar = fmaxf(maxrbar, rhobarold);
+      if (itn > 1) minrbar = fminf(minrbar, rhobarold);
+      condA = fmaxf(maxrbar, rhotemp) / fminf(minrbar, rhotemp);
+      normAr = fabsf(zetabar);
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      normx = h_scal[4];
+      const float test1 = normr / normb, test2 = normAr / (normA * normr), test3 = 1.0f / condA;
+      const float t1 = test1 / (1.0f + normA * normx / normb);
+      const float rtol = btol + atol * normA * normx / normb;
+      if (itn >= itnlim) istop = 7;
+      if (1.0f + test3 <= 1.0f) istop = 6;
+      if (1.0f + test2 <= 1.0f) istop = 5;
+      if (1.0f + t1 <= 1.0f) istop = 4;
+      if (test3 <= ctol) istop = 3;
+      if (test2 <= atol) istop = 2;
+      if (test1 <= rtol) istop = 1;
+      if (istop != 0) break;
+    }
+  }
+  if (damp > 0.0f && istop == 2) istop = 3;  // :686
+  DZ_HIP(hipEventRecord(e1, ctx->stream));
+  DZ_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  DZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  ctx->ksec["lsmr"] = ms * 1e-3;
+  ctx->ksec["spmv"] = n_spmv ? t_spmv / n_spmv : -1.0;
+  ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipHostFree(h_scal);
+  if (istop_o) *istop_o = istop;
+  if (itn_o) *itn_o = itn;
+  if (normA_o) *normA_o = normA;
+  if (condA_o) *condA_o = condA;
+  if (normr_o) *normr_o = normr;
+  if (normAr_o) *normAr_o = normAr;
+  if (normx_o) *normx_o = normx;
+  if ((rc = x.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -92,6 +92,29 @@ int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float gozd, floa
                     const int *period_idx, float *veln, float *ttn, float *ttnr, int *nstsr,
                     dazim_refbox *boxes, int *status);
 
+/* ---- K6/K7: sparse matrix + LSMR ----------------------------------------------------------------
+ * The reference stores G as COO triplets rw / iw(2:nar+1) rows / iw(nar+2:2nar+1) cols
+ * (inv/aprod.f90:20-24).  dazim_csr keeps the same matrix on the device twice: CSR for A*x and the
+ * stable transpose (CSC) for A^T*y, fp32 values + int32 indices, int64 pointers.               */
+typedef struct dazim_csr dazim_csr;
+
+/* build from the reference's COO arrays (1-based irow/icol, rows need not be sorted).  nnz order
+ * inside a row is kept, so sums run over the row in the order the reference appended it.        */
+int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int *irow,
+                       const int *icol, const float *rw, dazim_csr **A);
+int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A);
+int dazim_csr_dims(const dazim_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
+/* multiply every stored entry of row i by w[i] (rw(i)=rw(i)*datweight(iw(1+i)), inv/Main_Jt.f90:467) */
+int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w);
+
+/* = aprod (inv/aprod.f90:7): mode 1: y(m) += A*x(n) ; mode 2: x(n) += A^T*y(m)                    */
+int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y);
+
+/* = LSMR (inv/lsmrModule.f90:36), fp32 like the reference; b[m] in, x[n] out.                     */
+int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,
+               float btol, float conlim, int itnlim, int localSize, float *x, int *istop, int *itn,
+               float *normA, float *condA, float *normr, float *normAr, float *normx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,120 @@
+"""-m gpu: aprod (SpMV both ways) and LSMR on the device against the CPU oracle.
+
+Tolerances: the products sum in a different order than the reference's serial COO
+loop, so y is compared with rel-L2 <= 2e-6 per product (fp32 round-off of O(sqrt(nnz/row)) terms);
+LSMR `x` with rel-L2 <= 1e-3 and `itn` within +-3 of the oracle for identical (A, b).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_system(m, n, per_row, seed, tikh_rows=0):
+    rng = np.random.default_rng(seed)
+    rows, cols, vals = [], [], []
+    for r in range(m):
+        k = int(rng.integers(max(1, per_row // 2), per_row * 2))
+        k = min(k, n)
+        start = int(rng.integers(0, n))
+        c = np.unique((start + np.cumsum(rng.integers(1, 4, k))) % n)
+        rows.append(np.full(len(c), r + 1)); cols.append(c + 1)
+        vals.append(-np.abs(rng.standard_normal(len(c))) * 0.3 - 1e-3)
+    for t in range(tikh_rows):
+        rows.append(np.array([m + t + 1])); cols.append(np.array([t % n + 1])); vals.append(np.array([2.0]))
+    irow = np.concatenate(rows).astype(np.int32)
+    icol = np.concatenate(cols).astype(np.int32)
+    rw = np.concatenate(vals).astype(np.float32)
+    return irow, icol, rw, m + tikh_rows
+
+
+@pytest.mark.parametrize("m,n,per_row", [(300, 200, 9), (1000, 675, 120), (5000, 3000, 700), (64, 4096, 3)])
+def test_aprod_matches_oracle(ctx, orc, m, n, per_row):
+    irow, icol, rw, mm = random_system(m, n, per_row, seed=m + n)
+    A = ctx.csr_from_coo(mm, n, irow, icol, rw)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(n).astype(np.float32)
+    y0 = rng.standard_normal(mm).astype(np.float32)
+    y_gpu, y_cpu = y0.copy(), y0.copy()
+    ctx.aprod(1, A, x, y_gpu)
+    orc.aprod(1, mm, n, x.copy(), y_cpu, irow, icol, rw)
+    assert np.linalg.norm(y_gpu - y_cpu) <= 2e-6 * np.linalg.norm(y_cpu)
+    x_gpu, x_cpu = x.copy(), x.copy()
+    ctx.aprod(2, A, x_gpu, y0.copy())
+    orc.aprod(2, mm, n, x_cpu, y0.copy(), irow, icol, rw)
+    assert np.linalg.norm(x_gpu - x_cpu) <= 2e-6 * np.linalg.norm(x_cpu)
+    A.free()
+
+
+def test_aprod_unsorted_rows_and_empty_rows(ctx, orc):
+    """COO rows in arbitrary order, rows/columns with no entry at all, duplicate (row,col) pairs"""
+    rng = np.random.default_rng(4)
+    m, n, nnz = 50, 40, 400
+    irow = rng.integers(1, m - 5, nnz).astype(np.int32)   # last rows stay empty
+    icol = rng.integers(3, n + 1, nnz).astype(np.int32)   # first columns stay empty
+    rw = rng.standard_normal(nnz).astype(np.float32)
+    A = ctx.csr_from_coo(m, n, irow, icol, rw)
+    x = rng.standard_normal(n).astype(np.float32); y = np.zeros(m, np.float32); y2 = y.copy()
+    ctx.aprod(1, A, x, y); orc.aprod(1, m, n, x.copy(), y2, irow, icol, rw)
+    assert np.allclose(y, y2, rtol=1e-5, atol=1e-5)
+    yy = rng.standard_normal(m).astype(np.float32); xx = np.zeros(n, np.float32); xx2 = xx.copy()
+    ctx.aprod(2, A, xx, yy); orc.aprod(2, m, n, xx2, yy.copy(), irow, icol, rw)
+    assert np.allclose(xx, xx2, rtol=1e-5, atol=1e-5)
+    A.free()
+
+
+def test_csr_rejects_bad_index(ctx):
+    import dazimsurftomo_amd as dz
+    with pytest.raises(dz.DazimError):
+        ctx.csr_from_coo(3, 3, np.array([1, 4], np.int32), np.array([1, 1], np.int32), np.array([1, 1], np.float32))
+
+
+@pytest.mark.parametrize("cfg", [dict(atol=1e-3, btol=1e-3, conlim=1200, itnlim=1000, ls=None),   # iso, inv/Main_Jt.f90:542-547
+                                 dict(atol=1e-5, btol=1e-4, conlim=200, itnlim=500, ls=10)])      # joint, :549-553
+def test_lsmr_matches_oracle(ctx, orc, cfg):
+    m0, n = 1500, 675
+    irow, icol, rw, m = random_system(m0, n, 130, seed=9, tikh_rows=n)
+    rng = np.random.default_rng(2)
+    b = np.zeros(m, np.float32); b[:m0] = rng.standard_normal(m0).astype(np.float32)
+    ls = cfg["ls"] if cfg["ls"] is not None else n // 4
+    A = ctx.csr_from_coo(m, n, irow, icol, rw)
+    x, info = ctx.lsmr(A, b, 0.01, cfg["atol"], cfg["btol"], cfg["conlim"], cfg["itnlim"], ls)
+    xo, io = orc.lsmr(m, n, irow, icol, rw, b, 0.01, cfg["atol"], cfg["btol"], cfg["conlim"], cfg["itnlim"], ls)
+    assert info["istop"] == io["istop"]
+    assert abs(info["itn"] - io["itn"]) <= 3
+    assert np.linalg.norm(x - xo) <= 1e-3 * np.linalg.norm(xo)
+    assert abs(info["normr"] - io["normr"]) <= 1e-3 * io["normr"]
+    assert abs(info["normA"] - io["normA"]) <= 1e-2 * io["normA"]
+    # residual property, independent of the oracle: A^T(b - A x) is small relative to |A||r|
+    r = b.copy(); tmp = np.zeros(m, np.float32)
+    orc.aprod(1, m, n, x.copy(), tmp, irow, icol, rw); r -= tmp
+    g = np.zeros(n, np.float32); orc.aprod(2, m, n, g, r, irow, icol, rw)
+    g -= np.float32(0.01) ** 2 * x
+    assert np.linalg.norm(g) <= max(cfg["atol"], 2e-3) * info["normA"] * np.linalg.norm(r) * 5
+    A.free()
+
+
+def test_lsmr_zero_rhs(ctx):
+    irow, icol, rw, m = random_system(40, 30, 5, seed=3)
+    A = ctx.csr_from_coo(m, 30, irow, icol, rw)
+    x, info = ctx.lsmr(A, np.zeros(m, np.float32), 0.0, 1e-6, 1e-6, 1e8, 100, 0)
+    assert info["istop"] == 0 and info["itn"] == 0 and not x.any()  # 'The exact solution is x = 0'
+    A.free()
+
+
+def test_scale_rows(ctx, orc):
+    irow, icol, rw, m = random_system(200, 100, 20, seed=6)
+    A = ctx.csr_from_coo(m, 100, irow, icol, rw)
+    w = (np.random.default_rng(0).random(m) + 0.5).astype(np.float32)
+    A.scale_rows(w)
+    rw2 = (rw * w[irow - 1]).astype(np.float32)   # inv/Main_Jt.f90:467-469
+    x = np.random.default_rng(1).standard_normal(100).astype(np.float32)
+    for mode in (1, 2):
+        a = np.zeros(m if mode == 1 else 100, np.float32); b_ = a.copy()
+        if mode == 1:
+            ctx.aprod(1, A, x, a); orc.aprod(1, m, 100, x.copy(), b_, irow, icol, rw2)
+        else:
+            yv = np.random.default_rng(2).standard_normal(m).astype(np.float32)
+            ctx.aprod(2, A, a, yv); orc.aprod(2, m, 100, b_, yv.copy(), irow, icol, rw2)
+        assert np.allclose(a, b_, rtol=2e-5, atol=1e-5)
+    A.free()
