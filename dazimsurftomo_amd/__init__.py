@@ -92,6 +92,33 @@ class Context:
     def sync(self):
         self._check(self.lib.dazim_sync(self._h))
 
+    # ---- K1 ---------------------------------------------------------------------------------
+    def depthkernel(self, vel, depz, tRc, minthk, kernels=True, pv=None, sen=None):
+        """depthkernel (inv/CalSurfG.f90:1): vel[nz][ny][nx] -> pvRc[kmax][nx*ny] and, if `kernels`,
+        (sen_vs, sen_vp, sen_rho)[nz][kmax][nx*ny].  Returns (pv, sen, n_failed)."""
+        nz, ny, nx = vel.shape
+        depz = np.ascontiguousarray(depz, np.float32)
+        tRc = np.ascontiguousarray(tRc, np.float64)
+        kmax = len(tRc)
+        if _is_torch(vel):
+            import torch
+            if pv is None:
+                pv = torch.empty((kmax, nx * ny), dtype=torch.float64, device=vel.device)
+            if kernels and sen is None:
+                sen = [torch.empty((nz, kmax, nx * ny), dtype=torch.float64, device=vel.device) for _ in range(3)]
+        else:
+            vel = np.ascontiguousarray(vel, np.float32)
+            if pv is None:
+                pv = np.zeros((kmax, nx * ny), np.float64)
+            if kernels and sen is None:
+                sen = [np.zeros((nz, kmax, nx * ny), np.float64) for _ in range(3)]
+        nf = C.c_int(0)
+        sp = [_ptr(a) for a in sen] if kernels else [None] * 3
+        rc = self.lib.dazim_dispersion_kernels(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk),
+                                               kmax, _ptr(tRc), _ptr(pv), sp[0], sp[1], sp[2], C.byref(nf))
+        self._check(rc)
+        return pv, (sen if kernels else None), nf.value
+
     # ---- K2+K3 -----------------------------------------------------------------------------
     def fmm_batch(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, period_idx,
                   veln=None, ttn=None, ttnr=None, nstsr=None, boxes=None, status=None,

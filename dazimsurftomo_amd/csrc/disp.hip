@@ -1,0 +1,596 @@
+// disp.hip -- K1 of SURVEY.md: Rayleigh fundamental-mode phase velocities (surfdisp96,
+// inv/surfdisp96.f:52-1062) and their finite-difference depth kernels (depthkernel,
+// inv/CalSurfG.f90:1-139) for every model column, on gfx950.
+//
+// Work item = (column, variant): variant 0 is the column itself, the other 6*nz are its +-0.5 %
+// perturbations of one knot's Vs, Vp or rho.  One lane per work item; lanes of a wavefront run the
+// reference's bracket + Neville root search as independent state machines that meet at the only
+// expensive step, the Dunkin compound-matrix secular function (dltar4), which all lanes evaluate
+// in lockstep (uniform trip count = number of layers).  Nothing per-lane is indexed dynamically:
+// the layer stack is rebuilt on the fly from the column's knots (LDS, broadcast reads) with the
+// lane's single perturbed knot patched in, and the Earth-flattening factors, which depend on the
+// layer thicknesses only, come from a host table (same libm log/powf the CPU reference calls).
+// fp64 VALU + transcendental bound; no MFMA, negligible HBM traffic.
+#include <cmath>
+
+#include "dazim_internal.h"
+
+namespace {
+
+constexpr int NL = 200;       // inv/surfdisp96.f:57
+constexpr int NP = 60;        // inv/surfdisp96.f:59
+constexpr int NZMAX = 64;     // knots per column we accept
+constexpr int DT = 128;       // threads per workgroup
+constexpr int NEVN = 11;      // Neville points kept (x(1..11), inv/surfdisp96.f:569,655)
+
+struct Layer {   // per refined layer, geometry only
+  double tmp;    // (ar+ar)/(r0+r1), sphere() :528
+  float d;       // flattened thickness, :524
+  float rfac;    // btp**(-2.275), :541
+  float fm, den; // (2j-1), 2*nsublay of refineGrid2LayerMdl (inv/CalSurfG.f90:2352)
+  int iv;        // interval (1-based knot index i); 0 for the half-space
+};
+
+struct DispArgs {
+  int ncol, nz, kmax, nvar, mmax;
+  const float *vel;  // [nz][ncol]
+  const Layer *lay;  // [mmax]
+  const double *t;   // [kmax]
+  float *cg;         // [ncol*nvar][kmax]
+};
+
+__device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
+
+struct Knots {           // one lane's view of its column
+  const float *vs, *vp, *rho;  // LDS, [nz] each
+  int pi, pq;                  // perturbed knot (1-based) and quantity (0 vs, 1 vp, 2 rho); pi=0: none
+  float pv;                    // perturbed value
+  __device__ __forceinline__ float get(int q, int i) const {
+    const float *b = q == 0 ? vs : (q == 1 ? vp : rho);
+    const float v = b[i - 1];
+    return (i == pi && q == pq) ? pv : v;
+  }
+};
+
+// flattened layer m (1-based): Vp a, Vs b, density rho, thickness d as surfdisp96 holds them after
+// refineGrid2LayerMdl + sphere(0,0) + sphere(2,1)
+__device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, int m, int nz, float &a,
+                                            float &b, float &rho, float &d) {
+  const Layer L = lay[m - 1];
+  float rvp, rvs, rrho;
+  if (L.iv > 0) {
+    const int i = L.iv;
+    const float p0 = K.get(1, i), p1 = K.get(1, i + 1);
+    const float s0 = K.get(0, i), s1 = K.get(0, i + 1);
+    const float r0 = K.get(2, i), r1 = K.get(2, i + 1);
+    rvp = p0 + L.fm * (p1 - p0) / L.den;
+    rvs = s0 + L.fm * (s1 - s0) / L.den;
+    rrho = r0 + L.fm * (r1 - r0) / L.den;
+  } else {
+    rvp = K.get(1, nz);
+    rvs = K.get(0, nz);
+    rrho = K.get(2, nz);
+  }
+  a = (float)((double)rvp * L.tmp);
+  b = (float)((double)rvs * L.tmp);
+  rho = rrho * L.rfac;
+  d = L.d;
+}
+
+// inv/surfdisp96.f:767-865 with var (:868-985), dnka (:1018-1062) and normc (:989-1014) inlined;
+// llw = 1 (no water layer).  normc's log() is dead in the reference and dropped.
+__device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, double wvno, double omga) {
+  double e0, e1, e2, e3, e4;
+  double omega = omga;
+  if (omega < 1.0e-4) omega = 1.0e-4;
+  const double wvno2 = wvno * wvno;
+  float fa, fb, frho, fd;
+  layer_model(K, lay, mmax, nz, fa, fb, frho, fd);
+  {
+    const double xka = omega / (double)fa, xkb = omega / (double)fb;
+    double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
+    const double ra = sqrt(wvnop * wvnom);
+    wvnop = wvno + xkb;
+    wvnom = fabs(wvno - xkb);
+    const double rb = sqrt(wvnop * wvnom);
+    const double t = (double)fb / omega;
+    const double gammk = 2.0 * t * t;
+    const double gam = gammk * wvno2;
+    const double gamm1 = gam - 1.0;
+    const double rho1 = (double)frho;
+    e0 = rho1 * rho1 * (gamm1 * gamm1 - gam * gammk * ra * rb);
+    e1 = -rho1 * ra;
+    e2 = rho1 * (gamm1 - gammk * ra * rb);
+    e3 = rho1 * rb;
+    e4 = wvno2 - ra * rb;
+  }
+  for (int m = mmax - 1; m >= 1; m--) {
+    layer_model(K, lay, m, nz, fa, fb, frho, fd);
+    const double xka = omega / (double)fa, xkb = omega / (double)fb;
+    const double t = (double)fb / omega;
+    const double gammk = 2.0 * t * t;
+    const double gam = gammk * wvno2;
+    double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
+    const double ra = sqrt(wvnop * wvnom);
+    wvnop = wvno + xkb;
+    wvnom = fabs(wvno - xkb);
+    const double rb = sqrt(wvnop * wvnom);
+    const double dpth = (double)fd, rho1 = (double)frho;
+    const double p = ra * dpth, q = rb * dpth;
+    double w, x, y, z, cosp, cosq, sinp, sinq, fac, pex = 0.0, sex = 0.0;
+    if (wvno < xka) {
+      sinp = sin(p);
+      w = sinp / ra;
+      x = -ra * sinp;
+      cosp = cos(p);
+    } else if (wvno == xka) {
+      cosp = 1.0;
+      w = dpth;
+      x = 0.0;
+    } else {
+      pex = p;
+      fac = 0.0;
+      if (p < 16) fac = exp(-2.0 * p);
+      cosp = (1.0 + fac) * 0.5;
+      sinp = (1.0 - fac) * 0.5;
+      w = sinp / ra;
+      x = ra * sinp;
+    }
+    if (wvno < xkb) {
+      sinq = sin(q);
+      y = sinq / rb;
+      z = -rb * sinq;
+      cosq = cos(q);
+    } else if (wvno == xkb) {
+      cosq = 1.0;
+      y = dpth;
+      z = 0.0;
+    } else {
+      sex = q;
+      fac = 0.0;
+      if (q < 16) fac = exp(-2.0 * q);
+      cosq = (1.0 + fac) * 0.5;
+      sinq = (1.0 - fac) * 0.5;
+      y = sinq / rb;
+      z = rb * sinq;
+    }
+    const double exa = pex + sex;
+    double a0 = 0.0;
+    if (exa < 60.0) a0 = exp(-exa);
+    const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
+    const double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
+    const double gamm1 = gam - 1.0;
+    const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1, gm1sq = gamm1 * gamm1;
+    const double rho2 = rho1 * rho1, a0pq = a0 - cpcq;
+    const double ca11 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - wvno2 * gm1sq * wy;
+    const double ca12 = (wvno2 * cpy - cqx) / rho1;
+    const double ca13 = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) / rho1;
+    const double ca14 = (cpz - wvno2 * cqw) / rho1;
+    const double ca15 = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) / rho2;
+    const double ca21 = (gmgmk * cpz - gm1sq * cqw) * rho1;
+    const double ca22 = cpcq;
+    const double ca23 = gammk * cpz - gamm1 * cqw;
+    const double ca24 = -wz;
+    const double ca25 = ca14;
+    const double ca41 = (gm1sq * cpy - gmgmk * cqx) * rho1;
+    const double ca42 = -xy;
+    const double ca43 = gamm1 * cpy - gammk * cqx;
+    const double ca44 = ca22;
+    const double ca45 = ca12;
+    const double ca51 = -(2.0 * gmgmk * gm1sq * a0pq + gmgmk * gmgmk * xz + gm1sq * gm1sq * wy) * rho2;
+    const double ca52 = ca41;
+    const double ca53 = -(gammk * gamm1 * twgm1 * a0pq + gam * gammk * gammk * xz + gamm1 * gm1sq * wy) * rho1;
+    const double ca54 = ca21;
+    const double ca55 = ca11;
+    const double tt = -2.0 * wvno2;
+    const double ca31 = tt * ca53, ca32 = tt * ca43, ca33 = a0 + 2.0 * (cpcq - ca11), ca34 = tt * ca23,
+                 ca35 = tt * ca13;
+    // ee(i) = sum_j e(j)*ca(j,i), accumulated from 0 in the order j = 1..5 (:832-838)
+    double n0 = 0.0 + e0 * ca11;  n0 = n0 + e1 * ca21;  n0 = n0 + e2 * ca31;  n0 = n0 + e3 * ca41;  n0 = n0 + e4 * ca51;
+    double n1 = 0.0 + e0 * ca12;  n1 = n1 + e1 * ca22;  n1 = n1 + e2 * ca32;  n1 = n1 + e3 * ca42;  n1 = n1 + e4 * ca52;
+    double n2 = 0.0 + e0 * ca13;  n2 = n2 + e1 * ca23;  n2 = n2 + e2 * ca33;  n2 = n2 + e3 * ca43;  n2 = n2 + e4 * ca53;
+    double n3 = 0.0 + e0 * ca14;  n3 = n3 + e1 * ca24;  n3 = n3 + e2 * ca34;  n3 = n3 + e3 * ca44;  n3 = n3 + e4 * ca54;
+    double n4 = 0.0 + e0 * ca15;  n4 = n4 + e1 * ca25;  n4 = n4 + e2 * ca35;  n4 = n4 + e3 * ca45;  n4 = n4 + e4 * ca55;
+    double t1 = 0.0;
+    if (fabs(n0) > t1) t1 = fabs(n0);
+    if (fabs(n1) > t1) t1 = fabs(n1);
+    if (fabs(n2) > t1) t1 = fabs(n2);
+    if (fabs(n3) > t1) t1 = fabs(n3);
+    if (fabs(n4) > t1) t1 = fabs(n4);
+    if (t1 < 1.e-40) t1 = 1.0;
+    e0 = n0 / t1;
+    e1 = n1 / t1;
+    e2 = n2 / t1;
+    e3 = n3 / t1;
+    e4 = n4 / t1;
+  }
+  return e0;
+}
+
+// inv/surfdisp96.f:361-382, all fp32
+__device__ float gtsolh(float a, float b) {
+  float c = 0.95f * b;
+  for (int i = 0; i < 5; i++) {
+    const float gamma = b / a;
+    const float kappa = c / b;
+    const float k2 = kappa * kappa;
+    const float gk2 = (gamma * kappa) * (gamma * kappa);
+    const float fac1 = sqrtf(1.0f - gk2);
+    const float fac2 = sqrtf(1.0f - k2);
+    const float fr = (2.0f - k2) * (2.0f - k2) - 4.0f * fac1 * fac2;
+    float frp = -4.0f * (2.0f - k2) * kappa + 4.0f * fac2 * gamma * gamma * kappa / fac1 + 4.0f * fac1 * kappa / fac2;
+    frp = frp / b;
+    c = c - fr / frp;
+  }
+  return c;
+}
+
+__device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // inv/CalSurfG.f90:49-53
+  const float v2 = vs * vs, v3 = v2 * vs, v4 = v3 * vs;
+  const float p = 0.9409f + 2.0947f * vs - 0.8206f * v2 + 0.2683f * v3 - 0.0251f * v4;
+  const float p2 = p * p, p3 = p2 * p, p4 = p3 * p, p5 = p4 * p;
+  vp = p;
+  rho = 1.6612f * p - 0.4721f * p2 + 0.0671f * p3 - 0.0043f * p4 + 0.000106f * p5;
+}
+
+enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
+
+__global__ __launch_bounds__(DT) void disp_kernel(DispArgs A) {
+  __shared__ Layer s_lay[NL];
+  __shared__ double s_t[NP];
+  extern __shared__ __attribute__((aligned(16))) float s_knot[];  // [cpb][3][nz]
+  __shared__ double s_x[NEVN][DT], s_y[NEVN][DT];
+  const int tid = threadIdx.x;
+  const int nz = A.nz, kmax = A.kmax, mmax = A.mmax, nvar = A.nvar;
+  const long w0 = (long)blockIdx.x * DT;
+  const long nwork = (long)A.ncol * nvar;
+  const int col0 = (int)(w0 / nvar);
+  for (int i = tid; i < mmax; i += DT) s_lay[i] = A.lay[i];
+  for (int i = tid; i < kmax; i += DT) s_t[i] = A.t[i];
+  const int cpb = (DT + nvar - 1) / nvar + 1;  // columns this workgroup's work items may span
+  for (int i = tid; i < cpb * nz; i += DT) {
+    const int c = i / nz, k = i - c * nz, col = col0 + c;
+    if (col < A.ncol) {
+      const float vs = A.vel[(size_t)k * A.ncol + col];
+      float vp, rho;
+      brocher(vs, vp, rho);
+      s_knot[(c * 3 + 0) * nz + k] = vs;
+      s_knot[(c * 3 + 1) * nz + k] = vp;
+      s_knot[(c * 3 + 2) * nz + k] = rho;
+    }
+  }
+  __syncthreads();
+  const long w = w0 + tid;
+  const bool active = w < nwork;
+  const int col = active ? (int)(w / nvar) : col0;
+  const int var = active ? (int)(w - (long)col * nvar) : 0;
+  Knots K;
+  K.vs = s_knot + ((col - col0) * 3 + 0) * nz;
+  K.vp = s_knot + ((col - col0) * 3 + 1) * nz;
+  K.rho = s_knot + ((col - col0) * 3 + 2) * nz;
+  K.pi = 0;
+  K.pq = -1;
+  K.pv = 0.0f;
+  if (var > 0) {  // depthkernel's perturbation order: knot i, then (vs,vp,rho), then (-,+)  (:76-124)
+    const int v1 = var - 1;
+    K.pi = v1 / 6 + 1;
+    const int r = v1 - (K.pi - 1) * 6;
+    K.pq = r >> 1;
+    const float b0 = (K.pq == 0 ? K.vs : (K.pq == 1 ? K.vp : K.rho))[K.pi - 1];
+    const float dln = 0.01f;
+    K.pv = (r & 1) ? b0 + 0.5f * dln * b0 : b0 - 0.5f * dln * b0;
+  }
+  // ---- start-up of surfdisp96 (:134-216): extremal velocities, half-space start value ----
+  float betmx = -1.e20f, betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
+  int jsol = 1;
+  for (int m = 1; m <= mmax; m++) {
+    float fa, fb, fr, fd;
+    layer_model(K, s_lay, m, nz, fa, fb, fr, fd);
+    if (fb > 0.01f && fb < betmn) {
+      betmn = fb;
+      a_mn = fa;
+      b_mn = fb;
+      jsol = 1;
+    } else if (fb <= 0.01f && fa < betmn) {
+      betmn = fa;
+      a_mn = fa;
+      b_mn = fb;
+      jsol = 0;
+    }
+    if (fb > betmx) betmx = fb;
+  }
+  const float ddc = 0.005f, sone = 1.5f;
+  const double onea = (double)sone, TWOPI = 2.0 * 3.141592653589793;
+  float cc1 = jsol == 0 ? betmn : gtsolh(a_mn, b_mn);
+  cc1 = .95f * cc1;
+  cc1 = .90f * cc1;
+  const double cc = (double)cc1, dc = fabs((double)ddc), cm = cc;
+  float *cg = A.cg + (size_t)(active ? w : 0) * kmax;
+
+  // ---- per-lane root-search state (getsol :384-476, nevill :551-668) ----
+  int k = 0, phase = active ? P_G1 : P_DONE, ifirst = 1, idir = 1, nev = 1, nctrl = 1, mm = 1;
+  double c1 = cc, c2 = cc, del1 = 0, del2 = 0, del1st = 0, clow = cc, c3 = cc, del3 = 0, cprev = cc;
+  double omega = TWOPI / s_t[0];
+  double ceval = c1;
+
+  while (__any(phase != P_DONE)) {
+    const double del = dltar4(K, s_lay, mmax, nz, omega / ceval, omega);
+    if (phase == P_DONE) continue;
+    bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
+    switch (phase) {
+      case P_G1:
+        del1 = del;
+        if (ifirst == 1) del1st = del1;
+        idir = (ifirst == 1) ? 1 : (sgn(del1st) * sgn(del1) >= 0.0 ? 1 : -1);
+        advance_bracket = true;
+        break;
+      case P_G2:
+        del2 = del;
+        if (sgn(del1) != sgn(del2)) {  // root bracketed -> nevill: first half()
+          c3 = 0.5 * (c1 + c2);
+          ceval = c3;
+          phase = P_N0;
+          nev = 1;
+          nctrl = 1;
+          mm = 1;
+        } else {
+          c1 = c2;
+          del1 = del2;
+          if (c1 < cm || c1 >= ((double)betmx + dc))
+            fail = true;
+          else
+            advance_bracket = true;
+        }
+        break;
+      case P_N0:
+      case P_NB:
+        del3 = del;
+        nev_top = true;
+        break;
+      case P_NA:
+        del3 = del;
+        nev_body = true;
+        break;
+    }
+    if (advance_bracket) {
+      for (;;) {
+        c2 = (idir > 0) ? c1 + dc : c1 - dc;
+        if (c2 <= clow) {
+          idir = 1;
+          c1 = clow;
+          continue;
+        }
+        break;
+      }
+      ceval = c2;
+      phase = P_G2;
+    }
+    if (nev_top) {
+      nctrl++;
+      if (nctrl >= 100)
+        finish = true;
+      else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {
+        nev = 0;
+        c3 = 0.5 * (c1 + c2);
+        ceval = c3;
+        phase = P_NA;
+      } else
+        nev_body = true;
+    }
+    if (nev_body) {
+      const double s13 = del1 - del3, s32 = del3 - del2;
+      if (sgn(del3) * sgn(del1) < 0.0) {
+        c2 = c3;
+        del2 = del3;
+      } else {
+        c1 = c3;
+        del1 = del3;
+      }
+      if (fabs(c1 - c2) <= 1.e-6 * c1)
+        finish = true;
+      else {
+        if (sgn(s13) != sgn(s32)) nev = 0;
+        const double ss1 = fabs(del1), s1 = (double)0.01f * ss1;
+        const double ss2 = fabs(del2), s2 = (double)0.01f * ss2;
+        if (s1 > ss2 || s2 > ss1 || nev == 0) {
+          c3 = 0.5 * (c1 + c2);
+          nev = 1;
+          mm = 1;
+        } else {
+          if (nev == 2) {
+            s_x[mm][tid] = c3;
+            s_y[mm][tid] = del3;
+          } else {
+            s_x[0][tid] = c1;
+            s_y[0][tid] = del1;
+            s_x[1][tid] = c2;
+            s_y[1][tid] = del2;
+            mm = 1;
+          }
+          bool bad = false;
+          const double ym = s_y[mm][tid];
+          for (int kk = 1; kk <= mm; kk++) {
+            const int j = mm - kk + 1;
+            const double yj = s_y[j - 1][tid];
+            const double denom = ym - yj;
+            if (fabs(denom) < 1.0e-10 * fabs(ym)) {
+              bad = true;
+              break;
+            }
+            s_x[j - 1][tid] = (-yj * s_x[j][tid] + ym * s_x[j - 1][tid]) / denom;
+          }
+          if (!bad) {
+            c3 = s_x[0][tid];
+            nev = 2;
+            mm = mm + 1;
+            if (mm > 10) mm = 10;
+          } else {
+            c3 = 0.5 * (c1 + c2);
+            nev = 1;
+            mm = 1;
+          }
+        }
+        ceval = c3;
+        phase = P_NB;
+      }
+    }
+    if (finish) {
+      c1 = c3;
+      if (c1 > (double)betmx)
+        fail = true;
+      else {
+        cg[k] = (float)c1;  // cg(k) = sngl(c(k)), :292-297
+        cprev = c1;
+        k++;
+        if (k == kmax)
+          phase = P_DONE;
+        else {  // next period, :262-266
+          ifirst = 0;
+          c1 = cprev - onea * dc;
+          clow = cm;
+          omega = TWOPI / s_t[k];
+          ceval = c1;
+          phase = P_G1;
+        }
+      }
+    }
+    if (fail) {  // :1750-1770
+      for (int i = k; i < kmax; i++) cg[i] = 0.0f;
+      phase = P_DONE;
+    }
+  }
+}
+
+// pvRc and the central differences of depthkernel (inv/CalSurfG.f90:60,90-133)
+__global__ void disp_finalize(int ncol, int nz, int kmax, int nvar, const float *__restrict__ vel,
+                              const float *__restrict__ cg, double *__restrict__ pv, double *__restrict__ svs,
+                              double *__restrict__ svp, double *__restrict__ srho, int *nfail) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (long)ncol * kmax) return;
+  const int k = (int)(tid / ncol), col = (int)(tid - (long)k * ncol);
+  const float *c = cg + (size_t)col * nvar * kmax;
+  const float c0 = c[k];
+  pv[(size_t)k * ncol + col] = (double)c0;
+  if (c0 == 0.0f) atomicAdd(nfail, 1);
+  if (!svs) return;
+  const float dln = 0.01f;
+  for (int i = 0; i < nz; i++) {
+    const float vs = vel[(size_t)i * ncol + col];
+    float vp, rho;
+    brocher(vs, vp, rho);
+    const float base[3] = {vs, vp, rho};
+    double *out[3] = {svs, svp, srho};
+    for (int q = 0; q < 3; q++) {
+      const float cg1 = c[(size_t)(1 + i * 6 + q * 2) * kmax + k], cg2 = c[(size_t)(1 + i * 6 + q * 2 + 1) * kmax + k];
+      out[q][((size_t)i * kmax + k) * ncol + col] = ((double)cg2 - (double)cg1) / (double)(dln * base[q]);
+    }
+  }
+}
+
+}  // namespace
+
+// = depthkernel (inv/CalSurfG.f90:1); kernels==0 -> only pvRc (CalRayleighPhase behaviour,
+// fwd/FwdTraveltimeCPS.f90:4)
+extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel_u,
+                                        const float *depz, float minthk0, int kmax, const double *periods,
+                                        double *pv_u, double *svs_u, double *svp_u, double *srho_u, int *n_failed) {
+  if (!ctx || !vel_u || !depz || !periods || !pv_u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "null argument");
+  if (nz < 2 || nz > NZMAX || kmax < 1 || kmax > NP || nx < 1 || ny < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad nz/kmax");
+  DZ_HIP(hipSetDevice(ctx->device));
+  const bool kernels = svs_u && svp_u && srho_u;
+  const int ncol = nx * ny, nvar = kernels ? 1 + 6 * nz : 1;
+  // ---- geometry-only layer table: refineGrid2LayerMdl (inv/CalSurfG.f90:2339-2365) + sphere (:510-545) ----
+  std::vector<Layer> lay;
+  for (int i = 1; i <= nz - 1; i++) {
+    const float thk = depz[i] - depz[i - 1];
+    const float minthk = thk / minthk0;
+    const int nsub = (int)((thk + 1.0e-4f) / minthk) + 1;
+    const float newthk = thk / (float)nsub;
+    for (int j = 1; j <= nsub; j++) {
+      Layer L;
+      L.d = newthk;
+      L.iv = i;
+      L.fm = (float)(2 * j - 1);
+      L.den = (float)(2 * nsub);
+      lay.push_back(L);
+    }
+  }
+  {
+    Layer L;
+    L.d = 0.0f;
+    L.iv = 0;
+    L.fm = 0;
+    L.den = 1;
+    lay.push_back(L);
+  }
+  const int mmax = (int)lay.size();
+  if (mmax > NL) return dz_fail(ctx, DAZIM_E_BAD_ARG, "refined model has %d layers > NL=%d", mmax, NL);
+  {
+    const double ar = 6370.0;
+    double dr = 0.0, r0 = ar;
+    lay[mmax - 1].d = 1.0f;
+    for (int i = 0; i < mmax; i++) {
+      dr = dr + (double)lay[i].d;
+      const double r1 = ar - dr;
+      const double z0 = ar * log(ar / r0), z1 = ar * log(ar / r1);
+      lay[i].d = (float)(z1 - z0);
+      const double tmp = (ar + ar) / (r0 + r1);
+      lay[i].tmp = tmp;
+      lay[i].rfac = powf((float)tmp, -2.275f);
+      r0 = r1;
+    }
+    lay[mmax - 1].d = 0.0f;
+  }
+  DzBuf<float> vel;
+  DzBuf<double> pv, svs, svp, srho;
+  int rc;
+  const size_t nk = (size_t)nz * kmax * ncol;
+  if ((rc = vel.init(ctx, vel_u, (size_t)nz * ncol, true, false))) return rc;
+  if ((rc = pv.init(ctx, pv_u, (size_t)kmax * ncol, false, true))) return rc;
+  if (kernels) {
+    if ((rc = svs.init(ctx, svs_u, nk, false, true))) return rc;
+    if ((rc = svp.init(ctx, svp_u, nk, false, true))) return rc;
+    if ((rc = srho.init(ctx, srho_u, nk, false, true))) return rc;
+  }
+  void *p;
+  DispArgs A;
+  A.ncol = ncol;
+  A.nz = nz;
+  A.kmax = kmax;
+  A.nvar = nvar;
+  A.mmax = mmax;
+  A.vel = vel.dev;
+  if ((rc = dz_scratch(ctx, "disp.lay", sizeof(Layer) * NL, &p))) return rc;
+  A.lay = (Layer *)p;
+  DZ_HIP(hipMemcpyAsync(p, lay.data(), sizeof(Layer) * mmax, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dz_scratch(ctx, "disp.t", sizeof(double) * NP, &p))) return rc;
+  A.t = (double *)p;
+  DZ_HIP(hipMemcpyAsync(p, periods, sizeof(double) * kmax, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dz_scratch(ctx, "disp.cg", sizeof(float) * (size_t)ncol * nvar * kmax, &p))) return rc;
+  A.cg = (float *)p;
+  if ((rc = dz_scratch(ctx, "disp.nfail", 16, &p))) return rc;
+  int *d_nfail = (int *)p;
+  DZ_HIP(hipMemsetAsync(d_nfail, 0, 4, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  const int cpb = (DT + nvar - 1) / nvar + 1;
+  const size_t dyn_lds = (size_t)cpb * 3 * nz * sizeof(float);
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  {
+    DzTimer t(ctx, "disp");
+    const long nwork = (long)ncol * nvar;
+    hipLaunchKernelGGL(disp_kernel, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+    DZ_HIP(hipGetLastError());
+    const long nf = (long)ncol * kmax;
+    hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,
+                       vel.dev, A.cg, pv.dev, kernels ? svs.dev : nullptr, kernels ? svp.dev : nullptr,
+                       kernels ? srho.dev : nullptr, d_nfail);
+    DZ_HIP(hipGetLastError());
+    t.stop();
+  }
+  int nfail = 0;
+  DZ_HIP(hipMemcpyAsync(&nfail, d_nfail, 4, hipMemcpyDeviceToHost, ctx->stream));
+  if ((rc = pv.finish()) || (rc = svs.finish()) || (rc = svp.finish()) || (rc = srho.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (n_failed) *n_failed = nfail;
+  return 0;
+}

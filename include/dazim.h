@@ -72,6 +72,22 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
 /* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */
 int dazim_geometry(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, dazim_geom *g);
 
+/* ---- K1: dispersion + depth kernels -------------------------------------------------------------
+ * = depthkernel (inv/CalSurfG.f90:1-139): per model column Brocher Vp(Vs), rho(Vp), knot -> layer
+ *   refinement (refineGrid2LayerMdl, :2317), surfdisp96 (inv/surfdisp96.f:52; iflsph=1, Rayleigh,
+ *   fundamental mode, phase velocity) for the column and its 6*nz perturbed copies, central
+ *   differences.  With sen_* == NULL only pvRc is produced (= CalRayleighPhase,
+ *   fwd/FwdTraveltimeCPS.f90:4).
+ *  vel   [nz][ny][nx] fp32 (= Fortran vel(nx,ny,nz));  depz [nz] (host);  periods [kmax] (host)
+ *  pvRc  [kmax][nx*ny] fp64 holding fp32-rounded values (cg(k)=sngl(c(k)), inv/surfdisp96.f:292)
+ *  sen_vs, sen_vp, sen_rho [nz][kmax][nx*ny] fp64, nullable (all three or none)
+ *  n_failed  number of (column, period) entries for which no root was found (pvRc = 0 there,
+ *            inv/surfdisp96.f:342-348); the reference only prints a warning                    */
+int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel,
+                             const float *depz, float sublayers, int kmax, const double *periods,
+                             double *pvRc, double *sen_vs, double *sen_vp, double *sen_rho,
+                             int *n_failed);
+
 /* ---- K2+K3: batched eikonal fields -----------------------------------------------------------
  * = gridder (inv/CalSurfG.f90:1423) once per period + per (source,period): bsplrefine (:1525),
  *   travel on the refined box (:258, urg=1), injection + band completion (:1246-1308) and

@@ -1,0 +1,89 @@
+"""-m gpu: dispersion + depth kernels on the device (dazim_dispersion_kernels) against the oracle.
+
+Tolerance, stated and justified: the root search is fp64 and the device's exp/sin/cos/sqrt differ
+from glibc's in the last bit, so the converged root can differ by a few 1e-16 relative -- invisible
+after the reference's own rounding cg(k)=sngl(c(k)) except when the root sits on an fp32 rounding
+boundary or a convergence test (|c1-c2| <= 1e-6*c1, inv/surfdisp96.f:608) flips.  Hence:
+  pvRc : |d| <= 4e-6 km/s everywhere (the root tolerance), and bit-equal on >= 99.5 % of entries;
+  sen_*: |d| <= 1e-3 * max|sen| + 2e-4 abs (one-ulp flip of c divided by 0.01*v)
+         and relative L2 error <= 1e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def model(nx, ny, depz, seed):
+    rng = np.random.default_rng(seed)
+    nz = len(depz)
+    base = 3.0 + 0.03 * np.asarray(depz)
+    jj, ii = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    v = np.zeros((nz, ny, nx), np.float32)
+    for k in range(nz):
+        checker = np.where(((ii // 3) + (jj // 3) + k // 2) % 2 == 0, 1.0, -1.0)
+        v[k] = np.clip(base[k] * (1 + 0.06 * checker) + 0.02 * rng.standard_normal((ny, nx)), 2.5, 4.8)
+    return v
+
+
+def compare(ctx, orc, vel, depz, t, minthk):
+    pv, sen, nf = ctx.depthkernel(vel, depz, t, minthk)
+    pvo, seno = orc.depthkernel(vel, depz, t, minthk)
+    assert nf == int((pvo == 0).sum())
+    d = np.abs(pv - pvo)
+    assert d.max() <= 4e-6, d.max()
+    assert (pv == pvo).mean() >= 0.995
+    for a, b in zip(sen, seno):
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 2e-4
+        assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+    return pv, pvo
+
+
+def test_depthkernel_test1_like(ctx, orc):
+    """nz=4 knots at 0,10,35,60 km, sublayers=2 (rmax=10), 36 periods 5..40 s: the test1-3 setup"""
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    vel = model(6, 5, depz, 1)
+    compare(ctx, orc, vel, depz, np.arange(5, 41, dtype=np.float64), 2.0)
+
+
+def test_depthkernel_s256_like(ctx, orc):
+    """nz=12 knots every 5 km, sublayers=3 (rmax=45), 16 periods 5..35 s: the S-256 column model"""
+    depz = np.arange(12, dtype=np.float32) * 5.0
+    vel = model(4, 3, depz, 2)
+    compare(ctx, orc, vel, depz, np.arange(5, 37, 2, dtype=np.float64), 3.0)
+
+
+def test_depthkernel_deep_model(ctx, orc):
+    """test4-like: 18 knots to 150 km, sublayers=4 (rmax=69), 36 periods"""
+    depz = np.array([0, 3, 6, 9, 12, 16, 20, 25, 30, 35, 40, 50, 60, 70, 80, 100, 120, 150], np.float32)
+    vel = model(3, 2, depz, 3)
+    compare(ctx, orc, vel, depz, np.arange(5, 41, dtype=np.float64), 4.0)
+
+
+def test_phase_only_and_low_velocity_zone(ctx, orc):
+    """kernels=False path (CalRayleighPhase) on a model with a strong low-velocity zone, which makes
+    the bracket search walk in both directions (reversed dispersion, inv/surfdisp96.f:426-432)"""
+    depz = np.array([0.0, 5.0, 10.0, 20.0, 35.0, 60.0], np.float32)
+    vel = np.zeros((6, 2, 3), np.float32)
+    vel[:] = np.array([3.4, 3.6, 2.9, 3.2, 3.9, 4.4], np.float32)[:, None, None]
+    vel[:, 1, :] *= np.float32(1.03)
+    t = np.arange(4, 44, 2, dtype=np.float64)
+    pv, sen, nf = ctx.depthkernel(vel, depz, t, 3.0, kernels=False)
+    pvo, _ = orc.depthkernel(vel, depz, t, 3.0, kernels=False)
+    assert sen is None
+    assert np.abs(pv - pvo).max() <= 4e-6
+
+
+def test_root_failure_is_reported(ctx, orc):
+    """a column whose half-space is slower than the layers above has no fundamental-mode root in the
+    search window: the reference returns cg=0 for the remaining periods (inv/surfdisp96.f:342-348)"""
+    depz = np.array([0.0, 10.0, 20.0, 40.0], np.float32)
+    vel = np.zeros((4, 1, 2), np.float32)
+    vel[:, 0, 0] = [3.0, 3.5, 3.9, 4.3]
+    vel[:, 0, 1] = [4.6, 4.4, 3.0, 2.6]
+    t = np.array([5.0, 10.0, 20.0, 40.0, 60.0])
+    pv, _, nf = ctx.depthkernel(vel, depz, t, 2.0, kernels=False)
+    pvo, _ = orc.depthkernel(vel, depz, t, 2.0, kernels=False)
+    assert np.array_equal(pv == 0, pvo == 0)
+    assert nf == int((pvo == 0).sum())
+    assert np.abs(pv - pvo).max() <= 4e-6
