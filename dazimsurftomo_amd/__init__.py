@@ -159,6 +159,37 @@ class Context:
             raise err
         return out
 
+    # ---- K4+K5 -------------------------------------------------------------------------------
+    def rays_build_G(self, nx, ny, goxd, gozd, dvxd, dvzd, vels, fields, scx, scz, period_idx, field_of_ray,
+                     rcx, rcz, sen, kernel_idx=None, tpred=None):
+        """srtimes + rpaths + row assembly (receiver loop of CalSurfG, inv/CalSurfG.f90:1326-1364).
+        `fields` is the dict returned by fmm_batch for the same scx/scz/period_idx.
+        Returns (G, tpred, n_boundary)."""
+        nz = vels.shape[0]
+        kmax = fields["veln"].shape[0]
+        nfield = int(scx.shape[0])
+        nray = int(rcx.shape[0])
+        if tpred is None:
+            if _is_torch(rcx):
+                import torch
+                tpred = torch.empty(nray, dtype=torch.float32, device=rcx.device)
+            else:
+                tpred = np.zeros(nray, np.float32)
+        boxes = fields["boxes"]
+        bptr = C.c_void_p(boxes.data_ptr()) if _is_torch(boxes) else C.cast(boxes, C.c_void_p)
+        h = C.c_void_p()
+        nnz = C.c_int64(0)
+        nb = C.c_int(0)
+        rc = self.lib.dazim_rays_build_G(self._h, nx, ny, nz, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
+                                         C.c_float(dvzd), kmax, _ptr(vels, np.float32), nfield, _ptr(scx), _ptr(scz),
+                                         _ptr(period_idx), _ptr(kernel_idx), _ptr(fields["veln"]), _ptr(fields["ttn"]),
+                                         _ptr(fields["ttnr"]), _ptr(fields["nstsr"]), bptr, C.c_int64(nray),
+                                         _ptr(field_of_ray), _ptr(rcx), _ptr(rcz), _ptr(sen[0]), _ptr(sen[1]),
+                                         _ptr(sen[2]), _ptr(tpred), C.byref(h), C.byref(nnz), C.byref(nb))
+        self._check(rc)
+        n = (nx - 2) * (ny - 2) * (nz - 1)
+        return SparseMatrix(self, h, nray, n, nnz.value), tpred, nb.value
+
     # ---- K6/K7 -----------------------------------------------------------------------------
     def csr_from_coo(self, m, n, irow, icol, rw):
         """COO triplets as the reference holds them (1-based rows iw(2:nar+1), cols, values rw;
@@ -205,6 +236,20 @@ class SparseMatrix:
 
     def scale_rows(self, w):
         self.ctx._check(self.ctx.lib.dazim_csr_scale_rows(self.ctx._h, self._h, _ptr(w, np.float32)))
+
+    def append_coo(self, extra_m, irow, icol, rw):
+        """append rows m+1..m+extra_m (absolute 1-based ids) -- Tikhonov rows, inv/TikhRegul.f90:2"""
+        irow = np.ascontiguousarray(irow, np.int32); icol = np.ascontiguousarray(icol, np.int32)
+        rw = np.ascontiguousarray(rw, np.float32)
+        self.ctx._check(self.ctx.lib.dazim_csr_append_coo(self.ctx._h, self._h, C.c_int64(extra_m), C.c_int64(len(rw)),
+                                                          _ptr(irow), _ptr(icol), _ptr(rw)))
+        self.m += extra_m
+        self.nnz += len(rw)
+
+    def to_coo(self):
+        irow = np.zeros(self.nnz, np.int32); icol = np.zeros(self.nnz, np.int32); rw = np.zeros(self.nnz, np.float32)
+        self.ctx._check(self.ctx.lib.dazim_csr_to_coo(self.ctx._h, self._h, _ptr(irow), _ptr(icol), _ptr(rw)))
+        return irow, icol, rw
 
     def free(self):
         if self._h:

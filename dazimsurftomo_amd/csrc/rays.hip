@@ -1,0 +1,478 @@
+// rays.hip -- K4 + K5 of SURVEY.md: receiver traveltimes (srtimes, inv/CalSurfG.f90:1599), ray
+// back-tracing with B-spline Frechet weights (rpaths, :1735) and G-row assembly (:1339-1364) for a
+// batch of rays whose eikonal fields are already resident in HBM (output of dazim_fmm_batch).
+//
+// One wavefront per ray.  The Frechet grid fdm(0:nvz+1,0:nvx+1) of the ray lives in LDS; the
+// half-cell stepping is inherently serial and is executed redundantly by all lanes, while the
+// 4x4 B-spline scatter of every sub-segment is spread over lanes 0..15.  Rows are emitted straight
+// into CSR in the reference's column order (depth-major, then jj, kk) by a count pass, an exclusive
+// scan and an emit pass -- no atomics, so G is reproducible.  fp32 without FMA like the reference.
+#include <cmath>
+
+#include "dazim_internal.h"
+
+#include <rocprim/device/device_scan.hpp>
+
+namespace {
+
+constexpr int GDX = 5, GDZ = 5;
+constexpr int RM = DAZIM_RMAX;
+constexpr float EARTH = 6371.0f;
+constexpr float FTOL = 1e-4f;  // inv/CalSurfG.f90:999
+
+struct RayArgs {
+  dazim_geom g;
+  int nx, ny, nz, kmax;
+  long nray;
+  const int *field;     // [nray] field of each ray
+  const float *rcx, *rcz;
+  const float *scx, *scz;  // [nfield]
+  const int *period;       // [nfield], 1-based (velocity map of the field)
+  const int *kidx;         // [nfield], 1-based period slot of the depth kernels (knumi), may equal period
+  const float *veln;       // [kmax][nnx][nnz]
+  const float *ttn;        // [nfield][nnx][nnz]
+  const float *ttnr;       // [nfield][RM][RM]
+  const int *nstsr;        // [nfield][RM][RM]
+  const dazim_refbox *boxes;
+  const float *vels;       // [nz][ny][nx]
+  const double *svs, *svp, *srho;  // [nz][kmax][nx*ny]
+  float dplh;              // min cell size (before the 0.5 factor), host libm
+  float *dsurf;            // [nray]
+  int *status;             // [nray]
+  int *rbflag;             // [nray]
+  long *count;             // [nray]  (count pass out)
+  const long *rowptr;      // [nray+1] (emit pass in)
+  float *val;
+  int *col;
+};
+
+// sin of a colatitude: evaluated in fp64 and rounded, i.e. the correctly rounded fp32 sine.
+__device__ __forceinline__ float dz_sinf(float x) { return (float)sin((double)x); }
+
+__device__ __forceinline__ void basis(float v, float b[4]) {  // inv/CalSurfG.f90:2145-2148
+  const float om = 1.0f - v;
+  b[0] = om * om * om / 6.0f;
+  b[1] = (4.0f - 6.0f * (v * v) + 3.0f * (v * v * v)) / 6.0f;
+  b[2] = (1.0f + 3.0f * v + 3.0f * (v * v) - 3.0f * (v * v * v)) / 6.0f;
+  b[3] = v * v * v / 6.0f;
+}
+
+// bilinear velocity inside coarse cell (ipx,ipz), inv/CalSurfG.f90:2129-2137
+__device__ __forceinline__ float vel_at(const dazim_geom &g, const float *veln, int ipx, int ipz, float drx, float drz) {
+  float vel = 0.0f;
+#pragma unroll
+  for (int l = 1; l <= 2; l++)
+#pragma unroll
+    for (int m = 1; m <= 2; m++) {
+      float produ = (1.0f - fabsf(((float)(m - 1) * g.dnz - drz) / g.dnz));
+      produ = produ * (1.0f - fabsf(((float)(l - 1) * g.dnx - drx) / g.dnx));
+      if (ipz - 1 + m <= g.nnz && ipx - 1 + l <= g.nnx && ipz - 1 + m >= 1 && ipx - 1 + l >= 1)
+        vel = vel + veln[(size_t)(ipx - 2 + l) * g.nnz + (ipz - 2 + m)] * produ;
+    }
+  return vel;
+}
+
+// bilinear(nv,dsx,dsz), inv/CalSurfG.f90:2293 -- velocity at a point of cell (cx,cz)
+__device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *veln, int cx, int cz, float px, float pz) {
+  const float drx = (px - g.gox) - (float)(cx - 1) * g.dnx;
+  const float drz = (pz - g.goz) - (float)(cz - 1) * g.dnz;
+  float biv = 0.0f;
+#pragma unroll
+  for (int i = 1; i <= 2; i++)
+#pragma unroll
+    for (int j = 1; j <= 2; j++) {
+      const float produ = (1.0f - fabsf(((float)(i - 1) * g.dnx - drx) / g.dnx)) *
+                          (1.0f - fabsf(((float)(j - 1) * g.dnz - drz) / g.dnz));
+      biv = biv + veln[(size_t)(cx - 2 + i) * g.nnz + (cz - 2 + j)] * produ;
+    }
+  return biv;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float s_fdm[];  // [(nvx+2)*(nvz+2)] then cell list
+  const dazim_geom g = A.g;
+  const int lane = threadIdx.x;
+  const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_fdm + nf);
+  const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
+  for (long ray = blockIdx.x; ray < A.nray; ray += gridDim.x) {
+    const int f = A.field[ray];
+    const float scx = A.scx[f], scz = A.scz[f], rcx = A.rcx[ray], rcz = A.rcz[ray];
+    const float *veln = A.veln + (size_t)(A.period[f] - 1) * nnx * nnz;
+    const float *ttn = A.ttn + (size_t)f * nnx * nnz;
+    const float *ttnr = A.ttnr + (size_t)f * RM * RM;
+    const int *nstsr = A.nstsr + (size_t)f * RM * RM;
+    const dazim_refbox bx = A.boxes[f];
+    __syncthreads();
+    for (int i = lane; i < nf; i += 64) s_fdm[i] = 0.0f;
+    __syncthreads();
+    int status = 0, rb = 0;
+    // ---------------- srtimes, inv/CalSurfG.f90:1644-1711 ----------------
+    if (!EMIT) {
+      int irx = (int)((rcx - gox) / dnx) + 1, irz = (int)((rcz - goz) / dnz) + 1;
+      if (irx < 1 || irx > nnx || irz < 1 || irz > nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
+      if (!status) {
+        if (irx == nnx) irx--;
+        if (irz == nnz) irz--;
+        const int isx = (int)((scx - gox) / dnx) + 1, isz = (int)((scz - goz) / dnz) + 1;
+        float sred = ((scx - rcx) * EARTH) * ((scx - rcx) * EARTH);
+        const float e2 = (scz - rcz) * EARTH * dz_sinf(rcx);
+        sred = sqrtf(sred + e2 * e2);
+        bool sw = sred < A.dplh;
+        if (isx == irx && isz == irz) sw = true;
+        float trr;
+        if (sw) {
+          const float vs = bilin_cell(g, veln, isx, isz, scx, scz);
+          const float vr = bilin_cell(g, veln, irx, irz, rcx, rcz);
+          trr = 2.0f * sred / (vs + vr);
+        } else {
+          const float drx = (rcx - gox) - (float)(irx - 1) * dnx;
+          const float drz = (rcz - goz) - (float)(irz - 1) * dnz;
+          trr = 0.0f;
+#pragma unroll
+          for (int k = 1; k <= 2; k++)
+#pragma unroll
+            for (int l = 1; l <= 2; l++) {
+              const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
+                                  (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
+              trr = trr + ttn[(size_t)(irx - 2 + k) * nnz + (irz - 2 + l)] * produ;
+            }
+        }
+        if (lane == 0) A.dsurf[ray] = trr;
+      }
+    }
+    // ---------------- rpaths, inv/CalSurfG.f90:1818-2236 ----------------
+    const float goxr = bx.goxr, gozr = bx.gozr, dnxr = bx.dnxr, dnzr = bx.dnzr;
+    const int nnxr = bx.nnxr, nnzr = bx.nnzr;
+    const int isx = (int)((scx - goxr) / dnxr) + 1, isz = (int)((scz - gozr) / dnzr) + 1;
+    const float dpl = 0.5f * A.dplh;
+    int ipx = (int)((rcx - gox) / dnx) + 1, ipz = (int)((rcz - goz) / dnz) + 1;
+    if (ipx < 1 || ipx >= nnx || ipz < 1 || ipz >= nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
+    if (!status) {
+      float x0 = rcx, z0 = rcz;
+      int sw = 0;
+      float sred = ((scx - x0) * EARTH) * ((scx - x0) * EARTH);
+      float e2 = (scz - z0) * EARTH * dz_sinf(x0);
+      sred = sqrtf(sred + e2 * e2);
+      if (sred < 2.0f * dpl) sw = 1;
+      int ipxr = (int)((rcx - goxr) / dnxr) + 1, ipzr = (int)((rcz - gozr) / dnzr) + 1;
+      auto in_refined = [&](int px, int pz) -> int {
+        if (px < 1 || px >= nnxr || pz < 1 || pz >= nnzr) return 0;
+        const int *s = nstsr + (size_t)(px - 1) * RM + (pz - 1);
+        if (s[0] != 0 || s[1] != 0) return 0;
+        if (s[RM] != 0 || s[RM + 1] != 0) return 0;
+        return 1;
+      };
+      int igref = in_refined(ipxr, ipzr);
+      if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
+      const long maxrp = (long)nnx * nnz;
+      const int lm = lane & 3, ll = (lane >> 2) & 3;  // this lane's (m,l) of the 4x4 scatter
+      for (long j = 1; j <= maxrp; j++) {
+        if (sw == 1) break;
+        const float sinx0 = dz_sinf(x0);
+        float dtx, dtz;
+        if (igref == 1) {
+          const float *t = ttnr + (size_t)(ipxr - 1) * RM + (ipzr - 1);
+          dtx = t[RM] - t[0];
+          dtx = dtx + t[RM + 1] - t[1];
+          dtx = dtx / (2.0f * EARTH * dnxr);
+          dtz = t[1] - t[0];
+          dtz = dtz + t[RM + 1] - t[RM];
+          dtz = dtz / (2.0f * EARTH * sinx0 * dnzr);
+        } else {
+          const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
+          dtx = t[nnz] - t[0];
+          dtx = dtx + t[nnz + 1] - t[1];
+          dtx = dtx / (2.0f * EARTH * dnx);
+          dtz = t[1] - t[0];
+          dtz = dtz + t[nnz + 1] - t[nnz];
+          dtz = dtz / (2.0f * EARTH * sinx0 * dnz);
+        }
+        const float rd1 = sqrtf(dtx * dtx + dtz * dtz);
+        float x1 = x0 - dpl * dtx / (EARTH * rd1);
+        float z1 = z0 - dpl * dtz / (EARTH * sinx0 * rd1);
+        const int ipxo = ipx, ipzo = ipz;
+        ipxr = (int)((x1 - goxr) / dnxr) + 1;
+        ipzr = (int)((z1 - gozr) / dnzr) + 1;
+        igref = in_refined(ipxr, ipzr);
+        ipx = (int)((x1 - gox) / dnx) + 1;
+        ipz = (int)((z1 - goz) / dnz) + 1;
+        sred = ((scx - x1) * EARTH) * ((scx - x1) * EARTH);
+        e2 = (scz - z1) * EARTH * dz_sinf(x1);
+        sred = sqrtf(sred + e2 * e2);
+        sw = 0;
+        if (sred < 2.0f * dpl) sw = 1;
+        if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
+        if (ipx < 1) { x1 = gox; ipx = 1; rb = 1; }
+        if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; rb = 1; }
+        if (ipz < 1) { z1 = goz; ipz = 1; rb = 1; }
+        if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; rb = 1; }
+        // ---- Frechet weights, :2077-2229 ----
+        const int ivx = (ipx - 1) / GDX + 1, ivz = (ipz - 1) / GDZ + 1;
+        const int ivxo = (ipxo - 1) / GDX + 1, ivzo = (ipzo - 1) / GDZ + 1;
+        int nhp = 0, chp0 = 0, chp1 = 0;
+        float vr0 = 1.0f, vr1 = 1.0f, vr2 = 1.0f;
+        if (ivx != ivxo) {
+          nhp = 1;
+          const float xi = (ivx > ivxo) ? gox + (float)(ivx - 1) * dvx : gox + (float)ivx * dvx;
+          vr0 = (xi - x0) / (x1 - x0);
+          chp0 = 1;
+        }
+        if (ivz != ivzo) {
+          const float zi = (ivz > ivzo) ? goz + (float)(ivz - 1) * dvz : goz + (float)ivz * dvz;
+          const float r = (zi - z0) / (z1 - z0);
+          if (nhp == 0) {
+            vr0 = r;
+            chp0 = 2;
+          } else if (r >= vr0) {
+            vr1 = r;
+            chp1 = 2;
+          } else {
+            vr1 = vr0;
+            chp1 = chp0;
+            vr0 = r;
+            chp0 = 2;
+          }
+          nhp++;
+        }
+        nhp++;  // the closing sub-segment with vrat = 1, chp = 0
+        if (nhp == 1) vr0 = 1.0f;
+        if (nhp == 2) vr1 = 1.0f;
+        float drx = (x0 - gox) - (float)(ipxo - 1) * dnx;
+        float drz = (z0 - goz) - (float)(ipzo - 1) * dnz;
+        float vel = vel_at(g, veln, ipxo, ipzo, drx, drz);
+        drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
+        drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
+        float bv[4], bw[4];
+        basis(drx / dvx, bv);
+        basis(drz / dvz, bw);
+        float vi = bv[lm], wi = bw[ll];  // this lane's vi(m), wi(l)
+        int ivxt = ivxo, ivzt = ivzo;
+        for (int k = 1; k <= nhp; k++) {
+          const float velo = vel, vio = vi, wio = wi;
+          if (k > 1) {
+            const int cp = (k == 2) ? chp0 : chp1;
+            if (cp == 1) ivxt = ivx;
+            else if (cp == 2) ivzt = ivz;
+          }
+          const float vrk = (k == 1) ? vr0 : (k == 2 ? vr1 : vr2);
+          const float vrp = (k == 2) ? vr0 : vr1;
+          const float rigz = z0 + vrk * (z1 - z0);
+          const float rigx = x0 + vrk * (x1 - x0);
+          const int ipxt = (int)((rigx - gox) / dnx) + 1, ipzt = (int)((rigz - goz) / dnz) + 1;
+          drx = (rigx - gox) - (float)(ipxt - 1) * dnx;
+          drz = (rigz - goz) - (float)(ipzt - 1) * dnz;
+          vel = vel_at(g, veln, ipxt, ipzt, drx, drz);
+          drx = (rigx - gox) - (float)(ivxt - 1) * dvx;
+          drz = (rigz - goz) - (float)(ivzt - 1) * dvz;
+          basis(drx / dvx, bv);
+          basis(drz / dvz, bw);
+          vi = bv[lm];
+          wi = bw[ll];
+          const float dinc = (k == 1) ? vrk * dpl : (vrk - vrp) * dpl;
+          if (lane < 16) {
+            float r1 = vi * wi / (vel * vel);
+            const float r2 = vio * wio / (velo * velo);
+            r1 = -(r1 + r2) * dinc / 2.0f;
+            float *fp = &s_fdm[(ivxt - 2 + (lm + 1)) * ldf + (ivzt - 2 + (ll + 1))];
+            *fp = r1 + *fp;
+          }
+        }
+        x0 = x1;
+        z0 = z1;
+      }
+    }
+    __syncthreads();
+    if (!EMIT && lane == 0) {
+      A.status[ray] = status;
+      A.rbflag[ray] = rb;
+    }
+    // ---------------- G row, inv/CalSurfG.f90:1339-1364 ----------------
+    // cells with |fdm| >= ftol in (jj,kk) order -> LDS list
+    int nlist = 0;
+    if (!status) {
+      for (int base = 0; base < nvz * nvx; base += 64) {
+        const int c = base + lane;
+        bool keep = false;
+        if (c < nvz * nvx) {
+          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          keep = fabsf(s_fdm[kk * ldf + jj]) >= FTOL;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (keep) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)c;
+        nlist += __popcll(m);
+      }
+    }
+    __syncthreads();
+    const size_t ncol = (size_t)A.nx * A.ny;
+    const int kslot = A.kidx[f] - 1;
+    long cnt = 0;
+    const long rstart = EMIT ? A.rowptr[ray] : 0;
+    for (int k = 1; k <= A.nz - 1; k++) {
+      for (int base = 0; base < nlist; base += 64) {
+        const int li = base + lane;
+        bool keep = false;
+        float rowv = 0.0f;
+        int nn = 0;
+        if (li < nlist) {
+          const int c = s_list[li];
+          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          const float fd = s_fdm[kk * ldf + jj];
+          const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
+          const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
+          const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
+          const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
+                                         0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
+          const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
+          const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
+          rowv = (float)r;
+          keep = fabsf(rowv) > FTOL;
+          nn = (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
+        }
+        const unsigned long long m = __ballot(keep);
+        if (EMIT && keep) {
+          const long pos = rstart + cnt + __popcll(m & ((1ull << lane) - 1ull));
+          A.val[pos] = rowv;
+          A.col[pos] = nn - 1;
+        }
+        cnt += __popcll(m);
+      }
+    }
+    if (!EMIT && lane == 0) A.count[ray] = cnt;
+  }
+}
+
+}  // namespace
+
+struct dazim_csr;  // sparse.hip
+extern "C" int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
+                               float *val, dazim_csr **out);
+
+// = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields
+extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+                                  float dvzd, int kmax, const float *vels_u, int nfield, const float *scx_u,
+                                  const float *scz_u, const int *period_u, const int *kidx_u, const float *veln_u,
+                                  const float *ttn_u, const float *ttnr_u, const int *nstsr_u,
+                                  const dazim_refbox *boxes_u, int64_t nray, const int *field_u, const float *rcx_u,
+                                  const float *rcz_u, const double *svs_u, const double *svp_u, const double *srho_u,
+                                  float *dsurf_u, dazim_csr **G, int64_t *nnz_out, int *n_boundary) {
+  if (!ctx || !G) return DAZIM_E_BAD_ARG;
+  dazim_geom g;
+  if (dazim_geometry(nx, ny, goxd, gozd, dvxd, dvzd, &g)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad grid");
+  if (nray < 0 || nfield < 1 || nz < 2 || (size_t)g.nvx * g.nvz > 65535u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_rays_build_G");
+  DZ_HIP(hipSetDevice(ctx->device));
+  const size_t nn = (size_t)g.nnx * g.nnz, nr = (size_t)RM * RM, ncol = (size_t)nx * ny;
+  DzBuf<float> vels, scx, scz, veln, ttn, ttnr, rcx, rcz, dsurf;
+  DzBuf<int> period, kidx, nstsr, field;
+  DzBuf<dazim_refbox> boxes;
+  DzBuf<double> svs, svp, srho;
+  int rc;
+  if ((rc = vels.init(ctx, vels_u, (size_t)nz * ncol, true, false))) return rc;
+  if ((rc = scx.init(ctx, scx_u, nfield, true, false))) return rc;
+  if ((rc = scz.init(ctx, scz_u, nfield, true, false))) return rc;
+  if ((rc = period.init(ctx, period_u, nfield, true, false))) return rc;
+  if ((rc = kidx.init(ctx, kidx_u ? kidx_u : period_u, nfield, true, false))) return rc;
+  if ((rc = veln.init(ctx, veln_u, nn * kmax, true, false))) return rc;
+  if ((rc = ttn.init(ctx, ttn_u, nn * nfield, true, false))) return rc;
+  if ((rc = ttnr.init(ctx, ttnr_u, nr * nfield, true, false))) return rc;
+  if ((rc = nstsr.init(ctx, nstsr_u, nr * nfield, true, false))) return rc;
+  if ((rc = boxes.init(ctx, boxes_u, nfield, true, false))) return rc;
+  if ((rc = field.init(ctx, field_u, nray, true, false))) return rc;
+  if ((rc = rcx.init(ctx, rcx_u, nray, true, false))) return rc;
+  if ((rc = rcz.init(ctx, rcz_u, nray, true, false))) return rc;
+  const size_t nk = (size_t)nz * kmax * ncol;
+  if ((rc = svs.init(ctx, svs_u, nk, true, false))) return rc;
+  if ((rc = svp.init(ctx, svp_u, nk, true, false))) return rc;
+  if ((rc = srho.init(ctx, srho_u, nk, true, false))) return rc;
+  if ((rc = dsurf.init(ctx, dsurf_u, nray, false, true))) return rc;
+
+  RayArgs A;
+  A.g = g;
+  A.nx = nx; A.ny = ny; A.nz = nz; A.kmax = kmax;
+  A.nray = nray;
+  A.field = field.dev; A.rcx = rcx.dev; A.rcz = rcz.dev; A.scx = scx.dev; A.scz = scz.dev;
+  A.period = period.dev; A.kidx = kidx.dev; A.veln = veln.dev; A.ttn = ttn.dev; A.ttnr = ttnr.dev;
+  A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
+  {  // dpl, inv/CalSurfG.f90:1829-1833 (host libm sin, geometry only)
+    float dpl = g.dnx * EARTH;
+    float rd1 = g.dnz * EARTH * sinf(g.gox);
+    if (rd1 < dpl) dpl = rd1;
+    rd1 = g.dnz * EARTH * sinf(g.gox + (float)(g.nnx - 1) * g.dnx);
+    if (rd1 < dpl) dpl = rd1;
+    A.dplh = dpl;
+  }
+  void *p;
+  const int64_t m = nray;
+  const size_t nr1 = (size_t)(nray > 0 ? nray : 1);
+  if ((rc = dz_scratch(ctx, "rays.status", nr1 * 4, &p))) return rc;
+  A.status = (int *)p;
+  if ((rc = dz_scratch(ctx, "rays.rb", nr1 * 4, &p))) return rc;
+  A.rbflag = (int *)p;
+  if ((rc = dz_scratch(ctx, "rays.count", (size_t)(m + 1) * 8, &p))) return rc;
+  A.count = (long *)p;
+  int64_t *rowptr = nullptr;
+  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + 1) * 8));
+  A.dsurf = dsurf.dev;
+  A.rowptr = (const long *)rowptr;
+  A.val = nullptr;
+  A.col = nullptr;
+  const size_t lds = (size_t)(g.nvx + 2) * (g.nvz + 2) * 4 + (size_t)g.nvx * g.nvz * 2 + 16;
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)(160 * 1024 / (lds + 256));
+  if (per_cu > 32) per_cu = 32;
+  if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS Frechet grid");
+  long nwg = (long)ctx->num_cu * per_cu;
+  if (nwg > nray) nwg = nray;
+  int64_t nnz = 0;
+  DzTimer t(ctx, "rays");
+  DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
+  if (nray > 0) {
+    hipLaunchKernelGGL(rays_kernel<false>, dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    DZ_HIP(hipGetLastError());
+  }
+  {  // exclusive scan of the row counts -> rowptr
+    size_t tb = 0;
+    DZ_HIP(rocprim::exclusive_scan(nullptr, tb, A.count, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+    if ((rc = dz_scratch(ctx, "rays.scan", tb + 256, &p))) return rc;
+    DZ_HIP(rocprim::exclusive_scan(p, tb, A.count, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+    DZ_HIP(hipMemcpyAsync(&nnz, rowptr + m, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  float *val = nullptr;
+  int *col = nullptr;
+  DZ_HIP(hipMalloc((void **)&val, (size_t)(nnz > 0 ? nnz : 1) * 4));
+  DZ_HIP(hipMalloc((void **)&col, (size_t)(nnz > 0 ? nnz : 1) * 4));
+  A.val = val;
+  A.col = col;
+  if (nray > 0) {
+    hipLaunchKernelGGL(rays_kernel<true>, dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    DZ_HIP(hipGetLastError());
+  }
+  t.stop();
+  // statuses: first failing ray is the reference's STOP
+  std::vector<int> hs(nr1), hb(nr1);
+  if (nray > 0) {
+    DZ_HIP(hipMemcpyAsync(hs.data(), A.status, nray * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(hb.data(), A.rbflag, nray * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  int nb = 0, err = 0;
+  for (int64_t i = 0; i < nray; i++) {
+    nb += hb[i];
+    if (hs[i] && !err) err = dz_fail(ctx, hs[i], "ray %ld: receiver lies outside model", (long)i);
+  }
+  if (n_boundary) *n_boundary = nb;
+  if (nnz_out) *nnz_out = nnz;
+  if ((rc = dsurf.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (err) {
+    (void)hipFree(rowptr);
+    (void)hipFree(val);
+    (void)hipFree(col);
+    return err;
+  }
+  const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1);
+  return dazim_csr_adopt(ctx, m, n, nnz, rowptr, col, val, G);
+}

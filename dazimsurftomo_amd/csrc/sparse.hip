@@ -168,11 +168,11 @@ __global__ void k_gather_f(int64_t n, const unsigned *perm, const float *src, fl
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]];
 }
 __global__ void k_gather_i(int64_t n, const unsigned *perm, const int *src, int *dst, int add) {
-  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]] + add;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm ? perm[i] : (unsigned)i] + add;
 }
 __global__ void k_iota_keys(int64_t n, const int *one_based, unsigned *keys, unsigned *iota) {
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
-    keys[i] = (unsigned)(one_based[i] - 1);
+    if (keys) keys[i] = (unsigned)(one_based[i] - 1);
     iota[i] = (unsigned)i;
   }
 }
@@ -192,6 +192,7 @@ __global__ void k_check_range(int64_t n, const int *a, int lo, int hi, int *bad)
     if (a[i] < lo || a[i] > hi) atomicOr(bad, 1);
 }
 
+int spmv_blocks(dazim_ctx *ctx, int64_t nrows);
 inline int nblk(int64_t n, int cap = 2048) {
   int64_t b = (n + VB - 1) / VB;
   if (b < 1) b = 1;
@@ -212,6 +213,60 @@ int spmv_blocks(dazim_ctx *ctx, int64_t nrows) {
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// row id of every CSR entry (one wavefront per row)
+__global__ void k_expand_rows(int64_t nrows, const int64_t *ptr, unsigned *rowid) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * WPB + wv; r < nrows; r += (int64_t)gridDim.x * WPB)
+    for (int64_t i = ptr[r] + lane; i < ptr[r + 1]; i += 64) rowid[i] = (unsigned)r;
+}
+__global__ void k_offset_ptr(int64_t n, const int64_t *src, int64_t add, int64_t *dst) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[i] + add;
+}
+
+// build the stable transpose (colptr,row,tval,tperm) of A's CSR arrays
+int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
+  const int64_t nnz = A->nnz, n = A->n, m = A->m;
+  const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
+  for (void **pp : {(void **)&A->colptr, (void **)&A->row, (void **)&A->tval, (void **)&A->tperm})
+    if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+  DZ_HIP(hipMalloc((void **)&A->colptr, (n + 1) * 8));
+  DZ_HIP(hipMalloc((void **)&A->row, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->tval, nz * 4));
+  DZ_HIP(hipMalloc((void **)&A->tperm, nz * 4));
+  if (nnz == 0) {
+    DZ_HIP(hipMemsetAsync(A->colptr, 0, (n + 1) * 8, ctx->stream));
+    return 0;
+  }
+  int rc;
+  void *p;
+  unsigned *ck, *cks, *iota, *rowid;
+  if ((rc = dz_scratch(ctx, "csr.k0", nz * 4, &p))) return rc;
+  ck = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.k1", nz * 4, &p))) return rc;
+  cks = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.v0", nz * 4, &p))) return rc;
+  iota = (unsigned *)p;
+  if ((rc = dz_scratch(ctx, "csr.perm", nz * 4, &p))) return rc;
+  rowid = (unsigned *)p;
+  const int nb = nblk(nnz);
+  int cbits = 1;
+  while (((int64_t)1 << cbits) < n) cbits++;
+  // keys = column (0-based) + 1 so that k_iota_keys' "-1" applies
+  hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, (const unsigned *)nullptr, A->col, (int *)ck, 0);
+  hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, (const int *)nullptr, (unsigned *)nullptr, iota);
+  hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, m)), dim3(64 * WPB), 0, ctx->stream, m, A->rowptr, rowid);
+  size_t tb = 0;
+  DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, ck, cks, iota, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
+  void *tmp;
+  if ((rc = dz_scratch(ctx, "csr.tmp", tb + 256, &tmp))) return rc;
+  DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, ck, cks, iota, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
+  hipLaunchKernelGGL(k_lower_bound, dim3(nblk(n + 1)), dim3(VB), 0, ctx->stream, n, nnz, cks, A->colptr);
+  hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, A->val, A->tval);
+  hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, (const int *)rowid, A->row, 0);
+  DZ_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -253,12 +308,8 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   A->nnz = nnz;
   const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
   DZ_HIP(hipMalloc((void **)&A->rowptr, (m + 1) * 8));
-  DZ_HIP(hipMalloc((void **)&A->colptr, (n + 1) * 8));
   DZ_HIP(hipMalloc((void **)&A->col, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->row, nz * 4));
   DZ_HIP(hipMalloc((void **)&A->val, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->tval, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->tperm, nz * 4));
   unsigned *k0, *k1, *v0, *perm;
   int *bad;
   void *p;
@@ -297,25 +348,95 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
     hipLaunchKernelGGL(k_lower_bound, dim3(nblk(m + 1)), dim3(VB), 0, ctx->stream, m, nnz, k1, A->rowptr);
     hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, rw.dev, A->val);
     hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, icol.dev, A->col, -1);
-    // row index of each CSR entry (0-based) = sorted keys k1
-    // ---- CSC: stable sort of the CSR-ordered entries by column -> rows ascend inside a column ----
-    unsigned *ck = k0;  // reuse: keys = CSR column
-    DZ_HIP(hipMemcpyAsync(ck, A->col, nz * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    size_t tb2 = 0;
-    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb2, ck, perm, v0, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
-    if ((rc = dz_scratch(ctx, "csr.tmp", tb2 + 256, &tmp))) return rc;
-    // v0 is still iota (radix_sort_pairs does not modify its inputs)
-    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb2, ck, perm, v0, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
-    hipLaunchKernelGGL(k_lower_bound, dim3(nblk(n + 1)), dim3(VB), 0, ctx->stream, n, nnz, perm, A->colptr);
-    hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, A->val, A->tval);
-    hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, A->tperm, (const int *)k1, A->row, 0);
     DZ_HIP(hipGetLastError());
   } else {
     DZ_HIP(hipMemsetAsync(A->rowptr, 0, (m + 1) * 8, ctx->stream));
-    DZ_HIP(hipMemsetAsync(A->colptr, 0, (n + 1) * 8, ctx->stream));
   }
+  if ((rc = build_transpose(ctx, A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
+  return 0;
+}
+
+// take ownership of device CSR arrays (hipMalloc'ed: rowptr[m+1], col[nnz] 0-based, val[nnz])
+int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col, float *val,
+                    dazim_csr **out) {
+  if (!ctx || !out || !rowptr) return DAZIM_E_BAD_ARG;
+  dazim_csr *A = new dazim_csr;
+  A->m = m; A->n = n; A->nnz = nnz;
+  A->rowptr = rowptr; A->col = col; A->val = val;
+  int rc;
+  if ((rc = build_transpose(ctx, A))) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  *out = A;
+  return 0;
+}
+
+// append rows m+1..m+extra_m given as COO (1-based absolute row ids, any order) -- the reference
+// appends its Tikhonov rows to the same rw/iw/col arrays (inv/TikhRegul.f90:2)
+int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t nnz2, const int *irow_u,
+                         const int *icol_u, const float *rw_u) {
+  if (!ctx || !A || extra_m < 0 || nnz2 < 0) return DAZIM_E_BAD_ARG;
+  if (extra_m == 0 && nnz2 == 0) return 0;
+  // build the block as its own matrix with rows shifted to 1..extra_m
+  DzBuf<int> irow;
+  int rc;
+  if ((rc = irow.init(ctx, irow_u, nnz2, true, false))) return rc;
+  int *shifted;
+  void *p;
+  if ((rc = dz_scratch(ctx, "csr.shift", (size_t)(nnz2 > 0 ? nnz2 : 1) * 4, &p))) return rc;
+  shifted = (int *)p;
+  if (nnz2 > 0) hipLaunchKernelGGL(k_gather_i, dim3(nblk(nnz2)), dim3(VB), 0, ctx->stream, nnz2, (const unsigned *)nullptr, irow.dev, shifted, (int)-A->m);
+  dazim_csr *B = nullptr;
+  if ((rc = dazim_csr_from_coo(ctx, extra_m > 0 ? extra_m : 1, A->n, nnz2, shifted, icol_u, rw_u, &B))) return rc;
+  const int64_t m2 = A->m + extra_m, nz2 = A->nnz + nnz2;
+  int64_t *rowptr;
+  int *col;
+  float *val;
+  DZ_HIP(hipMalloc((void **)&rowptr, (m2 + 1) * 8));
+  DZ_HIP(hipMalloc((void **)&col, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  DZ_HIP(hipMalloc((void **)&val, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  DZ_HIP(hipMemcpyAsync(rowptr, A->rowptr, (A->m + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  if (extra_m > 0)
+    hipLaunchKernelGGL(k_offset_ptr, dim3(nblk(extra_m + 1)), dim3(VB), 0, ctx->stream, extra_m + 1, B->rowptr, A->nnz, rowptr + A->m);
+  DZ_HIP(hipMemcpyAsync(col, A->col, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(val, A->val, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(col + A->nnz, B->col, (size_t)nnz2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(val + A->nnz, B->val, (size_t)nnz2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  dazim_csr_free(ctx, B);
+  (void)hipFree(A->rowptr);
+  (void)hipFree(A->col);
+  (void)hipFree(A->val);
+  A->rowptr = rowptr; A->col = col; A->val = val;
+  A->m = m2; A->nnz = nz2;
+  if ((rc = build_transpose(ctx, A))) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// copy the matrix out as the reference's COO triplets (1-based), rows ascending
+int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow_u, int *icol_u, float *rw_u) {
+  if (!ctx || !A) return DAZIM_E_BAD_ARG;
+  DzBuf<int> irow, icol;
+  DzBuf<float> rw;
+  int rc;
+  if ((rc = irow.init(ctx, irow_u, A->nnz, false, true))) return rc;
+  if ((rc = icol.init(ctx, icol_u, A->nnz, false, true))) return rc;
+  if ((rc = rw.init(ctx, rw_u, A->nnz, false, true))) return rc;
+  if (A->nnz > 0) {
+    void *p;
+    if ((rc = dz_scratch(ctx, "csr.perm", (size_t)A->nnz * 4, &p))) return rc;
+    unsigned *rowid = (unsigned *)p;
+    hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, A->m)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, rowid);
+    const int nb = nblk(A->nnz);
+    if (irow.dev) hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, (const unsigned *)nullptr, (const int *)rowid, irow.dev, 1);
+    if (icol.dev) hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, (const unsigned *)nullptr, A->col, icol.dev, 1);
+    if (rw.dev) DZ_HIP(hipMemcpyAsync(rw.dev, A->val, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DZ_HIP(hipGetLastError());
+  }
+  if ((rc = irow.finish()) || (rc = icol.finish()) || (rc = rw.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 

@@ -123,6 +123,36 @@ int dazim_csr_dims(const dazim_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
 /* multiply every stored entry of row i by w[i] (rw(i)=rw(i)*datweight(iw(1+i)), inv/Main_Jt.f90:467) */
 int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w);
 
+/* device arrays in, ownership taken: rowptr[m+1] int64, col[nnz] 0-based int32, val[nnz] fp32   */
+int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
+                    float *val, dazim_csr **A);
+/* append rows m+1..m+extra_m given as COO with absolute 1-based row ids: how the reference adds its
+ * Tikhonov rows to the same triplet arrays (inv/TikhRegul.f90:2, inv/Main_Jt.f90:513-532)       */
+int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t nnz, const int *irow,
+                         const int *icol, const float *rw);
+/* the matrix back as the reference's triplets (1-based, rows ascending); any pointer may be NULL  */
+int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow, int *icol, float *rw);
+
+/* ---- K4+K5: receiver times, ray tracing, Frechet weights, G rows ---------------------------------
+ * = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364): srtimes (:1599), rpaths (:1735) and
+ *   the row assembly with the double ftol=1e-4 threshold, for every ray of a batch whose eikonal
+ *   fields (outputs of dazim_fmm_batch) are resident.  Row i of G belongs to ray i (the caller orders
+ *   rays period -> source -> receiver like the reference's count1); columns are the reference's
+ *   (k-1)*nvx*nvz+(jj-1)*nvx+kk, stored 0-based.
+ *  vels [nz][ny][nx]; scx,scz,period_idx[nfield] as for dazim_fmm_batch; kernel_idx[nfield] 1-based
+ *  period slot of sen_* (the reference's knumi; NULL = period_idx); veln,ttn,ttnr,nstsr,boxes: outputs
+ *  of dazim_fmm_batch; field_of_ray[nray] 0-based; rcx,rcz[nray] receiver colatitude/longitude (rad);
+ *  sen_vs,sen_vp,sen_rho [nz][kmax][nx*ny] from dazim_dispersion_kernels;
+ *  tpred[nray] out = dsurf; G out; n_boundary out = rays clipped at the model edge (rbint)       */
+int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+                       float dvzd, int kmax, const float *vels, int nfield, const float *scx,
+                       const float *scz, const int *period_idx, const int *kernel_idx,
+                       const float *veln, const float *ttn, const float *ttnr, const int *nstsr,
+                       const dazim_refbox *boxes, int64_t nray, const int *field_of_ray,
+                       const float *rcx, const float *rcz, const double *sen_vs, const double *sen_vp,
+                       const double *sen_rho, float *tpred, dazim_csr **G, int64_t *nnz,
+                       int *n_boundary);
+
 /* = aprod (inv/aprod.f90:7): mode 1: y(m) += A*x(n) ; mode 2: x(n) += A^T*y(m)                    */
 int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y);
 

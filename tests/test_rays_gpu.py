@@ -1,0 +1,111 @@
+"""-m gpu: receiver times, ray tracing / Frechet weights and G rows on the device against the oracle's
+restatement of CalSurfG (inv/CalSurfG.f90:909), fed with identical dispersion inputs.
+
+Tolerance, stated and justified: the ray tracer evaluates sin(colatitude) at every step; the device
+uses the correctly rounded fp32 sine while the CPU calls libm's sinf (<= 0.56 ulp), so a step can
+differ in the last bit and, rarely, land in the neighbouring cell.  Hence:
+  tpred (dsurf): bit-equal expected (no sine on that path except the near-source branch), asserted
+                 to rel <= 1e-6;
+  G compared densely: max |dG| <= 2e-4 (= 2*ftol: an entry sitting on the 1e-4 threshold may appear
+                 on one side only) and relative Frobenius error <= 1e-4.
+"""
+import numpy as np
+import pytest
+
+from tests import synth
+from tests.test_disp_gpu import model
+
+pytestmark = pytest.mark.gpu
+
+
+def build_case(nx, ny, depz, kmax, nsta, nrc, seed, goxd=30.0, gozd=100.0, dv=0.25):
+    rng = np.random.default_rng(seed)
+    vel = model(nx, ny, depz, seed)
+    lat, lon = synth.stations(nx, ny, goxd, gozd, dv, dv, nsta, seed)
+    sx, sz = synth.radians(lat, lon)
+    nsrc = nsta
+    scxf = np.zeros((kmax, nsrc), np.float32); sczf = scxf.copy()
+    rcxf = np.zeros((kmax, nsrc, nsta), np.float32); rczf = rcxf.copy()
+    nrc1 = np.zeros((kmax, nsrc), np.int32); nsrc1 = np.zeros(kmax, np.int32); periods = np.zeros((kmax, nsrc), np.int32)
+    for k in range(kmax):
+        ns = max(2, nsta - 1 - k)
+        nsrc1[k] = ns
+        for s in range(ns):
+            scxf[k, s] = sx[s]; sczf[k, s] = sz[s]; periods[k, s] = k + 1
+            idx = rng.permutation(np.delete(np.arange(nsta), s))[:nrc]
+            nrc1[k, s] = len(idx); rcxf[k, s, :len(idx)] = sx[idx]; rczf[k, s, :len(idx)] = sz[idx]
+    return vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods
+
+
+def flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods):
+    """period -> source -> receiver order of the reference's count1 (inv/CalSurfG.f90:1114-1328)"""
+    fs, fz, fp, ray_f, rx, rz = [], [], [], [], [], []
+    for k in range(scxf.shape[0]):
+        for s in range(nsrc1[k]):
+            f = len(fs)
+            fs.append(scxf[k, s]); fz.append(sczf[k, s]); fp.append(periods[k, s])
+            for r in range(nrc1[k, s]):
+                ray_f.append(f); rx.append(rcxf[k, s, r]); rz.append(rczf[k, s, r])
+    a = lambda v, t: np.asarray(v, t)
+    return a(fs, np.float32), a(fz, np.float32), a(fp, np.int32), a(ray_f, np.int32), a(rx, np.float32), a(rz, np.float32)
+
+
+def dense(m, n, irow, icol, rw):
+    d = np.zeros((m, n), np.float64)
+    d[irow - 1, icol - 1] = rw
+    return d
+
+
+@pytest.mark.parametrize("nx,ny,depz,kmax,minthk", [
+    (17, 17, [0.0, 10.0, 35.0, 60.0], 3, 2.0),          # test1-3 geometry
+    (14, 20, [0.0, 5.0, 10.0, 20.0, 35.0, 60.0], 2, 3.0),  # rectangular, more layers
+])
+def test_G_matches_oracle(ctx, orc, nx, ny, depz, kmax, minthk):
+    depz = np.asarray(depz, np.float32)
+    goxd, gozd, dv = 30.0, 100.0, 0.25
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 10, 6, seed=nx)
+    t = np.array([6.0, 14.0, 30.0][:kmax])
+    rc, rw_o, ir_o, ic_o, ds_o, nb_o = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
+                                                    nrc1, nsrc1, periods, 4_000_000)
+    assert rc == 0
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)   # identical dispersion inputs for the device path
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    assert len(tpred) == len(ds_o)
+    assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
+    ir, ic, rw = G.to_coo()
+    m, n = len(ds_o), (nx - 2) * (ny - 2) * (len(depz) - 1)
+    assert (G.m, G.n) == (m, n)
+    assert np.all(np.diff(ir) >= 0) and np.all(np.abs(rw) > 1e-4)        # row order + threshold
+    D, Do = dense(m, n, ir, ic, rw), dense(m, n, ir_o, ic_o, rw_o)
+    assert np.abs(D - Do).max() <= 2e-4
+    assert np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
+    # every row ascending in column = the reference's nn loop order
+    for r in np.unique(ir)[:50]:
+        assert np.all(np.diff(ic[ir == r]) > 0)
+    # Tikhonov rows appended like inv/Main_Jt.f90:513 -> same system as the oracle's
+    c3, rwT, irT, icT = orc.tikhonov_iso(nx, ny, len(depz), m, 2.0, rw_o, ir_o, ic_o)
+    G.append_coo(c3, irT[len(rw_o):], icT[len(rw_o):], rwT[len(rw_o):])
+    assert (G.m, G.nnz) == (m + c3, len(rw) + len(rwT) - len(rw_o))
+    x = np.random.default_rng(0).standard_normal(n).astype(np.float32)
+    y = np.zeros(m + c3, np.float32); yo = y.copy()
+    ctx.aprod(1, G, x, y); orc.aprod(1, m + c3, n, x.copy(), yo, irT, icT, rwT)
+    assert np.linalg.norm(y - yo) <= 1e-4 * np.linalg.norm(yo)
+    G.free()
+
+
+def test_receiver_outside_is_an_error(ctx, orc):
+    import dazimsurftomo_amd as dz
+    nx = ny = 10
+    depz = np.array([0.0, 10.0, 30.0], np.float32)
+    vel = model(nx, ny, depz, 1)
+    t = np.array([8.0])
+    pv, sen = orc.depthkernel(vel, depz, t, 2.0)
+    sx, sz = synth.radians([29.0], [101.0])
+    rx, rz = synth.radians([29.2, 45.0], [100.8, 101.0])
+    fields = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, sx, sz, np.array([1], np.int32))
+    with pytest.raises(dz.DazimError) as e:
+        ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, sx, sz, np.array([1], np.int32),
+                         np.array([0, 0], np.int32), rx, rz, sen)
+    assert e.value.code == 2  # DAZIM_E_RECEIVER_OUTSIDE, inv/CalSurfG.f90:1649-1655
