@@ -1,0 +1,269 @@
+#!/usr/bin/env python
+"""bench.py -- the DAzimSurfTomo hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sources S] [--receivers R] [--no-cpu]
+
+One "step" = one pass of the hot path over the S-256 synthetic batch: dispersion +
+depth kernels for every model column, 16 periods x S sources eikonal fields on the 256x256 grid,
+R rays per field traced into the sensitivity matrix G, Tikhonov rows appended, and a fixed number
+of LSMR iterations on G.  Inputs are generated once and are resident in HBM before the timed region.
+`value` = eikonal fields per second of whole steps (all ranks), the first half of the BASELINE
+metric; the second half (LSMR SpMV HBM GB/s) is reported in `spmv`.  With --gpus N (launched by
+torch.distributed.run, one rank per GPU) every rank processes its own S sources (weak scaling, no
+data-path collective in the forward pass).
+
+The JSON line also carries `roofline` for the dominant kernel (the eikonal kernel, latency-bound:
+its HBM fraction is reported for transparency, not as a target), `spmv` (the HBM-bound kernel the
+40 % target applies to) and `cpu_baseline` (the oracle = plain-C port of the reference, 1 thread, on
+a bounded sample of the same workload on this box's host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX = NY = 54                    # -> 256 x 256 propagation nodes
+GOXD, GOZD, DV = 30.0, 100.0, 0.25
+DEPZ = np.arange(12, dtype=np.float32) * 5.0   # 12 knots, 0..55 km
+MINTHK = 3.0                    # sublayers -> rmax = 45
+PERIODS = np.arange(5, 37, 2, dtype=np.float64)   # 16 periods 5..35 s
+HBM_PEAK_GBS = 8000.0
+BYTES_PER_FIELD = 256 * 256 * 8 + 129 * 129 * 8   # read veln + write ttn, coarse + refined
+
+
+def s256_model(seed=20250929):
+    """Vs(z) = 3.0 + 0.03 z, +-6 % checkerboard (4x4 cells, alternating by depth pair), 1 % noise"""
+    rng = np.random.default_rng(seed)
+    nz = len(DEPZ)
+    jj, ii = np.meshgrid(np.arange(NY), np.arange(NX), indexing="ij")
+    from tests.synth import smooth_noise
+    vel = np.zeros((nz, NY, NX), np.float32)
+    for k in range(nz):
+        checker = np.where(((ii // 4) + (jj // 4) + (k // 2)) % 2 == 0, 1.0, -1.0)
+        v = (3.0 + 0.03 * DEPZ[k]) * (1 + 0.06 * checker) + 0.01 * smooth_noise(rng, (NY, NX))
+        vel[k] = np.clip(v, 2.5, 4.8)
+    return vel
+
+
+def workload(nsrc, nrcv, rank):
+    from tests import synth
+    kmax = len(PERIODS)
+    lat, lon = synth.stations(NX, NY, GOXD, GOZD, DV, DV, nsrc, seed=1 + 1000 * rank, shrink=0.3)
+    sx, sz = synth.radians(lat, lon)
+    scx = np.tile(sx, kmax)
+    scz = np.tile(sz, kmax)
+    per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
+    rng = np.random.default_rng(2 + rank)
+    rcv = np.stack([rng.permutation(np.delete(np.arange(nsrc), s))[:nrcv] for s in range(nsrc)])  # [nsrc][nrcv]
+    nr = rcv.shape[1]
+    field_of_ray = np.repeat(np.arange(kmax * nsrc, dtype=np.int32), nr)
+    ridx = np.tile(rcv, (kmax, 1)).reshape(-1)
+    return scx, scz, per, field_of_ray, sx[ridx].copy(), sz[ridx].copy()
+
+
+def tikhonov_rows(nx, ny, nz, dall, w):
+    """7-point Laplacian rows of inv/TikhRegul.f90:2 (host side of the path, O(n))"""
+    nvx, nvz = nx - 2, ny - 2
+    ir, ic, rw = [], [], []
+    cnt = 0
+    for k in range(1, nz):
+        for j in range(1, nvz + 1):
+            for i in range(1, nvx + 1):
+                c0 = (k - 1) * nvz * nvx + (j - 1) * nvx + i
+                cnt += 1
+                if i in (1, nvx) or j in (1, nvz) or k in (1, nz - 1):
+                    ir.append(dall + cnt); ic.append(c0); rw.append(2.0 * w)
+                else:
+                    for c, v in ((c0, 6.0), (c0 - 1, -1.0), (c0 + 1, -1.0), (c0 - nvx, -1.0), (c0 + nvx, -1.0),
+                                 (c0 - nvz * nvx, -1.0), (c0 + nvz * nvx, -1.0)):
+                        ir.append(dall + cnt); ic.append(c); rw.append(v * w)
+    return cnt, np.array(ir, np.int32), np.array(ic, np.int32), np.array(rw, np.float32)
+
+
+def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_per_field, budget_s=20.0):
+    """the oracle (plain-C port of the reference, 1 thread) on a bounded sample of the same workload"""
+    from oracle.pyoracle import Oracle, build
+    build()
+    orc = Oracle()
+    kmax = len(PERIODS)
+    ncolumns = NX * NY
+    # dispersion + depth kernels: a few columns (each = 73 curves x 16 periods)
+    ncol_s = 6
+    sub = np.ascontiguousarray(vel[:, 20:21, 10:10 + ncol_s])
+    t0 = time.perf_counter()
+    orc.depthkernel(sub, DEPZ, PERIODS, MINTHK)
+    t_disp_col = (time.perf_counter() - t0) / ncol_s
+    # eikonal fields + their rays
+    pv_full, sen = None, None
+    from tests import synth
+    pv_maps = synth.phase_velocity_maps(NX, NY, kmax)   # same shape/statistics as pvRc; avoids 2916 CPU columns
+    g = orc.geometry(NX, NY, GOXD, GOZD, DV, DV)
+    t_f = t_r = 0.0
+    nf = nr = 0
+    t_start = time.perf_counter()
+    stride = max(1, nfield_total // 400)
+    for f in range(0, nfield_total, stride):
+        k = per[f] - 1
+        veln = orc.gridder(g, pv_maps[k])
+        t0 = time.perf_counter()
+        veln = orc.gridder(g, pv_maps[k])          # the reference re-grids per source (inv/CalSurfG.f90:1146)
+        rc, ttn, ttnr, nstsr, velnr, box = orc.fmm_field(g, pv_maps[k], veln, scx[f], scz[f])
+        t_f += time.perf_counter() - t0
+        nf += 1
+        rays = np.nonzero(field_of_ray == f)[0][:8]
+        t0 = time.perf_counter()
+        for r in rays:
+            orc.srtimes(g, veln, ttn, scx[f], scz[f], rcx[r], rcz[r])
+            orc.rpaths(g, box, veln, ttn, ttnr, nstsr, scx[f], scz[f], rcx[r], rcz[r])
+        t_r += time.perf_counter() - t0
+        nr += len(rays)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    t_field = t_f / nf
+    t_ray = t_r / max(nr, 1)
+    per_field = t_field + rays_per_field * t_ray + t_disp_col * ncolumns / nfield_total
+    return {
+        "value": 1.0 / per_field, "unit": "fields/s", "cores": 1, "kind": "port",
+        "sample": f"{ncol_s} columns of depthkernel (73 curves x 16 periods each), {nf} eikonal fields 256x256, "
+                  f"{nr} rays traced (row assembly excluded); forward time per field = fmm + {rays_per_field} rays + "
+                  f"dispersion share of {ncolumns} columns / {nfield_total} fields",
+        "fmm_fields_per_s": 1.0 / t_field, "rays_per_s": 1.0 / t_ray, "depthkernel_columns_per_s": 1.0 / t_disp_col,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--sources", type=int, default=1000)
+    ap.add_argument("--receivers", type=int, default=32)
+    ap.add_argument("--lsmr-iters", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import dazimsurftomo_amd as dz
+    dz.build()
+    ctx = dz.Context(local)
+
+    kmax = len(PERIODS)
+    vel = s256_model()
+    scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, rank)
+    nfield, nray = len(scx), len(rcx)
+    rays_per_field = nray // nfield
+    g = dz.geometry(NX, NY, GOXD, GOZD, DV, DV)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_vel, d_scx, d_scz, d_per = T(vel), T(scx), T(scz), T(per)
+    d_fray, d_rcx, d_rcz = T(field_of_ray), T(rcx), T(rcz)
+    ncol = NX * NY
+    nz = len(DEPZ)
+    d_pv = torch.empty((kmax, ncol), dtype=torch.float64, device=dev)
+    d_sen = [torch.empty((nz, kmax, ncol), dtype=torch.float64, device=dev) for _ in range(3)]
+    d_veln = torch.empty((kmax, g.nnx, g.nnz), dtype=torch.float32, device=dev)
+    d_ttn = torch.empty((nfield, g.nnx, g.nnz), dtype=torch.float32, device=dev)
+    d_ttnr = torch.empty((nfield, 129, 129), dtype=torch.float32, device=dev)
+    d_nstsr = torch.empty((nfield, 129, 129), dtype=torch.int32, device=dev)
+    d_box = torch.empty((nfield, 12), dtype=torch.int32, device=dev)
+    d_st = torch.empty((nfield,), dtype=torch.int32, device=dev)
+    d_tpred = torch.empty((nray,), dtype=torch.float32, device=dev)
+    n_model = (NX - 2) * (NY - 2) * (nz - 1)
+    c3, t_ir, t_ic, t_rw = tikhonov_rows(NX, NY, nz, nray, 2.0)
+    rng = np.random.default_rng(3)
+    d_b = T(np.concatenate([(rng.standard_normal(nray) * 0.5).astype(np.float32), np.zeros(c3, np.float32)]))
+    d_x = torch.zeros(n_model, dtype=torch.float32, device=dev)
+
+    stats = {}
+
+    def step():
+        pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
+        stats["disp_s"] = ctx.kernel_seconds("disp")
+        fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, d_pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
+                               ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
+        stats["fmm_s"] = ctx.kernel_seconds("fmm")
+        G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
+                                        d_rcx, d_rcz, d_sen, tpred=d_tpred)
+        stats["rays_s"] = ctx.kernel_seconds("rays")
+        stats["nnz_data"] = G.nnz
+        G.append_coo(c3, t_ir, t_ic, t_rw)
+        stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
+        x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
+        stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
+        stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        stats["lsmr_itn"] = info["itn"]
+        stats["nfail"] = nfail
+        G.free()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        total_fields = nfield * world
+        fmm_gbs = BYTES_PER_FIELD * nfield / stats["fmm_s"] / 1e9
+        m, n, nnz = stats["m"], stats["n"], stats["nnz"]
+        b_ax = nnz * 8 + (m + 1) * 8 + n * 4 + 2 * m * 4      # A*x : CSR stream + rowptr + x + u read/write
+        b_aty = nnz * 8 + (n + 1) * 8 + m * 4 + 2 * n * 4
+        out = {
+            "metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s",
+            "value": total_fields / (dt / a.steps), "unit": "fields/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S-256: 54x54x12 model -> 256x256 nodes, 16 periods 5..35 s, {a.sources} sources x "
+                                   f"{rays_per_field} receivers per GPU ({nfield} fields, {nray} rays), "
+                                   f"{a.lsmr_iters} LSMR iterations", "fields_per_gpu": nfield, "rays_per_gpu": nray},
+            "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fmm_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "note": "latency-bound by the serial heap order of fast marching; algorithmic bytes = "
+                                 f"{BYTES_PER_FIELD} B/field x {nfield} fields per launch"},
+            "spmv": {"kernel": "spmv_rows", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "Ax": {"us": stats["spmv_s"] * 1e6, "achieved": b_ax / stats["spmv_s"] / 1e9,
+                            "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS},
+                     "ATy": {"us": stats["spmvt_s"] * 1e6, "achieved": b_aty / stats["spmvt_s"] / 1e9,
+                             "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS},
+                     "m": m, "n": n, "nnz": nnz},
+            "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
+            "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
+            "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],
+        }
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
+            out["speedup_vs_cpu_1core_forward"] = (nfield / (stats["disp_s"] + stats["fmm_s"] + stats["rays_s"])) / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
