@@ -1,0 +1,259 @@
+! dazim_mod.f90 -- Fortran host side of the MI355X hot path.
+!
+! ISO_C_BINDING interfaces to libdazim_hip.so (include/dazim.h) plus drop-in procedures that keep
+! the reference's names and argument lists, so that a host written like the reference's
+! Main_Jt.f90 links against this module instead of CalSurfG.f90 / lsmrModule.f90 / aprod.f90:
+!
+!   depthkernel(nx,ny,nz,vel,pvRc,sen_vsRc,sen_vpRc,sen_rhoRc,iwave,igr,kmaxRc,tRc,depz,minthk)
+!        = inv/CalSurfG.f90:1
+!   CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf,GVs,dall,goxdf,gozdf,dvxdf,dvzdf,kmaxRc,tRc,
+!            periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
+!        = inv/CalSurfG.f90:909 (the dense GVs copy is not filled: see DESIGN.md, N2)
+!   aprod(mode,m,n,x,y,leniw,lenrw,iw,rw)                      = inv/aprod.f90:7
+!   LSMR(m,n,leniw,lenrw,iw,rw,b,damp,atol,btol,conlim,itnlim,localSize,nout,x,istop,itn,
+!        normA,condA,normr,normAr,normx)                      = inv/lsmrModule.f90:36
+!
+! Error behaviour follows the reference: a source or receiver outside the model STOPs with the
+! reference's message; other library errors STOP with the library's message.
+module dazim_mod
+  use iso_c_binding
+  implicit none
+  private
+  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, aprod, LSMR, dazim_handle
+
+  type(c_ptr), save :: dazim_handle = c_null_ptr
+
+  type, bind(C) :: dazim_refbox
+    integer(c_int) :: vnl, vnr, vnt, vnb, nnxr, nnzr, isx, isz
+    real(c_float) :: goxr, gozr, dnxr, dnzr
+  end type
+
+  interface
+    integer(c_int) function dazim_create(ctx, device) bind(C, name="dazim_create")
+      import; type(c_ptr) :: ctx; integer(c_int), value :: device
+    end function
+    subroutine dazim_destroy(ctx) bind(C, name="dazim_destroy")
+      import; type(c_ptr), value :: ctx
+    end subroutine
+    type(c_ptr) function dazim_last_error(ctx) bind(C, name="dazim_last_error")
+      import; type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function dazim_dispersion_kernels(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, &
+        pv, svs, svp, srho, nfail) bind(C, name="dazim_dispersion_kernels")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nx, ny, nz, kmax
+      real(c_float), value :: sublayers
+      real(c_float) :: vel(*), depz(*)
+      real(c_double) :: periods(*), pv(*), svs(*), svp(*), srho(*)
+      integer(c_int) :: nfail
+    end function
+    integer(c_int) function dazim_fmm_batch(ctx, nx, ny, goxd, gozd, dvxd, dvzd, kmax, pv, nfield, scx, scz, &
+        period_idx, veln, ttn, ttnr, nstsr, boxes, status) bind(C, name="dazim_fmm_batch")
+      import
+      type(c_ptr), value :: ctx, veln, ttn, ttnr, nstsr, boxes, status
+      integer(c_int), value :: nx, ny, kmax, nfield
+      real(c_float), value :: goxd, gozd, dvxd, dvzd
+      real(c_double) :: pv(*)
+      real(c_float) :: scx(*), scz(*)
+      integer(c_int) :: period_idx(*)
+    end function
+    integer(c_int) function dazim_rays_build_G(ctx, nx, ny, nz, goxd, gozd, dvxd, dvzd, kmax, vels, nfield, scx, scz, &
+        period_idx, kernel_idx, veln, ttn, ttnr, nstsr, boxes, nray, field_of_ray, rcx, rcz, svs, svp, srho, &
+        tpred, G, nnz, nboundary) bind(C, name="dazim_rays_build_G")
+      import
+      type(c_ptr), value :: ctx, veln, ttn, ttnr, nstsr, boxes
+      integer(c_int), value :: nx, ny, nz, kmax, nfield
+      integer(c_int64_t), value :: nray
+      real(c_float), value :: goxd, gozd, dvxd, dvzd
+      real(c_float) :: vels(*), scx(*), scz(*), rcx(*), rcz(*), tpred(*)
+      integer(c_int) :: period_idx(*), kernel_idx(*), field_of_ray(*), nboundary
+      real(c_double) :: svs(*), svp(*), srho(*)
+      type(c_ptr) :: G
+      integer(c_int64_t) :: nnz
+    end function
+    integer(c_int) function dazim_malloc(ctx, p, bytes) bind(C, name="dazim_malloc")
+      import; type(c_ptr), value :: ctx; type(c_ptr) :: p; integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function dazim_free(ctx, p) bind(C, name="dazim_free")
+      import; type(c_ptr), value :: ctx, p
+    end function
+    integer(c_int) function dazim_csr_from_coo(ctx, m, n, nnz, irow, icol, rw, A) bind(C, name="dazim_csr_from_coo")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int64_t), value :: m, n, nnz
+      integer(c_int) :: irow(*), icol(*)
+      real(c_float) :: rw(*)
+      type(c_ptr) :: A
+    end function
+    integer(c_int) function dazim_csr_to_coo(ctx, A, irow, icol, rw) bind(C, name="dazim_csr_to_coo")
+      import
+      type(c_ptr), value :: ctx, A
+      integer(c_int) :: irow(*), icol(*)
+      real(c_float) :: rw(*)
+    end function
+    integer(c_int) function dazim_csr_free(ctx, A) bind(C, name="dazim_csr_free")
+      import; type(c_ptr), value :: ctx, A
+    end function
+    integer(c_int) function dazim_aprod(ctx, mode, A, x, y) bind(C, name="dazim_aprod")
+      import
+      type(c_ptr), value :: ctx, A
+      integer(c_int), value :: mode
+      real(c_float) :: x(*), y(*)
+    end function
+    integer(c_int) function dazim_lsmr(ctx, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
+        normA, condA, normr, normAr, normx) bind(C, name="dazim_lsmr")
+      import
+      type(c_ptr), value :: ctx, A
+      real(c_float) :: b(*), x(*)
+      real(c_float), value :: damp, atol, btol, conlim
+      integer(c_int), value :: itnlim, localSize
+      integer(c_int) :: istop, itn
+      real(c_float) :: normA, condA, normr, normAr, normx
+    end function
+  end interface
+
+contains
+
+  subroutine dazim_init(device)
+    integer, intent(in) :: device
+    if (c_associated(dazim_handle)) return
+    if (dazim_create(dazim_handle, int(device, c_int)) /= 0) stop 'dazim_create failed: no MI355X visible'
+  end subroutine
+
+  subroutine dazim_finalize()
+    if (c_associated(dazim_handle)) call dazim_destroy(dazim_handle)
+    dazim_handle = c_null_ptr
+  end subroutine
+
+  subroutine check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: what
+    character(kind=c_char), pointer :: msg(:)
+    integer :: i
+    if (rc == 0) return
+    if (rc == 1) then
+      write (6, *) "Source lies outside bounds of model"       ! inv/CalSurfG.f90:1177
+      write (6, *) "TERMINATING PROGRAM!!!"
+    else if (rc == 2) then
+      write (6, *) "Receiver lies outside model"               ! inv/CalSurfG.f90:1652
+      write (6, *) "TERMINATING PROGRAM!!!!"
+    end if
+    call c_f_pointer(dazim_last_error(dazim_handle), msg, [512])
+    do i = 1, 512
+      if (msg(i) == c_null_char) exit
+    end do
+    write (6, *) what, ': ', msg(1:i - 1)
+    stop
+  end subroutine
+
+  ! ---- inv/CalSurfG.f90:1 ------------------------------------------------------------------------
+  subroutine depthkernel(nx, ny, nz, vel, pvRc, sen_vsRc, sen_vpRc, sen_rhoRc, iwave, igr, kmaxRc, tRc, depz, minthk)
+    integer :: nx, ny, nz, iwave, igr, kmaxRc
+    real :: vel(nx, ny, nz), depz(nz), minthk
+    real*8 :: pvRc(nx*ny, kmaxRc), sen_vsRc(nx*ny, kmaxRc, nz), sen_vpRc(nx*ny, kmaxRc, nz), sen_rhoRc(nx*ny, kmaxRc, nz)
+    real*8 :: tRc(kmaxRc)
+    integer(c_int) :: nfail
+    if (iwave /= 2 .or. igr /= 0) stop 'Can only deal with Rayleigh wave phase velocity data!'  ! inv/Main_Jt.f90:213
+    call dazim_init(0)
+    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pvRc, &
+                                        sen_vsRc, sen_vpRc, sen_rhoRc, nfail), 'depthkernel')
+    if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
+  end subroutine
+
+  ! ---- inv/CalSurfG.f90:909 ----------------------------------------------------------------------
+  subroutine CalSurfG(nx, ny, nz, nparpi, vels, iw, rw, col, dsurf, GVs, dall, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
+                      periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar)
+    integer :: nx, ny, nz, nparpi, dall, kmaxRc, kmax, nsrcsurf, nrcf, nar
+    real :: vels(nx, ny, nz), rw(*), dsurf(*), GVs(dall, *), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
+    integer :: iw(*), col(*)
+    real*8 :: tRc(*)
+    integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
+    real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
+    real*8, allocatable :: pv(:, :), svs(:, :, :), svp(:, :, :), srho(:, :, :)
+    real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
+    integer, allocatable :: per(:), kidx(:), fray(:), irow(:)
+    type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box, G
+    integer :: nfield, nray, k, s, r, f, nnx, nnz
+    integer(c_int) :: nfail, nb
+    integer(c_int64_t) :: nnz64
+    integer(c_size_t) :: nn
+    call dazim_init(0)
+    allocate (pv(nx*ny, kmaxRc), svs(nx*ny, kmaxRc, nz), svp(nx*ny, kmaxRc, nz), srho(nx*ny, kmaxRc, nz))
+    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, svs, svp, srho, nfail), &
+               'CalSurfG/depthkernel')
+    ! flatten the (period, source, receiver) loops in the reference's order (:1114-1326)
+    nfield = sum(nsrcsurf1(1:kmax)); nray = 0
+    do k = 1, kmax
+      nray = nray + sum(nrc1(1:nsrcsurf1(k), k))
+    end do
+    allocate (scx(nfield), scz(nfield), per(nfield), kidx(nfield), fray(max(nray, 1)), rcx(max(nray, 1)), rcz(max(nray, 1)))
+    f = 0; nray = 0
+    do k = 1, kmax
+      do s = 1, nsrcsurf1(k)
+        f = f + 1
+        scx(f) = scxf(s, k); scz(f) = sczf(s, k); per(f) = periods(s, k); kidx(f) = k
+        do r = 1, nrc1(s, k)
+          nray = nray + 1
+          fray(nray) = f - 1; rcx(nray) = rcxf(r, s, k); rcz(nray) = rczf(r, s, k)
+        end do
+      end do
+    end do
+    nnx = (nx - 3)*5 + 1; nnz = (ny - 3)*5 + 1
+    nn = int(nnx, c_size_t)*nnz
+    ! eikonal fields stay on the device between the two calls
+    call check(dazim_malloc(dazim_handle, d_veln, nn*kmaxRc*4), 'malloc')
+    call check(dazim_malloc(dazim_handle, d_ttn, nn*nfield*4), 'malloc')
+    call check(dazim_malloc(dazim_handle, d_ttnr, int(129*129, c_size_t)*nfield*4), 'malloc')
+    call check(dazim_malloc(dazim_handle, d_nstsr, int(129*129, c_size_t)*nfield*4), 'malloc')
+    call check(dazim_malloc(dazim_handle, d_box, int(48, c_size_t)*nfield), 'malloc')
+    call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, pv, nfield, scx, scz, per, &
+                               d_veln, d_ttn, d_ttnr, d_nstsr, d_box, c_null_ptr), 'CalSurfG/travel')
+    call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
+                                  per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
+                                  svs, svp, srho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+    nar = int(nnz64)
+    allocate (irow(max(nar, 1)))
+    call check(dazim_csr_to_coo(dazim_handle, G, irow, col, rw), 'CalSurfG/coo')
+    iw(2:nar + 1) = irow(1:nar)             ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
+    if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
+    call check(dazim_csr_free(dazim_handle, G), 'free')
+    call check(dazim_free(dazim_handle, d_veln), 'free'); call check(dazim_free(dazim_handle, d_ttn), 'free')
+    call check(dazim_free(dazim_handle, d_ttnr), 'free'); call check(dazim_free(dazim_handle, d_nstsr), 'free')
+    call check(dazim_free(dazim_handle, d_box), 'free')
+  end subroutine
+
+  ! ---- inv/aprod.f90:7 -----------------------------------------------------------------------------
+  subroutine aprod(mode, m, n, x, y, leniw, lenrw, iw, rw)
+    integer :: mode, m, n, leniw, lenrw, iw(leniw)
+    real :: x(n), y(m), rw(lenrw)
+    type(c_ptr) :: A
+    integer :: kk
+    call dazim_init(0)
+    kk = iw(1)
+    call check(dazim_csr_from_coo(dazim_handle, int(m, c_int64_t), int(n, c_int64_t), int(kk, c_int64_t), &
+                                  iw(2:kk + 1), iw(kk + 2:2*kk + 1), rw, A), 'aprod')
+    call check(dazim_aprod(dazim_handle, mode, A, x, y), 'aprod')
+    call check(dazim_csr_free(dazim_handle, A), 'aprod')
+  end subroutine
+
+  ! ---- inv/lsmrModule.f90:36 -------------------------------------------------------------------------
+  subroutine LSMR(m, n, leniw, lenrw, iw, rw, b, damp, atol, btol, conlim, itnlim, localSize, nout, &
+                  x, istop, itn, normA, condA, normr, normAr, normx)
+    integer, intent(in) :: m, n, leniw, lenrw, iw(leniw), itnlim, localSize, nout
+    real, intent(in) :: rw(lenrw), b(m), damp, atol, btol, conlim
+    real, intent(out) :: x(n), normA, condA, normr, normAr, normx
+    integer, intent(out) :: istop, itn
+    type(c_ptr) :: A
+    integer :: kk
+    call dazim_init(0)
+    kk = iw(1)
+    call check(dazim_csr_from_coo(dazim_handle, int(m, c_int64_t), int(n, c_int64_t), int(kk, c_int64_t), &
+                                  iw(2:kk + 1), iw(kk + 2:2*kk + 1), rw, A), 'LSMR')
+    call check(dazim_lsmr(dazim_handle, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
+                          normA, condA, normr, normAr, normx), 'LSMR')
+    call check(dazim_csr_free(dazim_handle, A), 'LSMR')
+    if (nout > 0) write (nout, '(a,i3,a,i8,a,es12.5,a,es12.5)') ' Exit  LSMR.  istop =', istop, '  itn =', itn, &
+      '  normA =', normA, '  normr =', normr
+  end subroutine
+end module dazim_mod

@@ -1,0 +1,73 @@
+! host_example.f90 -- a Fortran host in the style of the reference's Main_Jt.f90 inner loop:
+! CalSurfG (G assembly) -> LSMR, through dazim_mod.  Input/outputs are plain list-directed text so
+! that tests can drive it:
+!   in : nx ny nz kmax nsrc nrcf / goxd gozd dvxd dvzd minthk / depz / periods(tRc) /
+!        vels (k, j, i fastest like the reference's MOD) / nsrc1(kmax) /
+!        per (period k, source s): scx scz nrc  then nrc lines rcx rcz   (radians)
+!        damp atol btol conlim itnlim localSize
+!   out: nar dall / dsurf / istop itn normA normr normx / x
+program host_example
+  use dazim_mod
+  implicit none
+  integer :: nx, ny, nz, kmax, nsrc, nrcf, k, s, r, i, j, dall, nar, maxnar, n, m
+  real :: goxd, gozd, dvxd, dvzd, minthk, damp, atol, btol, conlim
+  integer :: itnlim, localSize, istop, itn
+  real :: normA, condA, normr, normAr, normx
+  real, allocatable :: depz(:), vels(:, :, :), scxf(:, :), sczf(:, :), rcxf(:, :, :), rczf(:, :, :), rw(:), dsurf(:), GVs(:, :)
+  real, allocatable :: b(:), x(:)
+  real*8, allocatable :: tRc(:)
+  integer, allocatable :: nsrc1(:), nrc1(:, :), periods(:, :), iw(:), col(:)
+  character(len=256) :: fin, fout
+  call getarg(1, fin); call getarg(2, fout)
+  open (10, file=fin, status='old')
+  read (10, *) nx, ny, nz, kmax, nsrc, nrcf
+  read (10, *) goxd, gozd, dvxd, dvzd, minthk
+  allocate (depz(nz), tRc(kmax), vels(nx, ny, nz), nsrc1(kmax), nrc1(nsrc, kmax), periods(nsrc, kmax))
+  allocate (scxf(nsrc, kmax), sczf(nsrc, kmax), rcxf(nrcf, nsrc, kmax), rczf(nrcf, nsrc, kmax))
+  read (10, *) depz
+  read (10, *) tRc
+  do k = 1, nz
+    do j = 1, ny
+      read (10, *) (vels(i, j, k), i=1, nx)
+    end do
+  end do
+  read (10, *) nsrc1
+  nrc1 = 0; periods = 0; scxf = 0; sczf = 0; rcxf = 0; rczf = 0; dall = 0
+  do k = 1, kmax
+    do s = 1, nsrc1(k)
+      read (10, *) scxf(s, k), sczf(s, k), nrc1(s, k)
+      periods(s, k) = k
+      do r = 1, nrc1(s, k)
+        read (10, *) rcxf(r, s, k), rczf(r, s, k)
+        dall = dall + 1
+      end do
+    end do
+  end do
+  read (10, *) damp, atol, btol, conlim, itnlim, localSize
+  close (10)
+  n = (nx - 2)*(ny - 2)*(nz - 1)
+  maxnar = dall*n
+  allocate (rw(maxnar), iw(2*maxnar + 1), col(maxnar), dsurf(dall), GVs(1, 1))
+  call CalSurfG(nx, ny, nz, n, vels, iw, rw, col, dsurf, GVs, 1, goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
+                scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar)
+  ! pack iw = [nar | rows | cols] like inv/Main_Jt.f90:529-532 and solve G x = dsurf*1e-3 with LSMR
+  iw(1) = nar
+  do i = 1, nar
+    iw(1 + nar + i) = col(i)
+  end do
+  m = dall
+  allocate (b(m), x(n))
+  b = dsurf*1.0e-3
+  call LSMR(m, n, 2*nar + 1, nar, iw, rw, b, damp, atol, btol, conlim, itnlim, localSize, 0, &
+            x, istop, itn, normA, condA, normr, normAr, normx)
+  open (11, file=fout)
+  write (11, *) nar, dall
+  write (11, '(5es16.8)') dsurf
+  write (11, *) istop, itn, normA, normr, normx
+  write (11, '(5es16.8)') x
+  write (11, '(5es16.8)') rw(1:nar)
+  write (11, '(10i8)') iw(2:nar + 1)
+  write (11, '(10i8)') col(1:nar)
+  close (11)
+  call dazim_finalize()
+end program

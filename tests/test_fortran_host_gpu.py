@@ -1,0 +1,67 @@
+"""-m gpu: the Fortran host (host/dazim_mod.f90 + host/host_example.f90, built with flang) drives
+CalSurfG -> LSMR through ISO_C_BINDING; its outputs are compared with the oracle's CalSurfG and
+LSMR on the same input.  Tolerances as in test_rays_gpu.py / test_sparse_gpu.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.test_rays_gpu import build_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "host", "host_example")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(EXE), reason="no flang and no prebuilt host")
+def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
+    import dazimsurftomo_amd as dz
+    dz.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "all"])
+    nx = ny = 13
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    kmax, nsta, nrc = 2, 8, 5
+    goxd, gozd, dv, minthk = 30.0, 100.0, 0.25, 2.0
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, nsta, nrc, seed=21)
+    t = np.array([8.0, 20.0])
+    fin, fout = tmp_path / "in.txt", tmp_path / "out.txt"
+    cfg = (0.01, 1e-5, 1e-4, 200.0, 500, 10)
+    with open(fin, "w") as f:
+        f.write(f"{nx} {ny} {len(depz)} {kmax} {nsta} {nsta}\n{goxd} {gozd} {dv} {dv} {minthk}\n")
+        f.write(" ".join(repr(float(v)) for v in depz) + "\n" + " ".join(repr(float(v)) for v in t) + "\n")
+        for k in range(len(depz)):
+            for j in range(ny):
+                f.write(" ".join("%.9g" % v for v in vel[k, j]) + "\n")
+        f.write(" ".join(str(int(v)) for v in nsrc1) + "\n")
+        for k in range(kmax):
+            for s in range(nsrc1[k]):
+                f.write("%.9g %.9g %d\n" % (scxf[k, s], sczf[k, s], nrc1[k, s]))
+                for r in range(nrc1[k, s]):
+                    f.write("%.9g %.9g\n" % (rcxf[k, s, r], rczf[k, s, r]))
+        f.write("%g %g %g %g %d %d\n" % cfg)
+    subprocess.check_call([EXE, str(fin), str(fout)], timeout=300)
+    toks = open(fout).read().split()
+    nar, dall = int(toks[0]), int(toks[1])
+    p = 2
+    dsurf = np.array(toks[p:p + dall], np.float32); p += dall
+    istop, itn = int(toks[p]), int(toks[p + 1]); normA, normr, normx = map(float, toks[p + 2:p + 5]); p += 5
+    n = (nx - 2) * (ny - 2) * (len(depz) - 1)
+    x = np.array(toks[p:p + n], np.float32); p += n
+    rw = np.array(toks[p:p + nar], np.float32); p += nar
+    irow = np.array(toks[p:p + nar], np.int32); p += nar
+    icol = np.array(toks[p:p + nar], np.int32)
+    rc, rw_o, ir_o, ic_o, ds_o, nb = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
+                                                  nrc1, nsrc1, periods, 2_000_000)
+    assert rc == 0 and dall == len(ds_o)
+    assert np.abs(dsurf - ds_o).max() <= 2e-6 * np.abs(ds_o).max()   # text round trip keeps 9 digits
+    D = np.zeros((dall, n)); D[irow - 1, icol - 1] = rw
+    Do = np.zeros((dall, n)); Do[ir_o - 1, ic_o - 1] = rw_o
+    assert np.abs(D - Do).max() <= 2e-4 and np.linalg.norm(D - Do) <= 2e-4 * np.linalg.norm(Do)
+    # LSMR parity is judged on the host's own G (9 significant digits survive the text round trip),
+    # so that the 2e-4 differences between the two G's do not leak into an ill-conditioned solve
+    b = (dsurf * np.float32(1e-3)).astype(np.float32)
+    xo, io = orc.lsmr(dall, n, irow, icol, rw, b, *cfg)
+    assert istop == io["istop"] and abs(itn - io["itn"]) <= max(3, 0.03 * io["itn"])
+    assert abs(normr - io["normr"]) <= 1e-3 * io["normr"] + 1e-7
+    assert np.linalg.norm(x - xo) <= 5e-3 * np.linalg.norm(xo)
