@@ -184,8 +184,14 @@ def main():
     d_st = torch.empty((nfield,), dtype=torch.int32, device=dev)
     d_tpred = torch.empty((nray,), dtype=torch.float32, device=dev)
     n_model = (NX - 2) * (NY - 2) * (nz - 1)
-    c3, t_ir, t_ic, t_rw = tikhonov_rows(NX, NY, nz, nray, 2.0)
-    rng = np.random.default_rng(3)
+    c3_all, t_ir, t_ic, t_rw = tikhonov_rows(NX, NY, nz, nray, 2.0)
+    c3 = c3_all
+    if world > 1:   # every rank keeps its own ray rows + an even slice of the Tikhonov rows
+        from dazimsurftomo_amd.distributed import GpuLocalOps, lsmr_distributed, shard_rows
+        r0, r1 = shard_rows(c3_all, world, rank)
+        keep = (t_ir > nray + r0) & (t_ir <= nray + r1)
+        t_ir, t_ic, t_rw, c3 = (t_ir[keep] - r0).astype(np.int32), t_ic[keep], t_rw[keep], r1 - r0
+    rng = np.random.default_rng(3 + rank)
     d_b = T(np.concatenate([(rng.standard_normal(nray) * 0.5).astype(np.float32), np.zeros(c3, np.float32)]))
     d_x = torch.zeros(n_model, dtype=torch.float32, device=dev)
 
@@ -203,9 +209,16 @@ def main():
         stats["nnz_data"] = G.nnz
         G.append_coo(c3, t_ir, t_ic, t_rw)
         stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
-        x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
-        stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
-        stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        if world == 1:
+            x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
+            stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
+            stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        else:           # row-partitioned G, one RCCL all-reduce of G^T u (n floats) + one scalar per iteration
+            t_l = time.perf_counter()
+            x, info = lsmr_distributed(GpuLocalOps(ctx, G), d_b, n_model, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10)
+            torch.cuda.synchronize()
+            stats["lsmr_s"] = time.perf_counter() - t_l
+            stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
         stats["lsmr_itn"] = info["itn"]
         stats["nfail"] = nfail
         G.free()

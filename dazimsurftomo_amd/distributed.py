@@ -1,0 +1,206 @@
+"""Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+Forward pass: the (source x period) eikonal fields and their rays are independent, so they are
+sharded over ranks with NO collective (`shard_fields`); every rank recomputes the small dispersion
+tables.  Solve: G is row-partitioned exactly as its rows were produced (each rank keeps the rows of
+its own rays; the Tikhonov rows are split evenly, `shard_rows`), and LSMR (inv/lsmrModule.f90:36)
+needs per iteration one all-reduce of the n-vector A^T u and one scalar all-reduce for ||u||^2;
+everything n-sized (v, h, hbar, x, localV) is replicated and updated redundantly, so no other
+exchange exists.  At n <= 350 k floats the message is <= 1.4 MB: latency-bound, one ring pass.
+
+`lsmr_distributed` is the driver; the local products come from a `LocalOps` object: on GPUs
+`GpuLocalOps` (the HIP SpMV kernels through the C ABI on torch CUDA tensors), in the CPU gloo tests a
+test double backed by the oracle.  The scalar recurrences are the reference's, in fp32.
+"""
+import numpy as np
+
+
+def shard_fields(nfield, world, rank, weights=None):
+    """Contiguous partition of field ids 0..nfield-1 into `world` blocks, balanced by `weights`
+    (e.g. receivers per field; default 1).  Contiguity keeps the reference's period -> source ->
+    receiver row order inside every shard.  Returns (start, stop)."""
+    if world <= 1:
+        return 0, nfield
+    w = np.ones(nfield, np.float64) if weights is None else np.asarray(weights, np.float64)
+    c = np.concatenate([[0.0], np.cumsum(w)])
+    total = c[-1]
+    bounds = [int(np.searchsorted(c, total * r / world, side="left")) for r in range(world + 1)]
+    bounds[0], bounds[-1] = 0, nfield
+    for r in range(1, world + 1):  # monotone, never empty while fields remain
+        bounds[r] = max(bounds[r], bounds[r - 1])
+    return bounds[rank], bounds[rank + 1]
+
+
+def shard_rows(nrows, world, rank):
+    """even contiguous split of `nrows` extra rows (Tikhonov block) -> (start, stop)"""
+    base, rem = divmod(nrows, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class GpuLocalOps:
+    """local products on this rank's row block of G through the HIP kernels (dazim_aprod)"""
+
+    def __init__(self, ctx, G):
+        self.ctx, self.G = ctx, G
+        self.m, self.n = G.m, G.n
+
+    def aprod1(self, v, u):      # u += G_p v
+        self.ctx.aprod(1, self.G, v, u)
+
+    def aprod2(self, v, u):      # v += G_p^T u
+        self.ctx.aprod(2, self.G, v, u)
+
+
+def _f32(x):
+    return np.float32(x)
+
+
+def _d2norm(a, b):               # inv/lsmrModule.f90:708-721
+    scale = _f32(abs(a) + abs(b))
+    if scale == 0:
+        return _f32(0)
+    return _f32(scale * np.sqrt(_f32(_f32(a / scale) ** 2 + _f32(b / scale) ** 2), dtype=np.float32))
+
+
+def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSize, group=None):
+    """LSMR on a row-partitioned system.  `b_local` is this rank's slice of b (torch tensor on the
+    device the ops work on).  Returns (x, info) with x replicated on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    use_dist = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    dev, f32 = b_local.device, torch.float32
+
+    def allsum_(t):
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t
+
+    def gnorm_u(u):              # ||u|| over all ranks: local sum of squares in fp64, one scalar all-reduce
+        s = allsum_((u.double() ** 2).sum().reshape(1))
+        return _f32(np.sqrt(float(s.item())))
+
+    damp, atol, btol, conlim = map(_f32, (damp, atol, btol, conlim))
+    m_local = b_local.shape[0]
+    m_total = int(allsum_(torch.tensor([m_local], dtype=torch.int64, device=dev)).item())
+    localVecs = max(0, min(int(localSize), m_total, n))
+    u = b_local.clone().to(f32)
+    v = torch.zeros(n, dtype=f32, device=dev)
+    x = torch.zeros(n, dtype=f32, device=dev)
+    hbar = torch.zeros(n, dtype=f32, device=dev)
+    info = dict(istop=0, itn=0, normA=0.0, condA=0.0, normr=0.0, normAr=0.0, normx=0.0)
+    alpha = _f32(0)
+    beta = gnorm_u(u)
+    if beta > 0:
+        u.mul_(float(_f32(1) / beta))
+        ops.aprod2(v, u)
+        allsum_(v)                                   # the one n-vector all-reduce of this half-step
+        alpha = _f32(np.sqrt(float((v.double() ** 2).sum().item())))
+    if alpha > 0:
+        v.mul_(float(_f32(1) / alpha))
+    normAr = _f32(alpha * beta)
+    if normAr == 0:
+        return x, info
+    localV = torch.empty((max(localVecs, 1), n), dtype=f32, device=dev)
+    localPointer, localVQueueFull = 0, False
+    if localVecs > 0:
+        localPointer = 1
+        localV[0].copy_(v)
+    zetabar, alphabar = _f32(alpha * beta), alpha
+    rho = rhobar = cbar = _f32(1)
+    sbar = _f32(0)
+    h = v.clone()
+    betadd, betad, rhodold, tautildeold, thetatilde, zeta, d = beta, _f32(0), _f32(1), _f32(0), _f32(0), _f32(0), _f32(0)
+    normA2, maxrbar, minrbar, normb = _f32(alpha * alpha), _f32(0), _f32(1e30), beta
+    ctol = _f32(1) / conlim if conlim > 0 else _f32(0)
+    normr = beta
+    itn = istop = 0
+    normA = condA = normx = _f32(0)
+    w = torch.empty(n, dtype=f32, device=dev)
+    while True:
+        itn += 1
+        u.mul_(float(-alpha))
+        ops.aprod1(v, u)                              # u = A_p v - alpha u   (local rows only)
+        beta = gnorm_u(u)                             # scalar all-reduce
+        if beta > 0:
+            u.mul_(float(_f32(1) / beta))
+            if localVecs > 0:                         # localVEnqueue
+                if localPointer < localVecs:
+                    localPointer += 1
+                else:
+                    localPointer, localVQueueFull = 1, True
+                localV[localPointer - 1].copy_(v)
+            w.zero_()
+            ops.aprod2(w, u)                          # w = A_p^T u_p
+            allsum_(w)                                # RCCL all-reduce of G^T u over xGMI
+            v.mul_(float(-beta)).add_(w)
+            if localVecs > 0:                         # localVOrtho, modified Gram-Schmidt
+                lim = localVecs if localVQueueFull else localPointer
+                for q in range(lim):
+                    dq = torch.dot(v, localV[q])
+                    v.sub_(localV[q] * dq)
+            alpha = _f32(np.sqrt(float((v.double() ** 2).sum().item())))
+            if alpha > 0:
+                v.mul_(float(_f32(1) / alpha))
+        alphahat = _d2norm(alphabar, damp)
+        chat, shat = _f32(alphabar / alphahat), _f32(damp / alphahat)
+        rhoold = rho
+        rho = _d2norm(alphahat, beta)
+        c, s = _f32(alphahat / rho), _f32(beta / rho)
+        thetanew = _f32(s * alpha)
+        alphabar = _f32(c * alpha)
+        rhobarold, zetaold = rhobar, zeta
+        thetabar, rhotemp = _f32(sbar * rho), _f32(cbar * rho)
+        rhobar = _d2norm(_f32(cbar * rho), thetanew)
+        cbar = _f32(_f32(cbar * rho) / rhobar)
+        sbar = _f32(thetanew / rhobar)
+        zeta = _f32(cbar * zetabar)
+        zetabar = _f32(-sbar * zetabar)
+        f1 = float(_f32(_f32(thetabar * rho) / _f32(rhoold * rhobarold)))
+        f2 = float(_f32(zeta / _f32(rho * rhobar)))
+        f3 = float(_f32(thetanew / rho))
+        hbar.mul_(-f1).add_(h)
+        x.add_(hbar, alpha=f2)
+        h.mul_(-f3).add_(v)
+        betaacute, betacheck = _f32(chat * betadd), _f32(-shat * betadd)
+        betahat = _f32(c * betaacute)
+        betadd = _f32(-s * betaacute)
+        thetatildeold = thetatilde
+        rhotildeold = _d2norm(rhodold, thetabar)
+        ctildeold, stildeold = _f32(rhodold / rhotildeold), _f32(thetabar / rhotildeold)
+        thetatilde = _f32(stildeold * rhobar)
+        rhodold = _f32(ctildeold * rhobar)
+        betad = _f32(_f32(-stildeold * betad) + _f32(ctildeold * betahat))
+        tautildeold = _f32(_f32(zetaold - _f32(thetatildeold * tautildeold)) / rhotildeold)
+        taud = _f32(_f32(zeta - _f32(thetatilde * tautildeold)) / rhodold)
+        d = _f32(d + _f32(betacheck * betacheck))
+        normr = _f32(np.sqrt(_f32(_f32(d + _f32(_f32(betad - taud) ** 2)) + _f32(betadd * betadd)), dtype=np.float32))
+        normA2 = _f32(normA2 + _f32(beta * beta))
+        normA = _f32(np.sqrt(normA2, dtype=np.float32))
+        normA2 = _f32(normA2 + _f32(alpha * alpha))
+        maxrbar = max(maxrbar, rhobarold)
+        if itn > 1:
+            minrbar = min(minrbar, rhobarold)
+        condA = _f32(max(maxrbar, rhotemp) / min(minrbar, rhotemp))
+        normAr = _f32(abs(zetabar))
+        normx = _f32(np.sqrt(float((x.double() ** 2).sum().item())))
+        test1 = _f32(normr / normb)
+        test2 = _f32(normAr / _f32(normA * normr))
+        test3 = _f32(_f32(1) / condA)
+        t1 = _f32(test1 / _f32(_f32(1) + _f32(_f32(normA * normx) / normb)))
+        rtol = _f32(btol + _f32(_f32(_f32(atol * normA) * normx) / normb))
+        if itn >= itnlim: istop = 7
+        if _f32(1) + test3 <= 1: istop = 6
+        if _f32(1) + test2 <= 1: istop = 5
+        if _f32(1) + t1 <= 1: istop = 4
+        if test3 <= ctol: istop = 3
+        if test2 <= atol: istop = 2
+        if test1 <= rtol: istop = 1
+        if istop:
+            break
+    if damp > 0 and istop == 2:
+        istop = 3
+    info.update(istop=int(istop), itn=itn, normA=float(normA), condA=float(condA), normr=float(normr),
+                normAr=float(normAr), normx=float(normx))
+    return x, info

@@ -1,0 +1,106 @@
+"""CPU (-m "not gpu"): the N>1 host logic with world_size = 2 over gloo.
+
+* `shard_fields` / `shard_rows` cover every unit exactly once, contiguously, balanced.
+* `lsmr_distributed` on a row-partitioned system (each rank owns a block of ray rows + a slice of the
+  Tikhonov rows, products by a test double backed by the oracle, all-reduce over gloo) reproduces the
+  single-process oracle LSMR on the full system: same istop, itn within +-3, x rel-L2 <= 1e-3.
+  On GPUs the same driver runs with GpuLocalOps (HIP SpMV) and backend "nccl" (= RCCL over xGMI).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dazimsurftomo_amd.distributed import lsmr_distributed, shard_fields, shard_rows
+from tests.test_sparse_gpu import random_system
+
+
+def test_shard_fields_partitions_everything():
+    rng = np.random.default_rng(0)
+    for nfield, world in [(16000, 8), (7, 8), (100, 3), (1, 2), (0, 4)]:
+        w = rng.integers(1, 40, nfield)
+        spans = [shard_fields(nfield, world, r, w) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == nfield
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:])) and all(s <= e for s, e in spans)
+        if nfield >= 50 * world:
+            loads = [w[s:e].sum() for s, e in spans]
+            assert max(loads) <= 1.1 * w.sum() / world + w.max()
+    assert shard_fields(10, 1, 0) == (0, 10)
+    spans = [shard_rows(29744, 8, r) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == 29744 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+class OracleLocalOps:
+    """test double: this rank's row block through the oracle's aprod (numpy <-> torch CPU tensors)"""
+
+    def __init__(self, orc, m_local, n, irow, icol, rw):
+        self.orc, self.m, self.n, self.irow, self.icol, self.rw = orc, m_local, n, irow, icol, rw
+
+    def aprod1(self, v, u):
+        self.orc.aprod(1, self.m, self.n, v.numpy(), u.numpy(), self.irow, self.icol, self.rw)
+
+    def aprod2(self, v, u):
+        self.orc.aprod(2, self.m, self.n, v.numpy(), u.numpy(), self.irow, self.icol, self.rw)
+
+
+def _worker(rank, world, port, cfg, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
+        m0, n, tikh = 900, 300, 300
+        irow, icol, rw, m = random_system(m0, n, 60, seed=12, tikh_rows=tikh)
+        b = np.zeros(m, np.float32)
+        b[:m0] = np.random.default_rng(1).standard_normal(m0).astype(np.float32)
+        # rank r owns data rows [s0,e0) and Tikhonov rows [s1,e1), stacked locally in that order
+        s0, e0 = shard_fields(m0, world, rank)
+        s1, e1 = shard_rows(tikh, world, rank)
+        rows = np.concatenate([np.arange(s0, e0), m0 + np.arange(s1, e1)]) + 1
+        local_id = -np.ones(m + 1, np.int64)
+        local_id[rows] = np.arange(1, len(rows) + 1)
+        keep = local_id[irow] > 0
+        ops = OracleLocalOps(orc, len(rows), n, local_id[irow[keep]].astype(np.int32), icol[keep].copy(), rw[keep].copy())
+        x, info = lsmr_distributed(ops, torch.from_numpy(b[rows - 1].copy()), n, *cfg)
+        if rank == 0:
+            xo, io = orc.lsmr(m, n, irow, icol, rw, b, *cfg)
+            out["ok"] = (info["istop"] == io["istop"], abs(info["itn"] - io["itn"]),
+                         float(np.linalg.norm(x.numpy() - xo) / np.linalg.norm(xo)), info["itn"])
+        # replicated result: every rank must hold the same x bit for bit
+        xs = [torch.zeros_like(x) for _ in range(world)]
+        dist.all_gather(xs, x)
+        out[f"same{rank}"] = all(torch.equal(xs[0], t) for t in xs)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cfg", [(0.01, 1e-3, 1e-3, 1200.0, 1000, 75), (0.01, 1e-5, 1e-4, 200.0, 500, 10)])
+def test_lsmr_distributed_world2_gloo(orc, cfg):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, cfg, out), nprocs=2, join=True)
+    same_istop, ditn, rel, itn = out["ok"]
+    assert same_istop and ditn <= 3 and rel <= 1e-3, (out["ok"],)
+    assert out["same0"] and out["same1"]
+
+
+def test_lsmr_distributed_single_process_equals_oracle(orc):
+    """world_size 1 (no process group): the driver itself against the oracle"""
+    irow, icol, rw, m = random_system(500, 200, 40, seed=3, tikh_rows=200)
+    b = np.zeros(m, np.float32)
+    b[:500] = np.random.default_rng(2).standard_normal(500).astype(np.float32)
+    cfg = (0.01, 1e-5, 1e-4, 200.0, 500, 10)
+    ops = OracleLocalOps(orc, m, 200, irow, icol, rw)
+    x, info = lsmr_distributed(ops, torch.from_numpy(b.copy()), 200, *cfg)
+    xo, io = orc.lsmr(m, 200, irow, icol, rw, b, *cfg)
+    assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3
+    assert np.linalg.norm(x.numpy() - xo) <= 1e-3 * np.linalg.norm(xo)

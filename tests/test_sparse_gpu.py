@@ -118,3 +118,19 @@ def test_scale_rows(ctx, orc):
             ctx.aprod(2, A, a, yv); orc.aprod(2, m, 100, b_, yv.copy(), irow, icol, rw2)
         assert np.allclose(a, b_, rtol=2e-5, atol=1e-5)
     A.free()
+
+
+def test_lsmr_distributed_driver_on_gpu(ctx, orc):
+    """the multi-GPU driver (dazimsurftomo_amd/distributed.py) with GpuLocalOps at world_size 1:
+    HIP SpMV + torch vectors must reproduce the oracle like the C-ABI LSMR does"""
+    import torch
+    from dazimsurftomo_amd.distributed import GpuLocalOps, lsmr_distributed
+    irow, icol, rw, m = random_system(1200, 500, 90, seed=17, tikh_rows=500)
+    b = np.zeros(m, np.float32); b[:1200] = np.random.default_rng(4).standard_normal(1200).astype(np.float32)
+    A = ctx.csr_from_coo(m, 500, irow, icol, rw)
+    cfg = (0.01, 1e-5, 1e-4, 200.0, 500, 10)
+    x, info = lsmr_distributed(GpuLocalOps(ctx, A), torch.from_numpy(b).cuda(), 500, *cfg)
+    xo, io = orc.lsmr(m, 500, irow, icol, rw, b, *cfg)
+    assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3
+    assert np.linalg.norm(x.cpu().numpy() - xo) <= 1e-3 * np.linalg.norm(xo)
+    A.free()
