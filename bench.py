@@ -160,7 +160,10 @@ def main():
     dev = torch.device("cuda", local)
 
     import dazimsurftomo_amd as dz
-    dz.build()
+    if rank == 0:
+        dz.build()                      # no-op when the prebuilt library is current
+    if world > 1:
+        dist.barrier()
     ctx = dz.Context(local)
 
     kmax = len(PERIODS)

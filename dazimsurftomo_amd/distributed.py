@@ -45,10 +45,19 @@ class GpuLocalOps:
         self.ctx, self.G = ctx, G
         self.m, self.n = G.m, G.n
 
+    @staticmethod
+    def _order():
+        # the library launches on its own (blocking) HIP stream and returns synchronised; make the
+        # torch side explicit too so that the ordering does not hinge on legacy-default-stream rules
+        import torch
+        torch.cuda.current_stream().synchronize()
+
     def aprod1(self, v, u):      # u += G_p v
+        self._order()
         self.ctx.aprod(1, self.G, v, u)
 
     def aprod2(self, v, u):      # v += G_p^T u
+        self._order()
         self.ctx.aprod(2, self.G, v, u)
 
 
