@@ -89,6 +89,9 @@ class Context:
     def kernel_seconds(self, name):
         return self.lib.dazim_last_kernel_seconds(self._h, name.encode())
 
+    def set_option(self, name, value):
+        self._check(self.lib.dazim_set_option(self._h, name.encode(), int(value)))
+
     def sync(self):
         self._check(self.lib.dazim_sync(self._h))
 

@@ -101,6 +101,12 @@ int dazim_sync(dazim_ctx *ctx) {
 }
 void *dazim_stream(dazim_ctx *ctx) { return (void *)ctx->stream; }
 
+int dazim_set_option(dazim_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return DAZIM_E_BAD_ARG;
+  ctx->opts[name] = value;
+  return 0;
+}
+
 double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name) {
   auto it = ctx->ksec.find(name);
   return it == ctx->ksec.end() ? -1.0 : it->second;

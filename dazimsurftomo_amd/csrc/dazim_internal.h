@@ -18,6 +18,7 @@ struct dazim_ctx {
   std::string err;
   std::map<std::string, double> ksec;  // last measured kernel seconds by name
   int num_cu = 256;
+  std::map<std::string, int> opts;     // dazim_set_option
   // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
   std::map<std::string, std::pair<void *, size_t>> scratch;
 };

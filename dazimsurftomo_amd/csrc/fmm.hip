@@ -1,18 +1,23 @@
 // fmm.hip -- batched fast-marching eikonal solver for gfx950 (K2 + K3 of SURVEY.md section 2).
 //
-// One 64-lane wavefront (= one workgroup) marches one (source, period) field at a time and pulls
-// fields from an atomic queue until the batch is drained.  Per accepted node:
+// Fast marching is a strict dependence chain per field (one heap pop after the other), so all the
+// parallelism is across fields: a wavefront marches FOUR (source, period) fields at once, one per
+// 16-lane group, and workgroups (= one wavefront) pull batches of four fields from an atomic queue
+// until the batch is drained.  Per accepted node, inside a group:
 //   * the narrow-band binary heap lives in LDS as {key, node} pairs (keys cached next to the node
-//     id, so sifting never touches HBM); slots >= CAP spill to a per-workgroup HBM array;
-//   * lanes 0..15 evaluate the 4 neighbours x 4 quadrants of the mixed-order upwind stencil
-//     (fouds2, inv/CalSurfG.f90:557-729) in parallel; their {T, status} loads are issued before
-//     the root is sifted down so the L2 latency hides under the LDS heap work;
+//     id, so sifting never reads HBM); slots >= CAP spill to a per-group HBM array;
+//   * the 16 lanes are the 4 neighbours x 4 quadrants of the mixed-order upwind stencil (fouds2,
+//     inv/CalSurfG.f90:557-729): each lane loads its {T, status} records and solves one quadratic,
+//     two __shfl_xor give the minimum per neighbour;
 //   * heap updates are applied in the reference's order (x-1, x+1, z-1, z+1) so that the heap --
-//     and therefore the acceptance order, including ties -- is bit-identical to the reference.
-// A node's heap slot is not kept in HBM; a small LDS hint table (verified, with a wave-parallel
-// search as fallback) recovers it for "close" neighbours.  fp32 without FMA contraction
-// (this file is built with -ffp-contract=off); sin() of the colatitude comes from host tables so
-// that it is the same libm value the CPU reference uses.
+//     and therefore the acceptance order, including ties -- is bit-identical to the reference;
+//   * node status in HBM carries the heap slot of band nodes exactly like the reference's nsts, so
+//     "close" neighbours find their entry without a search (slots of the other pending neighbours
+//     are tracked in registers while one of them sifts).
+// The four groups execute the same instruction stream (SIMT), which cuts the instruction count per
+// field four-fold compared with one field per wavefront -- the kernel is issue-bound, not HBM-bound.
+// fp32 without FMA contraction (this file is built with -ffp-contract=off); sin() of the colatitude
+// comes from host tables so that it is the same libm value the CPU reference uses.
 #include <cmath>
 
 #include "dazim_internal.h"
@@ -22,11 +27,10 @@ namespace {
 constexpr int GDX = 5, GDZ = 5, SGDL = 8, SGS = 8;  // inv/CalSurfG.f90:1005-1012
 constexpr int RM = DAZIM_RMAX;
 constexpr float EARTH = 6371.0f;
-constexpr int TAB = 4096;  // slot-hint table entries
 
 struct __align__(8) Node {
   float t;
-  int s;  // during the march: -1 far, 0 alive, 1 close.  (the slot is written only at the end)
+  int s;  // nsts of the reference: -1 far, 0 alive, >0 slot in the narrow-band heap
 };
 struct __align__(8) HEnt {
   float key;
@@ -52,16 +56,8 @@ struct FmmArgs {
   HEnt *ovf;     // [nwg][ovfcap]
   int ovfcap;
   unsigned *counter;
+  const int *flist;  // nullable: indirection used by the spill rerun
 };
-
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float unif(float v) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
 
 // cubic B-spline basis, inv/CalSurfG.f90:1472-1475
 __device__ __forceinline__ void bspl4(float u, float w[4]) {
@@ -103,60 +99,100 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
 }
 
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
-// "hole" formulation: the moving element stays in registers while displaced entries are copied;
-// the comparisons, and hence the final array, are those of the reference's swap formulation.
-template <int CAP>
+// One heap per 16-lane group.  "Hole" formulation: the moving element stays in registers while
+// displaced entries are copied; the comparisons, and hence the final array, are those of the
+// reference's swap formulation.  Like the reference, the node status in HBM carries the heap slot
+// of every band node (nsts>0), written (lane 0 of the group) whenever an entry moves.
+constexpr int GP = 16;   // lanes per field
+constexpr int FPW = 4;   // fields per wavefront
+
+__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier:
+// same-wave LDS/VMEM operations execute in program order, so no s_waitcnt is needed for lane 0's
+// stores to be seen by the group's later loads.
+
+template <int CAP, bool SPILL>
 struct Heap {
-  HEnt *lds;            // [CAP], indexed by slot (slot 0 unused)
-  unsigned short *tab;  // [TAB] slot hints
-  HEnt *ovf;            // HBM spill for slots >= CAP
+  HEnt *lds;   // this group's [CAP] slots (slot 0 unused)
+  HEnt *ovf;   // HBM spill for slots >= CAP
+  Node *rec;   // node records of the grid being marched
+  int ld;
   int ntr;
-  bool lane0;
-  int lane;
+  bool g0;     // lane 0 of the group
 
-  __device__ __forceinline__ static int hash(int node) { return ((node >> 16) & 63) << 6 | (node & 63); }
-
+  __device__ __forceinline__ int idx(int node) const { return ((node >> 16) - 1) * ld + ((node & 0xffff) - 1); }
+  // SPILL=false: the whole band lives in LDS (no VMEM load inside the sift loops, so the back-pointer
+  // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
+  // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
   __device__ __forceinline__ HEnt get(int slot) const {
-    HEnt e = slot < CAP ? lds[slot] : ovf[slot - CAP];
-    e.key = unif(e.key);
-    e.node = uni(e.node);
-    return e;
+    if (SPILL && slot >= CAP) return ovf[slot - CAP];
+    return lds[slot];
   }
   __device__ __forceinline__ void get2(int slot, HEnt &a, HEnt &b) const {  // slot even
-    if (slot < CAP) {
-      const int4 v = *reinterpret_cast<const int4 *>(&lds[slot]);
-      a.key = __int_as_float(uni(v.x));
-      a.node = uni(v.y);
-      b.key = __int_as_float(uni(v.z));
-      b.node = uni(v.w);
+    if (SPILL && slot >= CAP) {
+      a = ovf[slot - CAP];
+      b = ovf[slot + 1 - CAP];
     } else {
-      a = get(slot);
-      b = get(slot + 1);
+      const int4 v = *reinterpret_cast<const int4 *>(&lds[slot]);
+      a.key = __int_as_float(v.x);
+      a.node = v.y;
+      b.key = __int_as_float(v.z);
+      b.node = v.w;
     }
   }
   __device__ __forceinline__ void put(int slot, float key, int node) {
-    if (lane0) {
+    if (g0) {
       HEnt e{key, node};
-      if (slot < CAP)
-        lds[slot] = e;
-      else
+      if (SPILL && slot >= CAP)
         ovf[slot - CAP] = e;
-      tab[hash(node)] = (unsigned short)slot;
+      else
+        lds[slot] = e;
+      rec[idx(node)].s = slot;
     }
   }
-  __device__ void sift_up(int c, float key, int node) {
+  // sift (key,node) up from slot c.  If `track`, entries that move down are compared with the
+  // pending neighbours' node ids so that their slots stay current (nbs[m] for m > from).
+  template <bool TRACK>
+  __device__ __forceinline__ void sift_up(int c, float key, int node, const int (&nbn)[4], int (&nbs)[4], int from) {
     while (c > 1) {
       const int p = c >> 1;
       const HEnt pe = get(p);
       if (key < pe.key) {
         put(c, pe.key, pe.node);
+        if (TRACK) {
+#pragma unroll
+          for (int m = 1; m < 4; m++)
+            if (m > from && pe.node == nbn[m]) nbs[m] = c;
+        }
         c = p;
       } else
         break;
     }
     put(c, key, node);
   }
-  __device__ void pop_root() {  // downtree
+  __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= CAP; }
+  __device__ __forceinline__ void add(float key, int node) {
+    const int nbn[4] = {0, 0, 0, 0};
+    int nbs[4] = {0, 0, 0, 0};
+    ntr++;
+    sift_up<false>(ntr, key, node, nbn, nbs, 0);
+  }
+  // LDS-only write of a heap entry (the HBM back-pointer is deferred by the caller)
+  __device__ __forceinline__ void put_lds(int slot, float key, int node) {
+    if (g0) {
+      HEnt e{key, node};
+      if (SPILL && slot >= CAP)
+        ovf[slot - CAP] = e;
+      else
+        lds[slot] = e;
+    }
+  }
+  // downtree.  The back-pointer stores of the entries that move are NOT issued here: move #i is
+  // captured by lane i of the group (mynode/myslot, nmoves) and flushed by the caller after the
+  // stencil loads have been consumed, so that those loads never queue behind this loop's stores.
+  // nbs[n] receives the new slot of pending neighbour n if its entry moved.
+  __device__ __forceinline__ void pop_root(int gl, const int (&nbn)[4], int (&nbm)[4], int &mynode, int &myslot,
+                                           int &nmoves) {
+    nmoves = 0;
     if (ntr == 1) {
       ntr = 0;
       return;
@@ -177,7 +213,12 @@ struct Heap {
         cn = c1.node;
       }
       if (ck < mv.key) {
-        put(p, ck, cn);
+        put_lds(p, ck, cn);
+        if (gl == nmoves) { mynode = cn; myslot = p; }
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+          if (cn == nbn[n]) nbm[n] = p;
+        nmoves++;
         p = c;
       } else {
         broke = true;
@@ -187,44 +228,116 @@ struct Heap {
     if (!broke && 2 * p == ntr) {
       const HEnt c = get(2 * p);
       if (c.key < mv.key) {
-        put(p, c.key, c.node);
+        put_lds(p, c.key, c.node);
+        if (gl == nmoves) { mynode = c.node; myslot = p; }
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+          if (c.node == nbn[n]) nbm[n] = p;
+        nmoves++;
         p = 2 * p;
       }
     }
-    put(p, mv.key, mv.node);
-  }
-  // slot of a node that is known to be in the heap
-  __device__ int find(int node) const {
-    int s = uni((int)tab[hash(node)]);
-    bool ok = s >= 1 && s <= ntr;
-    if (ok) ok = get(s).node == node;
-    if (ok) return s;
-    for (int base = 1; base <= ntr; base += 64) {  // rare: hint overwritten by a colliding node
-      const int sl = base + lane;
-      int nd = -1;
-      if (sl <= ntr) nd = (sl < CAP ? lds[sl] : ovf[sl - CAP]).node;
-      const unsigned long long m = __ballot(nd == node);
-      if (m) return base + (int)__builtin_ctzll(m);
-    }
-    return 1;  // unreachable for a consistent heap
+    put_lds(p, mv.key, mv.node);
+    if (gl == nmoves) { mynode = mv.node; myslot = p; }
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+      if (mv.node == nbn[n]) nbm[n] = p;
+    nmoves++;
   }
 };
 
-// ---- one marching run (travel, inv/CalSurfG.f90:356-456) -------------------------------------
+// fouds2 for one quadrant: inv/CalSurfG.f90:586-723.  (tj,sj) = neighbour along x, (tj2,sj2) the
+// node behind it, (tk,..) along z; vj2/vk2 = second node inside the grid.
+__device__ __forceinline__ float quadrant_time(float vel, float risti, float dnx, float dnz, Node nj, Node nj2,
+                                               Node nk, Node nk2, bool vj2, bool vk2) {
+  const float ri = EARTH;
+  const float slown = 1.0f / vel;
+  const bool aj = nj.s == 0, ak = nk.s == 0;
+  const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
+  const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
+  const float tj = nj.t, tj2 = nj2.t, tk = nk.t, tk2 = nk2.t;
+  float a = 1.0f, b = 0.0f, c = 0.0f, tref = 0.0f, tdiv = 1.0f, u, v, em;
+  if (so2j) {
+    if (so2k) {
+      u = 2.0f * ri * dnx;
+      v = 2.0f * risti * dnz;
+      em = 4.0f * tj - tj2 - 4.0f * tk;
+      em = em + tk2;
+      a = v * v + u * u;
+      b = 2.0f * em * (u * u);
+      c = (u * u) * (em * em - (slown * slown) * (v * v));
+      tref = 4.0f * tj - tj2;
+      tdiv = 3.0f;
+    } else if (ak) {
+      u = risti * dnz;
+      v = 2.0f * ri * dnx;
+      em = 3.0f * tk - 4.0f * tj + tj2;
+      a = v * v + 9.0f * (u * u);
+      b = 6.0f * em * (u * u);
+      c = (u * u) * (em * em - (slown * slown) * (v * v));
+      tref = tk;
+    } else {
+      u = 2.0f * ri * dnx;
+      c = -(u * u) * (slown * slown);
+      tref = 4.0f * tj - tj2;
+      tdiv = 3.0f;
+    }
+  } else if (aj) {
+    if (so2k) {
+      u = ri * dnx;
+      v = 2.0f * risti * dnz;
+      em = 3.0f * tj - 4.0f * tk + tk2;
+      a = v * v + 9.0f * (u * u);
+      b = 6.0f * em * (u * u);
+      c = (u * u) * (em * em - (v * v) * (slown * slown));
+      tref = tj;
+    } else if (ak) {
+      u = ri * dnx;
+      v = risti * dnz;
+      em = tk - tj;
+      a = u * u + v * v;
+      b = -2.0f * (u * u) * em;
+      c = (u * u) * (em * em - (v * v) * (slown * slown));
+      tref = tj;
+    } else {
+      c = -(slown * slown) * (ri * ri) * (dnx * dnx);
+      tref = tj;
+    }
+  } else {
+    if (so2k) {
+      u = 2.0f * risti * dnz;
+      c = -(u * u) * (slown * slown);
+      tref = 4.0f * tk - tk2;
+      tdiv = 3.0f;
+    } else if (ak) {
+      c = -(slown * slown) * (risti * risti) * (dnz * dnz);
+      tref = tk;
+    } else
+      return INFINITY;
+  }
+  float rd1 = b * b - 4.0f * a * c;
+  if (rd1 < 0.0f) rd1 = 0.0f;
+  const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+  return (tref + tdsh) / tdiv;
+}
+
+// ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
-// bit3 z=nnz).  Returns the packed node the run exited on, or 0.
-template <int CAP, bool REFINED>
-__device__ int march(Heap<CAP> &H, Node *__restrict__ rec, const float *__restrict__ veln,
-                     const float *__restrict__ risti_tab, int nnx, int nnz, int ld, float dnx,
-                     float dnz, int ex) {
-  const int lane = H.lane;
-  const int nb = lane >> 2, q = lane & 3;
+// bit3 z=nnz).
+template <int CAP, bool SPILL, bool REFINED>
+__device__ __forceinline__ bool march(Heap<CAP, SPILL> &H, const float *__restrict__ veln,
+                                      const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
+                                      int ex, int lane) {
+  const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
+  const int nb = gl >> 2, q = gl & 3;
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
-  const float ri = EARTH;
-  while (H.ntr > 0) {
-    wave_sync();
+  Node *rec = H.rec;
+  const int ld = H.ld;
+  bool overflow = false;
+  while (H.ntr > 0 && !overflow) {
+    cbar();
     const HEnt root = H.get(1);
     const int ix = root.node >> 16, iz = root.node & 0xffff;
     if (REFINED) {
@@ -233,339 +346,351 @@ __device__ int march(Heap<CAP> &H, Node *__restrict__ rec, const float *__restri
       if (ix == nnx && (ex & 2)) swrg = true;
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
-      if (swrg) return root.node;
+      if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
+        if (H.g0) rec[(ix - 1) * ld + (iz - 1)].s = 0;
+        break;
+      }
     }
-    if (H.lane0) rec[(ix - 1) * ld + (iz - 1)].s = 0;
-    wave_sync();
-    // ---- issue the stencil loads (lanes 0..15), then sift while they are in flight ----
+    if (H.g0) rec[(ix - 1) * ld + (iz - 1)].s = 0;
+    cbar();
+    // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
+    // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
+    // stay in flight while the root is sifted down in LDS. ----
     const int nix = ix + dix, niz = iz + diz;
-    const bool nvalid = lane < 16 && nix >= 1 && nix <= nnx && niz >= 1 && niz <= nnz;
+    const bool nvalid = nix >= 1 && nix <= nnx && niz >= 1 && niz <= nnz;
     const int j = nix + jd, j2 = nix + 2 * jd, k = niz + kd, k2 = niz + 2 * kd;
     const bool vj = nvalid && j >= 1 && j <= nnx, vj2 = vj && j2 >= 1 && j2 <= nnx;
     const bool vk = nvalid && k >= 1 && k <= nnz, vk2 = vk && k2 >= 1 && k2 <= nnz;
-    Node nself{0.0f, 0}, nj{0.0f, -1}, nj2{0.0f, -1}, nk{0.0f, -1}, nk2{0.0f, -1};
-    float vel = 1.0f, risti = 0.0f;
-    if (nvalid) {
-      nself = rec[(nix - 1) * ld + (niz - 1)];
-      vel = veln[(nix - 1) * ld + (niz - 1)];
-      risti = risti_tab[nix - 1];
-    }
-    if (vj) nj = rec[(j - 1) * ld + (niz - 1)];
-    if (vj2) nj2 = rec[(j2 - 1) * ld + (niz - 1)];
-    if (vk) nk = rec[(nix - 1) * ld + (k - 1)];
-    if (vk2) nk2 = rec[(nix - 1) * ld + (k2 - 1)];
-
-    H.pop_root();
-
-    // ---- fouds2 for (neighbour nb, quadrant q): inv/CalSurfG.f90:586-723 ----
-    float trav = INFINITY;
-    if (vj && vk && nself.s != 0) {
-      const float slown = 1.0f / vel;
-      const bool aj = nj.s == 0, ak = nk.s == 0;
-      const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
-      const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
-      const float tj = nj.t, tj2 = nj2.t, tk = nk.t, tk2 = nk2.t;
-      float a = 1.0f, b = 0.0f, c = 0.0f, tref = 0.0f, tdiv = 1.0f, u, v, em;
-      bool sol = true;
-      if (so2j) {
-        if (so2k) {
-          u = 2.0f * ri * dnx;
-          v = 2.0f * risti * dnz;
-          em = 4.0f * tj - tj2 - 4.0f * tk;
-          em = em + tk2;
-          a = v * v + u * u;
-          b = 2.0f * em * (u * u);
-          c = (u * u) * (em * em - (slown * slown) * (v * v));
-          tref = 4.0f * tj - tj2;
-          tdiv = 3.0f;
-        } else if (ak) {
-          u = risti * dnz;
-          v = 2.0f * ri * dnx;
-          em = 3.0f * tk - 4.0f * tj + tj2;
-          a = v * v + 9.0f * (u * u);
-          b = 6.0f * em * (u * u);
-          c = (u * u) * (em * em - (slown * slown) * (v * v));
-          tref = tk;
-        } else {
-          u = 2.0f * ri * dnx;
-          c = -(u * u) * (slown * slown);
-          tref = 4.0f * tj - tj2;
-          tdiv = 3.0f;
-        }
-      } else if (aj) {
-        if (so2k) {
-          u = ri * dnx;
-          v = 2.0f * risti * dnz;
-          em = 3.0f * tj - 4.0f * tk + tk2;
-          a = v * v + 9.0f * (u * u);
-          b = 6.0f * em * (u * u);
-          c = (u * u) * (em * em - (v * v) * (slown * slown));
-          tref = tj;
-        } else if (ak) {
-          u = ri * dnx;
-          v = risti * dnz;
-          em = tk - tj;
-          a = u * u + v * v;
-          b = -2.0f * (u * u) * em;
-          c = (u * u) * (em * em - (v * v) * (slown * slown));
-          tref = tj;
-        } else {
-          c = -(slown * slown) * (ri * ri) * (dnx * dnx);
-          tref = tj;
-        }
-      } else {
-        if (so2k) {
-          u = 2.0f * risti * dnz;
-          c = -(u * u) * (slown * slown);
-          tref = 4.0f * tk - tk2;
-          tdiv = 3.0f;
-        } else if (ak) {
-          c = -(slown * slown) * (risti * risti) * (dnz * dnz);
-          tref = tk;
-        } else
-          sol = false;
-      }
-      if (sol) {
-        float rd1 = b * b - 4.0f * a * c;
-        if (rd1 < 0.0f) rd1 = 0.0f;
-        const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
-        trav = (tref + tdsh) / tdiv;
-      }
-    }
-    trav = fminf(trav, __shfl_xor(trav, 1));
-    trav = fminf(trav, __shfl_xor(trav, 2));
-
-    // ---- apply the (up to) four heap updates in the reference's order ----
+    const int iroot = (ix - 1) * ld + (iz - 1);
+    Node nself = rec[nvalid ? (nix - 1) * ld + (niz - 1) : iroot];
+    Node nj = rec[vj ? (j - 1) * ld + (niz - 1) : iroot];
+    Node nj2 = rec[vj2 ? (j2 - 1) * ld + (niz - 1) : iroot];
+    Node nk = rec[vk ? (nix - 1) * ld + (k - 1) : iroot];
+    Node nk2 = rec[vk2 ? (nix - 1) * ld + (k2 - 1) : iroot];
+    const float vel = veln[nvalid ? (nix - 1) * ld + (niz - 1) : iroot];
+    const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
+    int nbn[4], nbs[4], nbm[4];
+    float nbt[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-      const int ux = ix + (n == 0 ? -1 : (n == 1 ? 1 : 0));
-      const int uz = iz + (n == 2 ? -1 : (n == 3 ? 1 : 0));
-      if (ux < 1 || ux > nnx || uz < 1 || uz > nnz) continue;
-      const int cls = __builtin_amdgcn_readlane(nself.s, 4 * n);
-      if (cls == 0) continue;
-      const float tn = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(trav), 4 * n));
-      const int node = (ux << 16) | uz;
-      if (H.lane0) rec[(ux - 1) * ld + (uz - 1)] = Node{tn, 1};
-      if (cls < 0) {
+      const int ux = ix + (n == 0 ? -1 : (n == 1 ? 1 : 0)), uz = iz + (n == 2 ? -1 : (n == 3 ? 1 : 0));
+      nbn[n] = (ux << 16) | uz;
+      nbm[n] = 0;
+    }
+    int mynode = 0, myslot = 0, nmoves = 0;
+    H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
+    // keep the compiler from sinking the loads behind a test of the first one and from hoisting
+    // the deferred stores above this point: all results are "used" here, together
+    asm volatile("" ::"v"(nself.t), "v"(nself.s), "v"(nj.t), "v"(nj.s), "v"(nj2.t), "v"(nj2.s), "v"(nk.t), "v"(nk.s),
+                 "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
+                 : "memory");
+    if (gl < nmoves) rec[H.idx(mynode)].s = myslot;   // deferred back-pointers of the sift-down
+    if (!nvalid) nself.s = 0;
+    if (!vj) nj.s = -1;
+    if (!vj2) nj2.s = -1;
+    if (!vk) nk.s = -1;
+    if (!vk2) nk2.s = -1;
+    float trav = INFINITY;
+    if (vj && vk && nself.s != 0) trav = quadrant_time(vel, risti, dnx, dnz, nj, nj2, nk, nk2, vj2, vk2);
+    trav = fminf(trav, __shfl_xor(trav, 1));
+    trav = fminf(trav, __shfl_xor(trav, 2));
+    // ---- the (up to) four heap updates in the reference's order (x-1, x+1, z-1, z+1) ----
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int ux = nbn[n] >> 16, uz = nbn[n] & 0xffff;
+      const bool ok = ux >= 1 && ux <= nnx && uz >= 1 && uz <= nnz;
+      int st = ok ? __shfl(nself.s, gbase + 4 * n) : 0;   // status: -1 far, 0 alive, >0 heap slot
+      if (st > 0 && nbm[n] > 0) st = nbm[n];               // its entry moved during the sift-down
+      nbs[n] = st;
+      nbt[n] = __shfl(trav, gbase + 4 * n);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      if (nbs[n] == 0) continue;
+      const int node = nbn[n];
+      if (H.g0) rec[H.idx(node)].t = nbt[n];
+      if (nbs[n] < 0) {
+        if (H.full()) {
+          overflow = true;
+          break;
+        }
         H.ntr++;
-        H.sift_up(H.ntr, tn, node);
+        H.template sift_up<true>(H.ntr, nbt[n], node, nbn, nbs, n);
       } else {
-        H.sift_up(H.find(node), tn, node);
+        H.template sift_up<true>(nbs[n], nbt[n], node, nbn, nbs, n);
       }
     }
   }
-  return 0;
+  return overflow;
 }
 
-template <int CAP>
+template <int CAP, bool SPILL>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
-  __shared__ __attribute__((aligned(16))) HEnt s_heap[CAP];
-  __shared__ unsigned short s_tab[TAB];
-  __shared__ unsigned s_field;
-  const int lane = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) HEnt s_heap[FPW][CAP];
+  __shared__ unsigned s_base;
+  const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
-  Node *rec_c = A.rec_c + (size_t)blockIdx.x * nn;
-  Node *rec_r = A.rec_r + (size_t)blockIdx.x * RM * RM;
-  float *velnr = A.velnr + (size_t)blockIdx.x * RM * RM;
-  Heap<CAP> H;
-  H.lds = s_heap;
-  H.tab = s_tab;
-  H.ovf = A.ovf + (size_t)blockIdx.x * A.ovfcap;
-  H.lane = lane;
-  H.lane0 = lane == 0;
+  const size_t slot = (size_t)blockIdx.x * FPW + grp;
+  Node *rec_c = A.rec_c + slot * nn;
+  Node *rec_r = A.rec_r + slot * RM * RM;
+  float *velnr = A.velnr + slot * RM * RM;
+  Heap<CAP, SPILL> H;
+  H.lds = s_heap[grp];
+  H.ovf = A.ovf + slot * A.ovfcap;
+  H.g0 = gl == 0;
 
   for (;;) {
     __syncthreads();
-    if (lane == 0) s_field = atomicAdd(A.counter, 1u);
+    if (lane == 0) s_base = atomicAdd(A.counter, (unsigned)FPW);
     __syncthreads();
-    const int f = (int)s_field;
-    if (f >= A.nfield) break;
-    const float scx = A.scx[f], scz = A.scz[f];
-    const int per = A.period[f] - 1;
-    const double *pv = A.pv + (size_t)per * (g.nvz + 2) * (g.nvx + 2);
-    const float *veln = A.veln + (size_t)per * nn;
-    float *ttn = A.ttn + (size_t)f * nn;
+    const unsigned fbase = s_base;
+    if (fbase >= (unsigned)A.nfield) break;
+    const int q = (int)fbase + grp;
+    if (q < A.nfield) {
+      const int f = A.flist ? A.flist[q] : q;   // the four groups run the same phases on their own field (SIMT across groups)
+      const float scx = A.scx[f], scz = A.scz[f];
+      const int per = A.period[f] - 1;
+      float *ttn = A.ttn + (size_t)f * nn;
+      // ---- refined source box, inv/CalSurfG.f90:1169-1206 ----
+      int isx = (int)((scx - g.gox) / g.dnx) + 1;
+      int isz = (int)((scz - g.goz) / g.dnz) + 1;
+      const bool outside = isx < 1 || isx > nnx || isz < 1 || isz > nnz || per < 0 || per >= A.kmax;
+      if (gl == 0) A.status[f] = outside ? DAZIM_E_SOURCE_OUTSIDE : 0;
+      if (outside) {
+        for (int i = gl; i < nn; i += GP) ttn[i] = 0.0f;
+      } else {
+        const double *pv = A.pv + (size_t)per * (g.nvz + 2) * (g.nvx + 2);
+        const float *veln = A.veln + (size_t)per * nn;
+        if (isx == nnx) isx--;
+        if (isz == nnz) isz--;
+        dazim_refbox bx;
+        bx.isx = isx;
+        bx.isz = isz;
+        bx.vnl = max(isx - SGS, 1);
+        bx.vnr = min(isx + SGS, nnx);
+        bx.vnt = max(isz - SGS, 1);
+        bx.vnb = min(isz + SGS, nnz);
+        bx.nnxr = (bx.vnr - bx.vnl) * SGDL + 1;
+        bx.nnzr = (bx.vnb - bx.vnt) * SGDL + 1;
+        bx.dnxr = g.dvx / (float)(GDX * SGDL);
+        bx.dnzr = g.dvz / (float)(GDZ * SGDL);
+        bx.goxr = g.gox + g.dnx * (float)(bx.vnl - 1);
+        bx.gozr = g.goz + g.dnz * (float)(bx.vnt - 1);
+        if (A.boxes && gl == 0) A.boxes[f] = bx;
+        const int nnxr = bx.nnxr, nnzr = bx.nnzr;
 
-    // ---- refined source box, inv/CalSurfG.f90:1169-1206 ----
-    int isx = (int)((scx - g.gox) / g.dnx) + 1;
-    int isz = (int)((scz - g.goz) / g.dnz) + 1;
-    const bool outside = isx < 1 || isx > nnx || isz < 1 || isz > nnz || per < 0 || per >= A.kmax;
-    if (A.status && lane == 0) A.status[f] = outside ? DAZIM_E_SOURCE_OUTSIDE : 0;
-    if (outside) {
-      for (int i = lane; i < nn; i += 64) ttn[i] = 0.0f;
-      continue;
-    }
-    if (isx == nnx) isx--;
-    if (isz == nnz) isz--;
-    dazim_refbox bx;
-    bx.isx = isx;
-    bx.isz = isz;
-    bx.vnl = max(isx - SGS, 1);
-    bx.vnr = min(isx + SGS, nnx);
-    bx.vnt = max(isz - SGS, 1);
-    bx.vnb = min(isz + SGS, nnz);
-    bx.nnxr = (bx.vnr - bx.vnl) * SGDL + 1;
-    bx.nnzr = (bx.vnb - bx.vnt) * SGDL + 1;
-    bx.dnxr = g.dvx / (float)(GDX * SGDL);
-    bx.dnzr = g.dvz / (float)(GDZ * SGDL);
-    bx.goxr = g.gox + g.dnx * (float)(bx.vnl - 1);
-    bx.gozr = g.goz + g.dnz * (float)(bx.vnt - 1);
-    if (A.boxes && lane == 0) A.boxes[f] = bx;
-    const int nnxr = bx.nnxr, nnzr = bx.nnzr;
-
-    // ---- bsplrefine (inv/CalSurfG.f90:1525-1591) + status reset, one node per lane ----
-    {
-      const int nrxr = GDX * SGDL, nrzr = GDZ * SGDL;
-      const int origx = (bx.vnl - 1) * SGDL + 1, origz = (bx.vnt - 1) * SGDL + 1;
-      for (int idx = lane; idx < nnxr * RM; idx += 64) {
-        const int idm2 = idx / RM + 1, idm1 = idx - (idm2 - 1) * RM + 1;
-        if (idm1 > nnzr) continue;
-        const int st2 = idm2 + origx - 1, st1 = idm1 + origz - 1;
-        int jc = (st2 - 1) / nrxr + 1;
-        if (jc > g.nvx - 1) jc = g.nvx - 1;
-        const int l = st2 - nrxr * (jc - 1);
-        int ic = (st1 - 1) / nrzr + 1;
-        if (ic > g.nvz - 1) ic = g.nvz - 1;
-        const int kk = st1 - nrzr * (ic - 1);
-        float ui[4], vi[4], sum[4];
-        bspl4((float)(l - 1) / (float)nrxr, ui);
-        bspl4((float)(kk - 1) / (float)nrzr, vi);
+        // ---- bsplrefine (inv/CalSurfG.f90:1525-1591) + status reset ----
+        {
+          const int nrxr = GDX * SGDL, nrzr = GDZ * SGDL;
+          const int origx = (bx.vnl - 1) * SGDL + 1, origz = (bx.vnt - 1) * SGDL + 1;
+          for (int idx = gl; idx < nnxr * RM; idx += GP) {
+            const int idm2 = idx / RM + 1, idm1 = idx - (idm2 - 1) * RM + 1;
+            if (idm1 > nnzr) continue;
+            const int st2 = idm2 + origx - 1, st1 = idm1 + origz - 1;
+            int jc = (st2 - 1) / nrxr + 1;
+            if (jc > g.nvx - 1) jc = g.nvx - 1;
+            const int l = st2 - nrxr * (jc - 1);
+            int ic = (st1 - 1) / nrzr + 1;
+            if (ic > g.nvz - 1) ic = g.nvz - 1;
+            const int kk = st1 - nrzr * (ic - 1);
+            float ui[4], vi[4], sum[4];
+            bspl4((float)(l - 1) / (float)nrxr, ui);
+            bspl4((float)(kk - 1) / (float)nrzr, vi);
 #pragma unroll
-        for (int i1 = 1; i1 <= 4; i1++) {
-          float s = 0.0f;
+            for (int i1 = 1; i1 <= 4; i1++) {
+              float s = 0.0f;
 #pragma unroll
-          for (int j1 = 1; j1 <= 4; j1++)
-            s = s + ui[j1 - 1] * (float)pv[(ic - 2 + i1) * (g.nvx + 2) + (jc - 2 + j1)];
-          sum[i1 - 1] = vi[i1 - 1] * s;
+              for (int j1 = 1; j1 <= 4; j1++)
+                s = s + ui[j1 - 1] * (float)pv[(ic - 2 + i1) * (g.nvx + 2) + (jc - 2 + j1)];
+              sum[i1 - 1] = vi[i1 - 1] * s;
+            }
+            velnr[idx] = sum[0] + sum[1] + sum[2] + sum[3];
+            rec_r[idx] = Node{0.0f, -1};
+          }
         }
-        velnr[idx] = sum[0] + sum[1] + sum[2] + sum[3];
-        rec_r[idx] = Node{0.0f, -1};
+        cbar();
+        // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 ----
+        H.ntr = 0;
+        H.rec = rec_r;
+        H.ld = RM;
+        int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
+        int rsz = (int)((scz - bx.gozr) / bx.dnzr) + 1;
+        if (rsx == nnxr) rsx--;
+        if (rsz == nnzr) rsz--;
+        {
+          const float dnx = bx.dnxr, dnz = bx.dnzr;
+          float vss[2][2];
+#pragma unroll
+          for (int i = 1; i <= 2; i++)
+#pragma unroll
+            for (int jj = 1; jj <= 2; jj++) vss[i - 1][jj - 1] = velnr[(rsx - 2 + i) * RM + (rsz - 2 + jj)];
+          const float dsx = (scx - bx.goxr) - (float)(rsx - 1) * dnx;
+          const float dsz = (scz - bx.gozr) - (float)(rsz - 1) * dnz;
+          float vsrc = 0.0f;  // bilinear, inv/CalSurfG.f90:2293
+#pragma unroll
+          for (int i = 1; i <= 2; i++)
+#pragma unroll
+            for (int jj = 1; jj <= 2; jj++) {
+              const float produ = (1.0f - fabsf(((float)(i - 1) * dnx - dsx) / dnx)) *
+                                  (1.0f - fabsf(((float)(jj - 1) * dnz - dsz) / dnz));
+              vsrc = vsrc + vss[i - 1][jj - 1] * produ;
+            }
+#pragma unroll
+          for (int i = 1; i <= 2; i++)
+#pragma unroll
+            for (int jj = 1; jj <= 2; jj++) {
+              const float ax = dsx - (float)(i - 1) * dnx, az = dsz - (float)(jj - 1) * dnz;
+              const float ds = sqrtf(ax * ax + az * az);
+              const float t0 = 2.0f * ds / (vss[i - 1][jj - 1] + vsrc);
+              const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
+              if (gl == 0) rec_r[(ux - 1) * RM + (uz - 1)].t = t0;
+              H.add(t0, (ux << 16) | uz);
+            }
+        }
+        // exit-rule quirk kept verbatim (inv/CalSurfG.f90:366-377): vnr/vnb (coarse indices) are
+        // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
+        const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
+                       (bx.vnb != nnzr ? 8 : 0);
+        bool ovf = march<CAP, SPILL, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        cbar();
+        // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
+        {
+          float *ttnr = A.ttnr ? A.ttnr + (size_t)f * RM * RM : nullptr;
+          int *nstsr = A.nstsr ? A.nstsr + (size_t)f * RM * RM : nullptr;
+          if (ttnr || nstsr)
+            for (int idx = gl; idx < RM * RM; idx += GP) {
+              const int c = idx / RM, r = idx - c * RM;
+              Node nd{0.0f, -9};
+              if (c < nnxr && r < nnzr) nd = rec_r[idx];
+              if (nstsr) nstsr[idx] = nd.s;
+              if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
+            }
+          for (int i = gl; i < nn; i += GP) rec_c[i] = Node{0.0f, -1};
+        }
+        cbar();
+        // ---- inject every sgdl-th refined node (inv/CalSurfG.f90:1252-1262) ----
+        const int bw = bx.vnr - bx.vnl + 1, bh = bx.vnb - bx.vnt + 1, nbox = bw * bh;
+        for (int i = gl; i < nbox; i += GP) {
+          const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
+          const Node nd = rec_r[(bxi * SGDL) * RM + bzi * SGDL];
+          Node o{0.0f, nd.s};
+          if (nd.s >= 0) o.t = nd.t;
+          rec_c[(bx.vnl - 1 + bxi) * nnz + (bx.vnt - 1 + bzi)] = o;
+        }
+        cbar();
+        // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only
+        // the tests against -1 matter and promotions never create a -1, so the sweep is order-free.
+        // Two passes (decide, then write) keep the 16 lanes from racing on each other's nodes. ----
+        for (int base = 0; base < nbox; base += GP) {
+          const int i = base + gl;
+          bool promote = false;
+          Node *p = nullptr;
+          if (i < nbox) {
+            const int bxi = i / bh, bzi = i - bxi * bh;
+            const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
+            p = &rec_c[(cx - 1) * nnz + (cz - 1)];
+            if (p->s == 0) {
+              if (cz - 1 >= 1 && p[-1].s == -1) promote = true;
+              if (cz + 1 <= nnz && p[1].s == -1) promote = true;
+              if (cx - 1 >= 1 && p[-nnz].s == -1) promote = true;
+              if (cx + 1 <= nnx && p[nnz].s == -1) promote = true;
+            }
+          }
+          cbar();
+          if (promote) p->s = 1;
+        }
+        cbar();
+        // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
+        H.ntr = 0;
+        H.rec = rec_c;
+        H.ld = nnz;
+        for (int base = 0; base < nbox; base += GP) {
+          const int i = base + gl;
+          Node nd{0.0f, -1};
+          int node = 0;
+          if (i < nbox) {
+            const int bxi = i / bh, bzi = i - bxi * bh;
+            const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
+            nd = rec_c[(cx - 1) * nnz + (cz - 1)];
+            node = (cx << 16) | cz;
+          }
+          unsigned m = (unsigned)((__ballot(nd.s > 0) >> (grp * GP)) & 0xffffull);
+          while (m) {
+            const int b = __builtin_ctz(m);
+            m &= m - 1;
+            const float t0 = __shfl(nd.t, grp * GP + b);
+            const int n0 = __shfl(node, grp * GP + b);
+            if (!H.full()) H.add(t0, n0); else ovf = true;
+          }
+        }
+        if (!ovf) ovf = march<CAP, SPILL, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        cbar();
+        if (ovf) {
+          if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
+        } else {
+          for (int i = gl; i < nn; i += GP) ttn[i] = rec_c[i].t;  // traveltime-grid write
+        }
       }
     }
-    __syncthreads();
-
-    // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 (uniform) ----
-    H.ntr = 0;
-    int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
-    int rsz = (int)((scz - bx.gozr) / bx.dnzr) + 1;
-    if (rsx == nnxr) rsx--;
-    if (rsz == nnzr) rsz--;
-    {
-      const float dnx = bx.dnxr, dnz = bx.dnzr;
-      float vss[2][2];
-#pragma unroll
-      for (int i = 1; i <= 2; i++)
-#pragma unroll
-        for (int jj = 1; jj <= 2; jj++) vss[i - 1][jj - 1] = unif(velnr[(rsx - 2 + i) * RM + (rsz - 2 + jj)]);
-      const float dsx = (scx - bx.goxr) - (float)(rsx - 1) * dnx;
-      const float dsz = (scz - bx.gozr) - (float)(rsz - 1) * dnz;
-      float vsrc = 0.0f;  // bilinear, inv/CalSurfG.f90:2293
-#pragma unroll
-      for (int i = 1; i <= 2; i++)
-#pragma unroll
-        for (int jj = 1; jj <= 2; jj++) {
-          const float produ = (1.0f - fabsf(((float)(i - 1) * dnx - dsx) / dnx)) *
-                              (1.0f - fabsf(((float)(jj - 1) * dnz - dsz) / dnz));
-          vsrc = vsrc + vss[i - 1][jj - 1] * produ;
-        }
-#pragma unroll
-      for (int i = 1; i <= 2; i++)
-#pragma unroll
-        for (int jj = 1; jj <= 2; jj++) {
-          const float ax = dsx - (float)(i - 1) * dnx, az = dsz - (float)(jj - 1) * dnz;
-          const float ds = sqrtf(ax * ax + az * az);
-          const float t0 = 2.0f * ds / (vss[i - 1][jj - 1] + vsrc);
-          const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
-          if (lane == 0) rec_r[(ux - 1) * RM + (uz - 1)] = Node{t0, 1};
-          H.ntr++;
-          H.sift_up(H.ntr, t0, (ux << 16) | uz);
-        }
-    }
-    // exit-rule quirk kept verbatim (inv/CalSurfG.f90:366-377): vnr/vnb (coarse indices) are
-    // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
-    const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
-                   (bx.vnb != nnzr ? 8 : 0);
-    const int exnode = march<CAP, true>(H, rec_r, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM,
-                                        nnxr, nnzr, RM, bx.dnxr, bx.dnzr, ex);
-    // nstsr carries the heap slot of every node still in the band (nstsr=nsts, :1247)
-    __syncthreads();
-    for (int sl = 1 + lane; sl <= H.ntr; sl += 64) {
-      const HEnt e = sl < CAP ? s_heap[sl] : H.ovf[sl - CAP];
-      rec_r[((e.node >> 16) - 1) * RM + ((e.node & 0xffff) - 1)].s = sl;
-    }
-    __syncthreads();
-    if (exnode && lane == 0) rec_r[((exnode >> 16) - 1) * RM + ((exnode & 0xffff) - 1)].s = 0;
-    __syncthreads();
-
-    // ---- refined outputs + reset of the coarse records ----
-    {
-      float *ttnr = A.ttnr ? A.ttnr + (size_t)f * RM * RM : nullptr;
-      int *nstsr = A.nstsr ? A.nstsr + (size_t)f * RM * RM : nullptr;
-      if (ttnr || nstsr)
-        for (int idx = lane; idx < RM * RM; idx += 64) {
-          const int c = idx / RM, r = idx - c * RM;
-          Node nd{0.0f, -9};
-          if (c < nnxr && r < nnzr) nd = rec_r[idx];
-          if (nstsr) nstsr[idx] = nd.s;
-          if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
-        }
-      for (int i = lane; i < nn; i += 64) rec_c[i] = Node{0.0f, -1};
-    }
-    __syncthreads();
-    // ---- inject every sgdl-th refined node (inv/CalSurfG.f90:1252-1262) ----
-    const int bw = bx.vnr - bx.vnl + 1, bh = bx.vnb - bx.vnt + 1, nbox = bw * bh;
-    for (int i = lane; i < nbox; i += 64) {
-      const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
-      const Node nd = rec_r[(bxi * SGDL) * RM + bzi * SGDL];
-      Node o{0.0f, nd.s};
-      if (nd.s >= 0) o.t = nd.t;
-      rec_c[(bx.vnl - 1 + bxi) * nnz + (bx.vnt - 1 + bzi)] = o;
-    }
-    __syncthreads();
-    // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only the
-    // tests against -1 matter and promotions never create a -1, so the sweep is order-free. ----
-    for (int i = lane; i < nbox; i += 64) {
-      const int bxi = i / bh, bzi = i - bxi * bh;
-      const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-      Node *p = &rec_c[(cx - 1) * nnz + (cz - 1)];
-      if (p->s == 0) {
-        bool far = false;
-        if (cz - 1 >= 1 && p[-1].s == -1) far = true;
-        if (cz + 1 <= nnz && p[1].s == -1) far = true;
-        if (cx - 1 >= 1 && p[-nnz].s == -1) far = true;
-        if (cx + 1 <= nnx && p[nnz].s == -1) far = true;
-        if (far) p->s = 1;
-      }
-    }
-    __syncthreads();
-    // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
-    H.ntr = 0;
-    for (int base = 0; base < nbox; base += 64) {
-      const int i = base + lane;
-      Node nd{0.0f, -1};
-      int node = 0;
-      if (i < nbox) {
-        const int bxi = i / bh, bzi = i - bxi * bh;
-        const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-        nd = rec_c[(cx - 1) * nnz + (cz - 1)];
-        node = (cx << 16) | cz;
-      }
-      unsigned long long m = __ballot(nd.s > 0);
-      while (m) {
-        const int b = (int)__builtin_ctzll(m);
-        m &= m - 1;
-        const float t0 = __shfl(nd.t, b);
-        const int n0 = __shfl(node, b);
-        if (lane == 0) rec_c[((n0 >> 16) - 1) * nnz + ((n0 & 0xffff) - 1)].s = 1;
-        H.ntr++;
-        H.sift_up(H.ntr, unif(t0), uni(n0));
-      }
-    }
-    march<CAP, false>(H, rec_c, veln, A.risti_c, nnx, nnz, nnz, g.dnx, g.dnz, 0);
-    __syncthreads();
-    for (int i = lane; i < nn; i += 64) ttn[i] = rec_c[i].t;  // coalesced traveltime-grid write
   }
+}
+
+
+template <int CAP>
+int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::vector<int> &hs) {
+  int rc;
+  void *p;
+  // workgroups (one wavefront, FPW fields each): as many as the LDS heaps allow per CU
+  int per_cu = (int)(160 * 1024 / (sizeof(HEnt) * CAP * FPW + 64));
+  if (per_cu > 16) per_cu = 16;
+  int nwg = ctx->num_cu * per_cu;
+  if (nwg > (nfield + FPW - 1) / FPW) nwg = (nfield + FPW - 1) / FPW;
+  const int nslot = nwg * FPW;
+  const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
+  A.ovfcap = ovfcap;
+  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * nn * sizeof(Node), &p))) return rc;
+  A.rec_c = (Node *)p;
+  if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * nr * sizeof(Node), &p))) return rc;
+  A.rec_r = (Node *)p;
+  if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
+  A.velnr = (float *)p;
+  if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * ovfcap * sizeof(HEnt), &p))) return rc;
+  A.ovf = (HEnt *)p;
+  if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
+  A.counter = (unsigned *)p;
+  A.status = d_status;
+  A.flist = nullptr;
+  const bool force_spill = ctx->opts.count("fmm.force_spill") && ctx->opts["fmm.force_spill"];
+  DzTimer t(ctx, "fmm");
+  std::vector<int> redo;
+  if (!force_spill) {
+    DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
+    hipLaunchKernelGGL((fmm_kernel<CAP, false>), dim3(nwg), dim3(64), 0, ctx->stream, A);
+    DZ_HIP(hipGetLastError());
+    DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nfield; i++)
+      if (hs[i] == -2) redo.push_back(i);
+  } else {
+    for (int i = 0; i < nfield; i++) redo.push_back(i);
+  }
+  ctx->ksec["fmm.spilled_fields"] = (double)redo.size();
+  if (!redo.empty()) {  // fields whose narrow band outgrew the LDS heap: same kernel, HBM spill enabled
+    if ((rc = dz_scratch(ctx, "fmm.flist", redo.size() * 4, &p))) return rc;
+    DZ_HIP(hipMemcpyAsync(p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    A.flist = (const int *)p;
+    A.nfield = (int)redo.size();
+    DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
+    int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
+    if (nwg2 > nwg) nwg2 = nwg;
+    hipLaunchKernelGGL((fmm_kernel<CAP, true>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
+    DZ_HIP(hipGetLastError());
+    DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  t.stop();
+  return 0;
 }
 
 }  // namespace
@@ -629,54 +754,41 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     t.stop();
   }
   if (nfield > 0) {
-    // workgroups: enough single-wave groups to fill every CU's LDS, never more than fields
-    constexpr int CAP = 1024;
-    int per_cu = 16;
-    int nwg = ctx->num_cu * per_cu;
-    if (nwg > nfield) nwg = nfield;
-    const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), :1068
-    FmmArgs A;
-    A.g = g;
-    A.nfield = nfield;
-    A.kmax = kmax;
-    A.pv = pv.dev;
-    A.veln = d_veln;
-    A.scx = scx.dev;
-    A.scz = scz.dev;
-    A.period = period.dev;
-    A.risti_c = d_rc;
-    A.risti_r = d_rr;
-    A.ttn = ttn.dev;
-    A.ttnr = ttnr.dev;
-    A.nstsr = nstsr.dev;
-    A.boxes = boxes.dev;
-    A.status = status.dev;
-    A.ovfcap = ovfcap;
-    if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nwg * nn * sizeof(Node), &p))) return rc;
-    A.rec_c = (Node *)p;
-    if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nwg * nr * sizeof(Node), &p))) return rc;
-    A.rec_r = (Node *)p;
-    if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nwg * nr * 4, &p))) return rc;
-    A.velnr = (float *)p;
-    if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nwg * ovfcap * sizeof(HEnt), &p))) return rc;
-    A.ovf = (HEnt *)p;
-    if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
-    A.counter = (unsigned *)p;
+    FmmArgs A0;
+    A0.g = g;
+    A0.nfield = nfield;
+    A0.kmax = kmax;
+    A0.pv = pv.dev;
+    A0.veln = d_veln;
+    A0.scx = scx.dev;
+    A0.scz = scz.dev;
+    A0.period = period.dev;
+    A0.risti_c = d_rc;
+    A0.risti_r = d_rr;
+    A0.ttn = ttn.dev;
+    A0.ttnr = ttnr.dev;
+    A0.nstsr = nstsr.dev;
+    A0.boxes = boxes.dev;
     int *d_status = status.dev;
     if (!d_status) {
       if ((rc = dz_scratch(ctx, "fmm.status", (size_t)nfield * 4, &p))) return rc;
       d_status = (int *)p;
-      A.status = d_status;
     }
-    DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
-    DzTimer t(ctx, "fmm");
-    hipLaunchKernelGGL(fmm_kernel<CAP>, dim3(nwg), dim3(64), 0, ctx->stream, A);
-    DZ_HIP(hipGetLastError());
-    t.stop();
-    // first failing field, like the reference's STOP
+    // LDS heap slots per field: the narrow band of an N x M grid peaks near 3*max(N,M) entries (and the
+    // 129 x 129 refined grid near 400); the smallest instantiation above that maximises the number of
+    // fields in flight per CU.  A field whose band still outgrows it is redone by the spill kernel.
+    int cap = 3 * (g.nnx > g.nnz ? g.nnx : g.nnz);
+    if (cap < 3 * RM) cap = 3 * RM;
+    if (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0) cap = ctx->opts["fmm.cap"];
     std::vector<int> hs(nfield);
-    DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
-    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (cap <= 64) rc = run_fmm<64>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 512) rc = run_fmm<512>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 768) rc = run_fmm<768>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 1024) rc = run_fmm<1024>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 1536) rc = run_fmm<1536>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else rc = run_fmm<2048>(ctx, A0, nfield, nn, nr, d_status, hs);
+    if (rc) return rc;
+    // first failing field, like the reference's STOP
     for (int i = 0; i < nfield; i++)
       if (hs[i]) {
         rc = dz_fail(ctx, hs[i], "field %d: source lies outside bounds of model", i);

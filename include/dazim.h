@@ -68,6 +68,10 @@ void *dazim_stream(dazim_ctx *ctx); /* the hipStream_t every kernel of this ctx 
 /* seconds spent in the last call's kernels, measured with HIP events on the ctx stream; name
  * selects the kernel ("fmm", "gridder", "disp", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
 double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
+/* tuning / test knobs.  "fmm.cap": LDS heap slots per field (0 = automatic from the grid size; 64
+ * exercises the HBM spill path on small grids); "fmm.force_spill": 1 = run every field through
+ * the spill kernel.                                                                             */
+int dazim_set_option(dazim_ctx *ctx, const char *name, int value);
 
 /* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */
 int dazim_geometry(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, dazim_geom *g);

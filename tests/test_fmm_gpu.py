@@ -89,3 +89,22 @@ def test_fmm_properties_full_size(ctx):
         assert abs(ix + 1 - b.isx) <= 1 and abs(iz + 1 - b.isz) <= 1
         # eikonal sanity: time to the far corner is bounded by distance / vmin, vmax
         assert ttn[f].max() < 14.0 * 111.2 * 1.5 / 2.5
+
+
+def test_fmm_heap_spill_paths(ctx, orc):
+    """narrow band larger than the LDS heap: with a 64-slot heap every 71x71 field overflows, is
+    flagged by the fast kernel and redone by the HBM-spill instantiation -- results stay bit-exact;
+    same with the spill kernel forced for every field at the default capacity"""
+    try:
+        ctx.set_option("fmm.cap", 64)
+        _run_case(ctx, orc, 17, 17, 2, 6, seed=8, goxd=26.5, gozd=101.25)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 12
+        ctx.set_option("fmm.cap", 0)
+        ctx.set_option("fmm.force_spill", 1)
+        _run_case(ctx, orc, 17, 17, 1, 5, seed=9, goxd=26.5, gozd=101.25)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 5
+    finally:
+        ctx.set_option("fmm.cap", 0)
+        ctx.set_option("fmm.force_spill", 0)
+    _run_case(ctx, orc, 17, 17, 1, 3, seed=10, goxd=26.5, gozd=101.25)
+    assert ctx.kernel_seconds("fmm.spilled_fields") == 0
