@@ -41,6 +41,10 @@ struct RayArgs {
   int *status;             // [nray]
   int *rbflag;             // [nray]
   long *count;             // [nray]  (count pass out)
+  int *nlist;              // [nray]  cells with |fdm| >= ftol saved by the count pass (-1: did not fit, retrace)
+  unsigned short *lcell;   // [nray][LK] their (jj,kk) cell ids, ascending
+  float *lval;             // [nray][LK] their fdm values
+  int LK;
   const long *rowptr;      // [nray+1] (emit pass in)
   float *val;
   int *col;
@@ -104,8 +108,10 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     const float *ttnr = A.ttnr + (size_t)f * RM * RM;
     const int *nstsr = A.nstsr + (size_t)f * RM * RM;
     const dazim_refbox bx = A.boxes[f];
+    const int saved = EMIT ? A.nlist[ray] : -1;   // EMIT: reuse the count pass's Frechet cells when they fit
     __syncthreads();
-    for (int i = lane; i < nf; i += 64) s_fdm[i] = 0.0f;
+    if (saved < 0)
+      for (int i = lane; i < nf; i += 64) s_fdm[i] = 0.0f;
     __syncthreads();
     int status = 0, rb = 0;
     // ---------------- srtimes, inv/CalSurfG.f90:1644-1711 ----------------
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     const float dpl = 0.5f * A.dplh;
     int ipx = (int)((rcx - gox) / dnx) + 1, ipz = (int)((rcz - goz) / dnz) + 1;
     if (ipx < 1 || ipx >= nnx || ipz < 1 || ipz >= nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
-    if (!status) {
+    if (!status && saved < 0) {
       float x0 = rcx, z0 = rcz;
       int sw = 0;
       float sred = ((scx - x0) * EARTH) * ((scx - x0) * EARTH);
@@ -291,7 +297,16 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     // ---------------- G row, inv/CalSurfG.f90:1339-1364 ----------------
     // cells with |fdm| >= ftol in (jj,kk) order -> LDS list
     int nlist = 0;
-    if (!status) {
+    if (saved >= 0) {
+      nlist = saved;
+      const size_t o = (size_t)ray * A.LK;
+      for (int i = lane; i < nlist; i += 64) {
+        const int c = A.lcell[o + i];
+        const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+        s_list[i] = (unsigned short)c;
+        s_fdm[kk * ldf + jj] = A.lval[o + i];
+      }
+    } else if (!status) {
       for (int base = 0; base < nvz * nvx; base += 64) {
         const int c = base + lane;
         bool keep = false;
@@ -305,6 +320,17 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
       }
     }
     __syncthreads();
+    if (!EMIT) {   // hand the Frechet cells to the emit pass so that it need not trace the ray again
+      const size_t o = (size_t)ray * A.LK;
+      if (nlist <= A.LK)
+        for (int i = lane; i < nlist; i += 64) {
+          const int c = s_list[i];
+          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          A.lcell[o + i] = (unsigned short)c;
+          A.lval[o + i] = s_fdm[kk * ldf + jj];
+        }
+      if (lane == 0) A.nlist[ray] = (status || nlist <= A.LK) ? (status ? 0 : nlist) : -1;
+    }
     const size_t ncol = (size_t)A.nx * A.ny;
     const int kslot = A.kidx[f] - 1;
     long cnt = 0;
@@ -411,6 +437,13 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   A.rbflag = (int *)p;
   if ((rc = dz_scratch(ctx, "rays.count", (size_t)(m + 1) * 8, &p))) return rc;
   A.count = (long *)p;
+  A.LK = g.nvx * g.nvz < 512 ? g.nvx * g.nvz : 512;
+  if ((rc = dz_scratch(ctx, "rays.nlist", nr1 * 4, &p))) return rc;
+  A.nlist = (int *)p;
+  if ((rc = dz_scratch(ctx, "rays.lcell", nr1 * A.LK * 2, &p))) return rc;
+  A.lcell = (unsigned short *)p;
+  if ((rc = dz_scratch(ctx, "rays.lval", nr1 * A.LK * 4, &p))) return rc;
+  A.lval = (float *)p;
   int64_t *rowptr = nullptr;
   DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + 1) * 8));
   A.dsurf = dsurf.dev;

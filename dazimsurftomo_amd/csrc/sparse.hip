@@ -78,6 +78,77 @@ __global__ __launch_bounds__(64 * WPB) void spmv_rows(int64_t nrows, const int64
   }
 }
 
+// Same product with the dense vector staged in LDS: used when 4*len(x) fits (<= 152 KB), which
+// removes the per-entry cache-line gather that otherwise bounds the product (~1 line/clk/CU).
+// One workgroup of 16 wavefronts per CU, each wavefront a row at a time, two 16-byte loads of
+// values and of indices in flight per lane.
+constexpr int LWPB = 16;
+__global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64_t nx, const int64_t *__restrict__ ptr,
+                                                           const int *__restrict__ idx, const float *__restrict__ val,
+                                                           const float *__restrict__ x, float *__restrict__ out,
+                                                           const float *__restrict__ beta_p, float beta_sign,
+                                                           double *__restrict__ sumsq) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];
+  for (int64_t i = threadIdx.x * 4; i < nx; i += 64 * LWPB * 4) {
+    if (i + 3 < nx)
+      *reinterpret_cast<float4 *>(xs + i) = *reinterpret_cast<const float4 *>(x + i);
+    else
+      for (int64_t j = i; j < nx; j++) xs[j] = x[j];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
+  double sq = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * LWPB + w; r < nrows; r += (int64_t)gridDim.x * LWPB) {
+    const int64_t s = ptr[r], e = ptr[r + 1];
+    float acc = 0.0f;
+    int64_t s4 = (s + 3) & ~(int64_t)3;
+    if (s4 > e) s4 = e;
+    for (int64_t i = s + lane; i < s4; i += 64) acc += val[i] * xs[idx[i]];
+    const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
+    int64_t i = s4 + 4 * lane;
+    for (; i + 256 < e4; i += 512) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(val + i);
+      const int4 c0 = *reinterpret_cast<const int4 *>(idx + i);
+      const float4 v1 = *reinterpret_cast<const float4 *>(val + i + 256);
+      const int4 c1 = *reinterpret_cast<const int4 *>(idx + i + 256);
+      acc += v0.x * xs[c0.x];
+      acc += v0.y * xs[c0.y];
+      acc += v0.z * xs[c0.z];
+      acc += v0.w * xs[c0.w];
+      acc += v1.x * xs[c1.x];
+      acc += v1.y * xs[c1.y];
+      acc += v1.z * xs[c1.z];
+      acc += v1.w * xs[c1.w];
+    }
+    for (; i < e4; i += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(val + i);
+      const int4 c = *reinterpret_cast<const int4 *>(idx + i);
+      acc += v.x * xs[c.x];
+      acc += v.y * xs[c.y];
+      acc += v.z * xs[c.z];
+      acc += v.w * xs[c.w];
+    }
+    for (int64_t k = e4 + lane; k < e; k += 64) acc += val[k] * xs[idx[k]];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float o = beta * out[r] + acc;
+      out[r] = o;
+      sq += (double)o * (double)o;
+    }
+  }
+  if (sumsq) {
+    __shared__ double s_sq[LWPB];
+    if (lane == 0) s_sq[w] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int k = 0; k < LWPB; k++) t += s_sq[k];
+      sumsq[blockIdx.x] = t;
+    }
+  }
+}
+
 // ---- small vector kernels (all O(m+n), negligible next to the products) ----------------------
 constexpr int VB = 256;   // threads per block
 constexpr int NPART = 256;  // partial sums per reduction
@@ -192,27 +263,41 @@ __global__ void k_check_range(int64_t n, const int *a, int lo, int hi, int *bad)
     if (a[i] < lo || a[i] > hi) atomicOr(bad, 1);
 }
 
-int spmv_blocks(dazim_ctx *ctx, int64_t nrows);
+int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx);
 inline int nblk(int64_t n, int cap = 2048) {
   int64_t b = (n + VB - 1) / VB;
   if (b < 1) b = 1;
   return (int)(b > cap ? cap : b);
 }
 
-int launch_spmv(dazim_ctx *ctx, int64_t nrows, const int64_t *ptr, const int *idx, const float *val,
-                const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
-                int nblocks) {
-  hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
-                     beta_p, beta_sign, sumsq);
-  DZ_HIP(hipGetLastError());
-  return 0;
+constexpr int64_t LDSX_MAX = 38 * 1024;  // floats of the dense vector that fit the 160 KB LDS next to the reduction scratch
+bool use_ldsx(dazim_ctx *ctx, int64_t nrows, int64_t nx) {
+  if (ctx->opts.count("spmv.ldsx") && !ctx->opts["spmv.ldsx"]) return false;
+  return nx <= LDSX_MAX && nrows >= (int64_t)ctx->num_cu * LWPB * 4;
 }
-int spmv_blocks(dazim_ctx *ctx, int64_t nrows) {
+int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx = -1) {
+  if (nx >= 0 && use_ldsx(ctx, nrows, nx)) return ctx->num_cu;  // one 16-wave workgroup per CU
   int64_t b = (nrows + WPB - 1) / WPB;
   const int64_t cap = (int64_t)ctx->num_cu * 8;  // 8 workgroups (32 waves) per CU, grid-stride the rest
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
+}
+// nx = length of the gathered vector; nblocks must come from spmv_blocks(ctx, nrows, nx)
+int launch_spmv(dazim_ctx *ctx, int64_t nrows, int64_t nx, const int64_t *ptr, const int *idx, const float *val,
+                const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
+                int nblocks) {
+  if (use_ldsx(ctx, nrows, nx)) {
+    const size_t lds = (size_t)((nx + 3) & ~(int64_t)3) * 4;
+    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spmv_rows_ldsx, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x, out,
+                       beta_p, beta_sign, sumsq);
+  } else {
+    hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
+                       beta_p, beta_sign, sumsq);
+  }
+  DZ_HIP(hipGetLastError());
+  return 0;
 }
 
 // row id of every CSR entry (one wavefront per row)
@@ -256,7 +341,7 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
   // keys = column (0-based) + 1 so that k_iota_keys' "-1" applies
   hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, (const unsigned *)nullptr, A->col, (int *)ck, 0);
   hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, (const int *)nullptr, (unsigned *)nullptr, iota);
-  hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, m)), dim3(64 * WPB), 0, ctx->stream, m, A->rowptr, rowid);
+  hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, m, -1)), dim3(64 * WPB), 0, ctx->stream, m, A->rowptr, rowid);
   size_t tb = 0;
   DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, ck, cks, iota, A->tperm, (size_t)nnz, 0, cbits, ctx->stream));
   void *tmp;
@@ -428,7 +513,7 @@ int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow_u, int *icol_
     void *p;
     if ((rc = dz_scratch(ctx, "csr.perm", (size_t)A->nnz * 4, &p))) return rc;
     unsigned *rowid = (unsigned *)p;
-    hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, A->m)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, rowid);
+    hipLaunchKernelGGL(k_expand_rows, dim3(spmv_blocks(ctx, A->m, -1)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, rowid);
     const int nb = nblk(A->nnz);
     if (irow.dev) hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, (const unsigned *)nullptr, (const int *)rowid, irow.dev, 1);
     if (icol.dev) hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, (const unsigned *)nullptr, A->col, icol.dev, 1);
@@ -445,7 +530,7 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   DzBuf<float> w;
   int rc;
   if ((rc = w.init(ctx, w_u, A->m, true, false))) return rc;
-  hipLaunchKernelGGL(k_scale_rows, dim3(spmv_blocks(ctx, A->m)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, A->val, w.dev);
+  hipLaunchKernelGGL(k_scale_rows, dim3(spmv_blocks(ctx, A->m, -1)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, A->val, w.dev);
   hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -462,11 +547,11 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
   if ((rc = y.init(ctx, y_u, A->m, true, mode == 1))) return rc;
   if (mode == 1) {
     DzTimer t(ctx, "spmv");
-    if ((rc = launch_spmv(ctx, A->m, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m)))) return rc;
+    if ((rc = launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m, A->n)))) return rc;
     t.stop();
   } else {
     DzTimer t(ctx, "spmvt");
-    if ((rc = launch_spmv(ctx, A->n, A->colptr, A->row, A->tval, y.dev, x.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->n)))) return rc;
+    if ((rc = launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y.dev, x.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->n, A->m)))) return rc;
     t.stop();
   }
   if ((rc = x.finish()) || (rc = y.finish())) return rc;
@@ -504,7 +589,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     if ((rc = dz_scratch(ctx, "lsmr.localV", (size_t)n * localVecs * 4, &p))) return rc;
     localV = (float *)p;
   }
-  const int gm = spmv_blocks(ctx, m), gn = spmv_blocks(ctx, n);
+  const int gm = spmv_blocks(ctx, m, n), gn = spmv_blocks(ctx, n, m);
   const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
   if ((rc = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return rc;
   part = (double *)p;
@@ -533,9 +618,9 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     DZ_HIP(hipEventRecord(a, ctx->stream));
     int r;
     if (!transpose)
-      r = launch_spmv(ctx, m, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
+      r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
     else
-      r = launch_spmv(ctx, n, A->colptr, A->row, A->tval, u, v, beta_p, sign, part, gn);
+      r = launch_spmv(ctx, n, m, A->colptr, A->row, A->tval, u, v, beta_p, sign, part, gn);
     if (r) return r;
     DZ_HIP(hipEventRecord(bq, ctx->stream));
     DZ_HIP(hipEventSynchronize(bq));
