@@ -15,6 +15,11 @@ struct dazim_csr {
   int *col = nullptr, *row = nullptr;            // CSR column / CSC row of each entry, 0-based
   float *val = nullptr, *tval = nullptr;         // CSR / CSC values
   unsigned *tperm = nullptr;                     // CSC entry -> CSR entry (for value rescaling)
+  // column-blocked view of the (canonical: columns ascending inside a row) CSR for the scatter form
+  // of A^T*y: row r's entries with column in block b are [cbptr[r*(ncb+1)+b], cbptr[r*(ncb+1)+b+1])
+  int ncb = 0, cbw = 0;                          // number of column blocks, block width
+  int64_t *cbptr = nullptr;
+  float vmax = 0.0f;                             // max |val|, sets the fixed-point scale
 };
 
 namespace {
@@ -264,6 +269,105 @@ __global__ void k_check_range(int64_t n, const int *a, int lo, int hi, int *bad)
 }
 
 int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx);
+// ---- A^T*y in scatter form ---------------------------------------------------------------------
+// The gather form (one wavefront per CSC column) is bound by one cache-line fetch of y per entry.
+// The scatter form streams the CSR rows instead -- y[r] is a per-row scalar, no gather at all -- and
+// accumulates val*y[r] into per-column accumulators in LDS.  To stay reproducible the accumulators
+// are 64-bit fixed point (integer addition is associative, so the order in which wavefronts arrive
+// does not matter; the quantum is 2^-40 of the largest |val*y|, far below fp32 round-off).  Columns
+// are split into blocks that fit LDS; a workgroup owns (row chunk, column block) and per-chunk
+// partials are combined in a second, equally order-free, pass.
+constexpr int SCW = 16;             // wavefronts per workgroup
+constexpr int CBW_MAX = 19 * 1024;  // int64 accumulators per column block (152 KB)
+
+__global__ void k_colblock_ptr(int64_t nrows, int ncb, int cbw, const int64_t *__restrict__ ptr,
+                               const int *__restrict__ col, int64_t *__restrict__ cbptr) {
+  const int64_t t = (int64_t)blockIdx.x * VB + threadIdx.x;
+  if (t >= nrows * (ncb + 1)) return;
+  const int64_t r = t / (ncb + 1);
+  const int b = (int)(t - r * (ncb + 1));
+  int64_t lo = ptr[r], hi = ptr[r + 1];
+  const int target = b * cbw;  // first entry with col >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  cbptr[t] = lo;
+}
+__global__ void k_absmax(int64_t n, const float *x, float *part) {
+  float v = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) v = fmaxf(v, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __shared__ float s[VB / 64];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int i = 0; i < VB / 64; i++) t = fmaxf(t, s[i]);
+    part[blockIdx.x] = t;
+  }
+}
+__global__ void k_absmax_finish(const float *part, int np, float *res) {
+  float v = 0.0f;
+  for (int i = threadIdx.x; i < np; i += 64) v = fmaxf(v, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  if (threadIdx.x == 0) res[0] = v;
+}
+
+__global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
+                                                          const int64_t *__restrict__ cbptr, const int *__restrict__ col,
+                                                          const float *__restrict__ val, const float *__restrict__ y,
+                                                          double scale, long long *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];
+  const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
+  const int c0 = cb * cbw;
+  const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
+  for (int i = threadIdx.x; i < width; i += 64 * SCW) acc[i] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t r0 = nrows * chunk / nchunk, r1 = nrows * (chunk + 1) / nchunk;
+  for (int64_t r = r0 + w; r < r1; r += SCW) {
+    const int64_t s = cbptr[r * (ncb + 1) + cb], e = cbptr[r * (ncb + 1) + cb + 1];
+    if (s == e) continue;
+    const float yr = y[r];
+    int64_t s4 = (s + 3) & ~(int64_t)3;
+    if (s4 > e) s4 = e;
+    for (int64_t i = s + lane; i < s4; i += 64)
+      atomicAdd((unsigned long long *)&acc[col[i] - c0], (unsigned long long)__double2ll_rn((double)(val[i] * yr) * scale));
+    const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
+    for (int64_t i = s4 + 4 * lane; i < e4; i += 256) {
+      const float4 v = *reinterpret_cast<const float4 *>(val + i);
+      const int4 c = *reinterpret_cast<const int4 *>(col + i);
+      atomicAdd((unsigned long long *)&acc[c.x - c0], (unsigned long long)__double2ll_rn((double)(v.x * yr) * scale));
+      atomicAdd((unsigned long long *)&acc[c.y - c0], (unsigned long long)__double2ll_rn((double)(v.y * yr) * scale));
+      atomicAdd((unsigned long long *)&acc[c.z - c0], (unsigned long long)__double2ll_rn((double)(v.z * yr) * scale));
+      atomicAdd((unsigned long long *)&acc[c.w - c0], (unsigned long long)__double2ll_rn((double)(v.w * yr) * scale));
+    }
+    for (int64_t i = e4 + lane; i < e; i += 64)
+      atomicAdd((unsigned long long *)&acc[col[i] - c0], (unsigned long long)__double2ll_rn((double)(val[i] * yr) * scale));
+  }
+  __syncthreads();
+  long long *dst = part + (size_t)chunk * ncols + c0;
+  for (int i = threadIdx.x; i < width; i += 64 * SCW) dst[i] = acc[i];
+}
+// out[c] = beta*out[c] + sum_chunks part[chunk][c] / scale ; partial ||out||^2
+__global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__restrict__ part, double inv_scale,
+                                  float *__restrict__ out, const float *__restrict__ beta_p, float beta_sign,
+                                  double *__restrict__ sumsq) {
+  const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
+  double sq = 0.0;
+  for (int64_t c = (int64_t)blockIdx.x * VB + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * VB) {
+    long long t = 0;
+    for (int k = 0; k < nchunk; k++) t += part[(size_t)k * ncols + c];
+    const float o = beta * out[c] + (float)((double)t * inv_scale);
+    out[c] = o;
+    sq += (double)o * o;
+  }
+  if (sumsq) block_partial(sq, sumsq);
+}
+
 inline int nblk(int64_t n, int cap = 2048) {
   int64_t b = (n + VB - 1) / VB;
   if (b < 1) b = 1;
@@ -354,6 +458,63 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
   return 0;
 }
 
+// column-block pointers + max|val| for the scatter form of A^T*y (needs canonical CSR)
+int build_colblocks(dazim_ctx *ctx, dazim_csr *A) {
+  if (A->cbptr) { (void)hipFree(A->cbptr); A->cbptr = nullptr; }
+  A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
+  A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
+  const int64_t np = A->m * (A->ncb + 1);
+  DZ_HIP(hipMalloc((void **)&A->cbptr, (size_t)np * 8));
+  hipLaunchKernelGGL(k_colblock_ptr, dim3((unsigned)((np + VB - 1) / VB)), dim3(VB), 0, ctx->stream, A->m, A->ncb, A->cbw,
+                     A->rowptr, A->col, A->cbptr);
+  int rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "csr.absmax", (NPART + 4) * 4, &p))) return rc;
+  float *pm = (float *)p;
+  A->vmax = 0.0f;
+  if (A->nnz > 0) {
+    const int nb = nblk(A->nnz, NPART);
+    hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, A->val, pm);
+    hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + NPART);
+    DZ_HIP(hipMemcpyAsync(&A->vmax, pm + NPART, 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+bool use_scatter(dazim_ctx *ctx, const dazim_csr *A) {
+  if (ctx->opts.count("spmv.scatter") && !ctx->opts["spmv.scatter"]) return false;
+  return A->cbptr && A->nnz >= (1 << 22) && A->m >= (int64_t)ctx->num_cu * SCW;
+}
+// x(out, n) = beta*x + A^T y ; returns the number of ||out||^2 partials written to sumsq in *npart
+int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax, float *out, const float *beta_p,
+                 float beta_sign, double *sumsq, int *npart) {
+  if (!use_scatter(ctx, A)) {
+    const int gn = spmv_blocks(ctx, A->n, A->m);
+    if (npart) *npart = gn;
+    return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn);
+  }
+  int nchunk = ctx->num_cu / A->ncb;
+  if (nchunk < 1) nchunk = 1;
+  int rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "spmvt.part", (size_t)nchunk * A->n * 8, &p))) return rc;
+  long long *part = (long long *)p;
+  const double pm = (double)A->vmax * (double)ymax;
+  int e = 0;
+  if (pm > 0) (void)frexp(pm, &e);   // pm = f * 2^e, 0.5 <= f < 1  ->  pm < 2^e
+  const double scale = ldexp(1.0, 40 - e);
+  const size_t lds = (size_t)A->cbw * 8;
+  DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(spmvT_scatter, dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
+                     A->n, A->cbptr, A->col, A->val, y, scale, part);
+  const int nb = nblk(A->n, NPART);
+  hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
+                     beta_sign, sumsq);
+  DZ_HIP(hipGetLastError());
+  if (npart) *npart = nb;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -361,7 +522,7 @@ extern "C" {
 int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
   if (!A) return 0;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm};
+  void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr};
   for (void *p : ps)
     if (p) (void)hipFree(p);
   delete A;
@@ -423,13 +584,21 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
     int rbits = 1, cbits = 1;
     while (((int64_t)1 << rbits) < m) rbits++;
     while (((int64_t)1 << cbits) < n) cbits++;
-    // ---- CSR: stable sort by row keeps the reference's within-row append order ----
-    hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, irow.dev, k0, v0);
-    size_t tb = 0;
-    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, perm, (size_t)nnz, 0, rbits, ctx->stream));
+    // ---- canonical CSR: stable sort by column, then stable sort by row -> rows ascending, columns
+    // ascending inside a row (entries of equal (row,col) keep the caller's order) ----
+    unsigned *permc;
+    if ((rc = dz_scratch(ctx, "csr.permc", nz * 4, &p))) return rc;
+    permc = (unsigned *)p;
+    hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, icol.dev, k0, v0);
+    size_t tb = 0, tb1 = 0;
+    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, permc, (size_t)nnz, 0, cbits, ctx->stream));
+    DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb1, k0, k1, permc, perm, (size_t)nnz, 0, rbits, ctx->stream));
+    if (tb1 > tb) tb = tb1;
     void *tmp;
     if ((rc = dz_scratch(ctx, "csr.tmp", tb + 256, &tmp))) return rc;
-    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, perm, (size_t)nnz, 0, rbits, ctx->stream));
+    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, permc, (size_t)nnz, 0, cbits, ctx->stream));
+    hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, permc, irow.dev, (int *)k0, -1);
+    DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, permc, perm, (size_t)nnz, 0, rbits, ctx->stream));
     hipLaunchKernelGGL(k_lower_bound, dim3(nblk(m + 1)), dim3(VB), 0, ctx->stream, m, nnz, k1, A->rowptr);
     hipLaunchKernelGGL(k_gather_f, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, rw.dev, A->val);
     hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, perm, icol.dev, A->col, -1);
@@ -438,6 +607,7 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
     DZ_HIP(hipMemsetAsync(A->rowptr, 0, (m + 1) * 8, ctx->stream));
   }
   if ((rc = build_transpose(ctx, A))) return rc;
+  if ((rc = build_colblocks(ctx, A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -452,6 +622,7 @@ int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *
   A->rowptr = rowptr; A->col = col; A->val = val;
   int rc;
   if ((rc = build_transpose(ctx, A))) return rc;
+  if ((rc = build_colblocks(ctx, A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -496,6 +667,7 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
   if ((rc = build_transpose(ctx, A))) return rc;
+  if ((rc = build_colblocks(ctx, A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -534,7 +706,7 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  return 0;
+  return build_colblocks(ctx, A);
 }
 
 // aprod, inv/aprod.f90:7
@@ -550,8 +722,19 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
     if ((rc = launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m, A->n)))) return rc;
     t.stop();
   } else {
+    float ymax = 1.0f;
+    if (use_scatter(ctx, A)) {   // fixed-point scale needs max|y| (inside LSMR it is 1: u is normalised)
+      void *p;
+      if ((rc = dz_scratch(ctx, "csr.absmax", (NPART + 4) * 4, &p))) return rc;
+      float *pm = (float *)p;
+      const int nb = nblk(A->m, NPART);
+      hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(VB), 0, ctx->stream, A->m, y.dev, pm);
+      hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + NPART);
+      DZ_HIP(hipMemcpyAsync(&ymax, pm + NPART, 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+    }
     DzTimer t(ctx, "spmvt");
-    if ((rc = launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y.dev, x.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->n, A->m)))) return rc;
+    if ((rc = launch_spmvT(ctx, A, y.dev, ymax, x.dev, nullptr, 1.0f, nullptr, nullptr))) return rc;
     t.stop();
   }
   if ((rc = x.finish()) || (rc = y.finish())) return rc;
@@ -590,6 +773,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     localV = (float *)p;
   }
   const int gm = spmv_blocks(ctx, m, n), gn = spmv_blocks(ctx, n, m);
+  int gn_t = gn;   // partial count of the last transposed product
   const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
   if ((rc = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return rc;
   part = (double *)p;
@@ -620,7 +804,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     if (!transpose)
       r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
     else
-      r = launch_spmv(ctx, n, m, A->colptr, A->row, A->tval, u, v, beta_p, sign, part, gn);
+      r = launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t);
     if (r) return r;
     DZ_HIP(hipEventRecord(bq, ctx->stream));
     DZ_HIP(hipEventSynchronize(bq));
@@ -643,7 +827,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   if (beta > 0.0f) {
     hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
     if ((rc = timed_spmv(true, nullptr, 1.0f))) return rc;  // v = 1*v(=0) + A^T u
-    if ((rc = norm_to_host(part, gn, &alpha))) return rc;
+    if ((rc = norm_to_host(part, gn_t, &alpha))) return rc;
   }
   if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
   normAr = alpha * beta;
@@ -695,7 +879,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
           hipLaunchKernelGGL(k_sumsq, dim3(bn), dim3(VB), 0, ctx->stream, n, v, part);
           if ((rc = norm_to_host(part, bn, &alpha))) return rc;
         } else {
-          if ((rc = norm_to_host(part, gn, &alpha))) return rc;
+          if ((rc = norm_to_host(part, gn_t, &alpha))) return rc;
         }
         if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
       }

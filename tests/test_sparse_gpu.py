@@ -134,3 +134,41 @@ def test_lsmr_distributed_driver_on_gpu(ctx, orc):
     assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3
     assert np.linalg.norm(x.cpu().numpy() - xo) <= 1e-3 * np.linalg.norm(xo)
     A.free()
+
+
+@pytest.mark.parametrize("n", [3000, 45000])
+def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n):
+    """>= 4 M entries: A*x runs with x staged in LDS (n <= 38 K) and A^T*y in the fixed-point scatter
+    form with 1 (n=3000) or 3 (n=45000) column blocks; both must still agree with the oracle, be
+    reproducible bit for bit, and agree with the gather kernels they replace"""
+    m, per_row = 8192, 640
+    rng = np.random.default_rng(n)
+    start = rng.integers(0, n, m)
+    cols = (start[:, None] + np.cumsum(rng.integers(1, 6, (m, per_row)), axis=1)) % n
+    cols.sort(axis=1)
+    irow = np.repeat(np.arange(1, m + 1, dtype=np.int32), per_row)
+    icol = (cols.reshape(-1) + 1).astype(np.int32)
+    rw = (-np.abs(rng.standard_normal(m * per_row)) * 0.2 - 1e-3).astype(np.float32)
+    A = ctx.csr_from_coo(m, n, irow, icol, rw)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = rng.standard_normal(m).astype(np.float32); y /= np.linalg.norm(y)
+    outs = {}
+    for tag, (ldsx, scat) in {"fast": (1, 1), "gather": (0, 0)}.items():
+        ctx.set_option("spmv.ldsx", ldsx); ctx.set_option("spmv.scatter", scat)
+        y1 = np.zeros(m, np.float32); ctx.aprod(1, A, x, y1)
+        x2 = np.zeros(n, np.float32); ctx.aprod(2, A, x2, y)
+        x3 = np.zeros(n, np.float32); ctx.aprod(2, A, x3, y)
+        assert np.array_equal(x2, x3), "A^T y must be reproducible"
+        outs[tag] = (y1, x2)
+    ctx.set_option("spmv.ldsx", 1); ctx.set_option("spmv.scatter", 1)
+    y_o = np.zeros(m, np.float32); orc.aprod(1, m, n, x.copy(), y_o, irow, icol, rw)
+    x_o = np.zeros(n, np.float32); orc.aprod(2, m, n, x_o, y.copy(), irow, icol, rw)
+    for tag in outs:
+        assert np.linalg.norm(outs[tag][0] - y_o) <= 3e-6 * np.linalg.norm(y_o), tag
+        assert np.linalg.norm(outs[tag][1] - x_o) <= 3e-6 * np.linalg.norm(x_o), tag
+    # the fixed-point sum is the more accurate one: compare both with a float64 reference
+    import scipy.sparse as sp
+    S = sp.csr_matrix((rw.astype(np.float64), (irow - 1, icol - 1)), shape=(m, n))
+    ref = S.T @ y.astype(np.float64)
+    assert np.linalg.norm(outs["fast"][1] - ref) <= np.linalg.norm(outs["gather"][1] - ref) * 1.5 + 1e-9
+    A.free()
