@@ -110,9 +110,23 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // same-wave LDS/VMEM operations execute in program order, so no s_waitcnt is needed for lane 0's
 // stores to be seen by the group's later loads.
 
-template <int CAP, bool SPILL>
+// LDS layout is structure-of-arrays: fp32 keys + node ids.  NT = unsigned short packs the node as
+// (ix-1)<<8 | (iz-1), possible when both grid sides are <= 256 (the S-256 case: 6 bytes per entry,
+// a third more fields in flight per CU); NT = int keeps (ix<<16)|iz for larger grids.
+template <class NT> struct NodeCodec;
+template <> struct NodeCodec<unsigned short> {
+  __device__ __forceinline__ static unsigned short enc(int node) { return (unsigned short)((((node >> 16) - 1) << 8) | ((node & 0xffff) - 1)); }
+  __device__ __forceinline__ static int dec(unsigned short c) { return (((int)(c >> 8) + 1) << 16) | ((int)(c & 0xff) + 1); }
+};
+template <> struct NodeCodec<int> {
+  __device__ __forceinline__ static int enc(int node) { return node; }
+  __device__ __forceinline__ static int dec(int c) { return c; }
+};
+
+template <int CAP, bool SPILL, class NT>
 struct Heap {
-  HEnt *lds;   // this group's [CAP] slots (slot 0 unused)
+  float *keys;  // this group's [CAP] keys (slot 0 unused)
+  NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
   Node *rec;   // node records of the grid being marched
   int ld;
@@ -125,27 +139,34 @@ struct Heap {
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
   __device__ __forceinline__ HEnt get(int slot) const {
     if (SPILL && slot >= CAP) return ovf[slot - CAP];
-    return lds[slot];
+    return HEnt{keys[slot], NodeCodec<NT>::dec(nodes[slot])};
   }
   __device__ __forceinline__ void get2(int slot, HEnt &a, HEnt &b) const {  // slot even
     if (SPILL && slot >= CAP) {
       a = ovf[slot - CAP];
       b = ovf[slot + 1 - CAP];
     } else {
-      const int4 v = *reinterpret_cast<const int4 *>(&lds[slot]);
-      a.key = __int_as_float(v.x);
-      a.node = v.y;
-      b.key = __int_as_float(v.z);
-      b.node = v.w;
+      const float2 k2 = *reinterpret_cast<const float2 *>(&keys[slot]);
+      a.key = k2.x;
+      b.key = k2.y;
+      if (sizeof(NT) == 2) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(&nodes[slot]);
+        a.node = NodeCodec<NT>::dec((NT)(v & 0xffffu));
+        b.node = NodeCodec<NT>::dec((NT)(v >> 16));
+      } else {
+        a.node = NodeCodec<NT>::dec(nodes[slot]);
+        b.node = NodeCodec<NT>::dec(nodes[slot + 1]);
+      }
     }
   }
   __device__ __forceinline__ void put(int slot, float key, int node) {
     if (g0) {
-      HEnt e{key, node};
       if (SPILL && slot >= CAP)
-        ovf[slot - CAP] = e;
-      else
-        lds[slot] = e;
+        ovf[slot - CAP] = HEnt{key, node};
+      else {
+        keys[slot] = key;
+        nodes[slot] = NodeCodec<NT>::enc(node);
+      }
       rec[idx(node)].s = slot;
     }
   }
@@ -179,11 +200,12 @@ struct Heap {
   // LDS-only write of a heap entry (the HBM back-pointer is deferred by the caller)
   __device__ __forceinline__ void put_lds(int slot, float key, int node) {
     if (g0) {
-      HEnt e{key, node};
       if (SPILL && slot >= CAP)
-        ovf[slot - CAP] = e;
-      else
-        lds[slot] = e;
+        ovf[slot - CAP] = HEnt{key, node};
+      else {
+        keys[slot] = key;
+        nodes[slot] = NodeCodec<NT>::enc(node);
+      }
     }
   }
   // downtree.  The back-pointer stores of the entries that move are NOT issued here: move #i is
@@ -324,8 +346,8 @@ __device__ __forceinline__ float quadrant_time(float vel, float risti, float dnx
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
-template <int CAP, bool SPILL, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL> &H, const float *__restrict__ veln,
+template <int CAP, bool SPILL, class NT, bool REFINED>
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ veln,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
@@ -424,9 +446,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL> &H, const float *__restri
   return overflow;
 }
 
-template <int CAP, bool SPILL>
+template <int CAP, bool SPILL, class NT>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
-  __shared__ __attribute__((aligned(16))) HEnt s_heap[FPW][CAP];
+  __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
+  __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
   __shared__ unsigned s_base;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
@@ -435,8 +458,9 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   Node *rec_c = A.rec_c + slot * nn;
   Node *rec_r = A.rec_r + slot * RM * RM;
   float *velnr = A.velnr + slot * RM * RM;
-  Heap<CAP, SPILL> H;
-  H.lds = s_heap[grp];
+  Heap<CAP, SPILL, NT> H;
+  H.keys = s_keys[grp];
+  H.nodes = s_nodes[grp];
   H.ovf = A.ovf + slot * A.ovfcap;
   H.g0 = gl == 0;
 
@@ -552,7 +576,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        bool ovf = march<CAP, SPILL, NT, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -624,7 +648,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -637,13 +661,14 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
 }
 
 
-template <int CAP>
+template <int CAP, class NT>
 int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::vector<int> &hs) {
   int rc;
   void *p;
   // workgroups (one wavefront, FPW fields each): as many as the LDS heaps allow per CU
-  int per_cu = (int)(160 * 1024 / (sizeof(HEnt) * CAP * FPW + 64));
+  int per_cu = (int)(160 * 1024 / ((4 + sizeof(NT)) * CAP * FPW + 64));
   if (per_cu > 16) per_cu = 16;
+  if (ctx->opts.count("fmm.wg_per_cu") && ctx->opts["fmm.wg_per_cu"] > 0 && ctx->opts["fmm.wg_per_cu"] < per_cu) per_cu = ctx->opts["fmm.wg_per_cu"];
   int nwg = ctx->num_cu * per_cu;
   if (nwg > (nfield + FPW - 1) / FPW) nwg = (nfield + FPW - 1) / FPW;
   const int nslot = nwg * FPW;
@@ -666,7 +691,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   std::vector<int> redo;
   if (!force_spill) {
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
-    hipLaunchKernelGGL((fmm_kernel<CAP, false>), dim3(nwg), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL((fmm_kernel<CAP, false, NT>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -684,7 +709,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
     int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
     if (nwg2 > nwg) nwg2 = nwg;
-    hipLaunchKernelGGL((fmm_kernel<CAP, true>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL((fmm_kernel<CAP, true, NT>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -781,12 +806,13 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if (cap < 3 * RM) cap = 3 * RM;
     if (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0) cap = ctx->opts["fmm.cap"];
     std::vector<int> hs(nfield);
-    if (cap <= 64) rc = run_fmm<64>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 512) rc = run_fmm<512>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 768) rc = run_fmm<768>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 1024) rc = run_fmm<1024>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 1536) rc = run_fmm<1536>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else rc = run_fmm<2048>(ctx, A0, nfield, nn, nr, d_status, hs);
+    const bool small = g.nnx <= 256 && g.nnz <= 256;   // node id fits 16 bits
+    if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 1536) rc = run_fmm<1536, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else rc = run_fmm<2048, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     if (rc) return rc;
     // first failing field, like the reference's STOP
     for (int i = 0; i < nfield; i++)

@@ -22,8 +22,10 @@ d_st = torch.empty((nf,), dtype=torch.int32, device=dev)
 import os
 cap=int(os.environ.get('CAP','0'))
 if cap: ctx.set_option('fmm.cap', cap)
+wpc=int(os.environ.get('WPC','0'))
+if wpc: ctx.set_option('fmm.wg_per_cu', wpc)
 for it in range(reps):
     ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, d_pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn, ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
     ks = ctx.kernel_seconds("fmm")
-    print(f"cap {cap} fields {nf} kernel {ks:.4f}s {nf/ks:.0f} fields/s spilled {ctx.kernel_seconds('fmm.spilled_fields')}")
+    print(f"wpc {wpc} cap {cap} fields {nf} kernel {ks:.4f}s {nf/ks:.0f} fields/s spilled {ctx.kernel_seconds('fmm.spilled_fields')}")
 print("checksum", float(d_ttn.double().sum()), int(d_nstsr.long().sum()))
