@@ -164,7 +164,7 @@ class Context:
 
     # ---- K4+K5 -------------------------------------------------------------------------------
     def rays_build_G(self, nx, ny, goxd, gozd, dvxd, dvzd, vels, fields, scx, scz, period_idx, field_of_ray,
-                     rcx, rcz, sen, kernel_idx=None, tpred=None):
+                     rcx, rcz, sen, kernel_idx=None, tpred=None, lsen=None):
         """srtimes + rpaths + row assembly (receiver loop of CalSurfG, inv/CalSurfG.f90:1326-1364).
         `fields` is the dict returned by fmm_batch for the same scx/scz/period_idx.
         Returns (G, tpred, n_boundary)."""
@@ -183,14 +183,18 @@ class Context:
         h = C.c_void_p()
         nnz = C.c_int64(0)
         nb = C.c_int(0)
-        rc = self.lib.dazim_rays_build_G(self._h, nx, ny, nz, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
-                                         C.c_float(dvzd), kmax, _ptr(vels, np.float32), nfield, _ptr(scx), _ptr(scz),
-                                         _ptr(period_idx), _ptr(kernel_idx), _ptr(fields["veln"]), _ptr(fields["ttn"]),
-                                         _ptr(fields["ttnr"]), _ptr(fields["nstsr"]), bptr, C.c_int64(nray),
-                                         _ptr(field_of_ray), _ptr(rcx), _ptr(rcz), _ptr(sen[0]), _ptr(sen[1]),
-                                         _ptr(sen[2]), _ptr(tpred), C.byref(h), C.byref(nnz), C.byref(nb))
+        args = [self._h, nx, ny, nz, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
+                C.c_float(dvzd), kmax, _ptr(vels, np.float32), nfield, _ptr(scx), _ptr(scz),
+                _ptr(period_idx), _ptr(kernel_idx), _ptr(fields["veln"]), _ptr(fields["ttn"]),
+                _ptr(fields["ttnr"]), _ptr(fields["nstsr"]), bptr, C.c_int64(nray),
+                _ptr(field_of_ray), _ptr(rcx), _ptr(rcz), _ptr(sen[0]), _ptr(sen[1]), _ptr(sen[2])]
+        tail = [_ptr(tpred), C.byref(h), C.byref(nnz), C.byref(nb)]
+        if lsen is None:   # isotropic rows (CalSurfG)
+            rc = self.lib.dazim_rays_build_G(*args, *tail)
+        else:              # joint rows dVs | Gc | Gs (CalSurfGAnisoJoint), lsen = Lsen_Gsc[nz-1][kmax][nx*ny]
+            rc = self.lib.dazim_rays_build_G_joint(*args, _ptr(lsen, np.float32), *tail)
         self._check(rc)
-        n = (nx - 2) * (ny - 2) * (nz - 1)
+        n = (nx - 2) * (ny - 2) * (nz - 1) * (1 if lsen is None else 3)
         return SparseMatrix(self, h, nray, n, nnz.value), tpred, nb.value
 
     # ---- K6/K7 -----------------------------------------------------------------------------

@@ -36,6 +36,7 @@ struct RayArgs {
   const dazim_refbox *boxes;
   const float *vels;       // [nz][ny][nx]
   const double *svs, *svp, *srho;  // [nz][kmax][nx*ny]
+  const float *lsen;       // joint mode: Lsen_Gsc [nz-1][kmax][nx*ny] (fp32, inv/CalSurfGAniso_Joint.f90:337)
   float dplh;              // min cell size (before the 0.5 factor), host libm
   float *dsurf;            // [nray]
   int *status;             // [nray]
@@ -43,7 +44,7 @@ struct RayArgs {
   long *count;             // [nray]  (count pass out)
   int *nlist;              // [nray]  cells with |fdm| >= ftol saved by the count pass (-1: did not fit, retrace)
   unsigned short *lcell;   // [nray][LK] their (jj,kk) cell ids, ascending
-  float *lval;             // [nray][LK] their fdm values
+  float *lval;             // [nray][LK] (x3 in joint mode) their fdm (, fdmc, fdms) values
   int LK;
   const long *rowptr;      // [nray+1] (emit pass in)
   float *val;
@@ -52,6 +53,33 @@ struct RayArgs {
 
 // sin of a colatitude: evaluated in fp64 and rounded, i.e. the correctly rounded fp32 sine.
 __device__ __forceinline__ float dz_sinf(float x) { return (float)sin((double)x); }
+
+// azimuth of the step (x0,z0) -> (x1,z1): azdist (inv/rpathsAzim.f90:687-793) with the reference's
+// implicit typing, called as at inv/rpathsAzim.f90:415-423; returns cos(2 psi), sin(2 psi)
+__device__ __forceinline__ void step_azimuth(float x0, float z0, float x1, float z1, float &c2psi, float &s2psi) {
+  const float PI_F = 3.1415926535898f;
+  const float evtlat = (PI_F / 2 - x0) * 180.0f / PI_F, evtlon = z0 * 180.0f / PI_F;
+  const float stalat = (PI_F / 2 - x1) * 180.0f / PI_F, stalon = z1 * 180.0f / PI_F;
+  const double pi = (double)3.1415926535898f;
+  const float piby2 = (float)(pi / (double)2.f);
+  const double rad = (double)2.f * pi / (double)360.f;
+  const double sph = (double)(1.0f / 298.257f);
+  const double scolat = (double)piby2 - atan((1. - sph) * (1. - sph) * tan((double)stalat * rad));
+  const double ecolat = (double)piby2 - atan((1. - sph) * (1. - sph) * tan((double)evtlat * rad));
+  const double slon = (double)stalon * rad, elon = (double)evtlon * rad;
+  const double a = sin(scolat) * cos(slon), b = sin(scolat) * sin(slon), c = cos(scolat);
+  const double dd = sin(elon), ee = -cos(elon), cc = cos(ecolat);
+  const double gg = -cc * ee, hh = cc * dd, kk = -sin(ecolat);
+  const double rhs1 = (a - dd) * (a - dd) + (b - ee) * (b - ee) + c * c - (double)2.f;
+  const double rhs2 = (a - gg) * (a - gg) + (b - hh) * (b - hh) + (c - kk) * (c - kk) - (double)2.f;
+  double daz = atan2(rhs1, rhs2);
+  if (daz < 0.0) daz = daz + 2 * pi;
+  float az = (float)(daz / rad);
+  if (fabsf(az - 360.f) < .00001f) az = 0.0f;
+  const float rgpsi = az / 180 * PI_F;
+  c2psi = (float)cos((double)(2.0f * rgpsi));
+  s2psi = (float)sin((double)(2.0f * rgpsi));
+}
 
 __device__ __forceinline__ void basis(float v, float b[4]) {  // inv/CalSurfG.f90:2145-2148
   const float om = 1.0f - v;
@@ -92,13 +120,14 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   return biv;
 }
 
-template <bool EMIT>
+template <bool EMIT, bool AZIM>
 __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float s_fdm[];  // [(nvx+2)*(nvz+2)] then cell list
+  extern __shared__ __attribute__((aligned(16))) float s_fdm[];  // fdm [(nvx+2)*(nvz+2)] (, fdmc, fdms) then cell list
   const dazim_geom g = A.g;
   const int lane = threadIdx.x;
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
-  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_fdm + nf);
+  float *s_fdmc = s_fdm + nf, *s_fdms = s_fdm + 2 * nf;   // joint mode only
+  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_fdm + (AZIM ? 3 : 1) * nf);
   const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
   for (long ray = blockIdx.x; ray < A.nray; ray += gridDim.x) {
     const int f = A.field[ray];
@@ -111,7 +140,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     const int saved = EMIT ? A.nlist[ray] : -1;   // EMIT: reuse the count pass's Frechet cells when they fit
     __syncthreads();
     if (saved < 0)
-      for (int i = lane; i < nf; i += 64) s_fdm[i] = 0.0f;
+      for (int i = lane; i < (AZIM ? 3 : 1) * nf; i += 64) s_fdm[i] = 0.0f;
     __syncthreads();
     int status = 0, rb = 0;
     // ---------------- srtimes, inv/CalSurfG.f90:1644-1711 ----------------
@@ -214,6 +243,8 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
         if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; rb = 1; }
         if (ipz < 1) { z1 = goz; ipz = 1; rb = 1; }
         if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; rb = 1; }
+        float c2psi = 0.0f, s2psi = 0.0f;
+        if (AZIM) step_azimuth(x0, z0, x1, z1, c2psi, s2psi);
         // ---- Frechet weights, :2077-2229 ----
         const int ivx = (ipx - 1) / GDX + 1, ivz = (ipz - 1) / GDZ + 1;
         const int ivxo = (ipxo - 1) / GDX + 1, ivzo = (ipzo - 1) / GDZ + 1;
@@ -278,11 +309,17 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
           wi = bw[ll];
           const float dinc = (k == 1) ? vrk * dpl : (vrk - vrp) * dpl;
           if (lane < 16) {
-            float r1 = vi * wi / (vel * vel);
-            const float r2 = vio * wio / (velo * velo);
-            r1 = -(r1 + r2) * dinc / 2.0f;
-            float *fp = &s_fdm[(ivxt - 2 + (lm + 1)) * ldf + (ivzt - 2 + (ll + 1))];
-            *fp = r1 + *fp;
+            const float rdc1 = vi * wi / (vel * vel);
+            const float rdc2 = vio * wio / (velo * velo);
+            float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
+            const int fi = (ivxt - 2 + (lm + 1)) * ldf + (ivzt - 2 + (ll + 1));
+            s_fdm[fi] = r1 + s_fdm[fi];
+            if (AZIM) {   // inv/rpathsAzim.f90:580-586
+              r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
+              s_fdmc[fi] = r1 + s_fdmc[fi];
+              r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
+              s_fdms[fi] = r1 + s_fdms[fi];
+            }
           }
         }
         x0 = x1;
@@ -299,12 +336,16 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     int nlist = 0;
     if (saved >= 0) {
       nlist = saved;
-      const size_t o = (size_t)ray * A.LK;
+      const size_t o = (size_t)ray * A.LK, ov = o * (AZIM ? 3 : 1);
       for (int i = lane; i < nlist; i += 64) {
         const int c = A.lcell[o + i];
         const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
         s_list[i] = (unsigned short)c;
-        s_fdm[kk * ldf + jj] = A.lval[o + i];
+        s_fdm[kk * ldf + jj] = A.lval[ov + i];
+        if (AZIM) {
+          s_fdmc[kk * ldf + jj] = A.lval[ov + A.LK + i];
+          s_fdms[kk * ldf + jj] = A.lval[ov + 2 * A.LK + i];
+        }
       }
     } else if (!status) {
       for (int base = 0; base < nvz * nvx; base += 64) {
@@ -321,13 +362,17 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     }
     __syncthreads();
     if (!EMIT) {   // hand the Frechet cells to the emit pass so that it need not trace the ray again
-      const size_t o = (size_t)ray * A.LK;
+      const size_t o = (size_t)ray * A.LK, ov = o * (AZIM ? 3 : 1);
       if (nlist <= A.LK)
         for (int i = lane; i < nlist; i += 64) {
           const int c = s_list[i];
           const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
           A.lcell[o + i] = (unsigned short)c;
-          A.lval[o + i] = s_fdm[kk * ldf + jj];
+          A.lval[ov + i] = s_fdm[kk * ldf + jj];
+          if (AZIM) {
+            A.lval[ov + A.LK + i] = s_fdmc[kk * ldf + jj];
+            A.lval[ov + 2 * A.LK + i] = s_fdms[kk * ldf + jj];
+          }
         }
       if (lane == 0) A.nlist[ray] = (status || nlist <= A.LK) ? (status ? 0 : nlist) : -1;
     }
@@ -335,36 +380,42 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     const int kslot = A.kidx[f] - 1;
     long cnt = 0;
     const long rstart = EMIT ? A.rowptr[ray] : 0;
-    for (int k = 1; k <= A.nz - 1; k++) {
-      for (int base = 0; base < nlist; base += 64) {
-        const int li = base + lane;
-        bool keep = false;
-        float rowv = 0.0f;
-        int nn = 0;
-        if (li < nlist) {
-          const int c = s_list[li];
-          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
-          const float fd = s_fdm[kk * ldf + jj];
-          const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
-          const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
-          const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
-          const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
-                                         0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
-          const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
-          const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
-          rowv = (float)r;
-          keep = fabsf(rowv) > FTOL;
-          nn = (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
+    const int nparpi = nvx * nvz * (A.nz - 1);
+    for (int blk = 0; blk < (AZIM ? 3 : 1); blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
+      for (int k = 1; k <= A.nz - 1; k++) {
+        for (int base = 0; base < nlist; base += 64) {
+          const int li = base + lane;
+          bool keep = false;
+          float rowv = 0.0f;
+          int nn = 0;
+          if (li < nlist) {
+            const int c = s_list[li];
+            const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+            const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
+            if (blk == 0) {
+              const float fd = s_fdm[kk * ldf + jj];
+              const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
+              const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
+              const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
+              const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
+                                             0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
+              const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
+              rowv = (float)r;
+            } else {
+              rowv = A.lsen[si] * (blk == 1 ? s_fdmc : s_fdms)[kk * ldf + jj];
+            }
+            keep = fabsf(rowv) > FTOL;
+            nn = blk * nparpi + (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
+          }
+          const unsigned long long m = __ballot(keep);
+          if (EMIT && keep) {
+            const long pos = rstart + cnt + __popcll(m & ((1ull << lane) - 1ull));
+            A.val[pos] = rowv;
+            A.col[pos] = nn - 1;
+          }
+          cnt += __popcll(m);
         }
-        const unsigned long long m = __ballot(keep);
-        if (EMIT && keep) {
-          const long pos = rstart + cnt + __popcll(m & ((1ull << lane) - 1ull));
-          A.val[pos] = rowv;
-          A.col[pos] = nn - 1;
-        }
-        cnt += __popcll(m);
       }
-    }
     if (!EMIT && lane == 0) A.count[ray] = cnt;
   }
 }
@@ -375,15 +426,15 @@ struct dazim_csr;  // sparse.hip
 extern "C" int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
                                float *val, dazim_csr **out);
 
-// = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields
-extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
                                   float dvzd, int kmax, const float *vels_u, int nfield, const float *scx_u,
                                   const float *scz_u, const int *period_u, const int *kidx_u, const float *veln_u,
                                   const float *ttn_u, const float *ttnr_u, const int *nstsr_u,
                                   const dazim_refbox *boxes_u, int64_t nray, const int *field_u, const float *rcx_u,
                                   const float *rcz_u, const double *svs_u, const double *svp_u, const double *srho_u,
-                                  float *dsurf_u, dazim_csr **G, int64_t *nnz_out, int *n_boundary) {
+                                  const float *lsen_u, float *dsurf_u, dazim_csr **G, int64_t *nnz_out, int *n_boundary) {
   if (!ctx || !G) return DAZIM_E_BAD_ARG;
+  const bool joint = lsen_u != nullptr;
   dazim_geom g;
   if (dazim_geometry(nx, ny, goxd, gozd, dvxd, dvzd, &g)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad grid");
   if (nray < 0 || nfield < 1 || nz < 2 || (size_t)g.nvx * g.nvz > 65535u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_rays_build_G");
@@ -412,6 +463,8 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   if ((rc = svp.init(ctx, svp_u, nk, true, false))) return rc;
   if ((rc = srho.init(ctx, srho_u, nk, true, false))) return rc;
   if ((rc = dsurf.init(ctx, dsurf_u, nray, false, true))) return rc;
+  DzBuf<float> lsen;
+  if (joint && (rc = lsen.init(ctx, lsen_u, (size_t)(nz - 1) * kmax * ncol, true, false))) return rc;
 
   RayArgs A;
   A.g = g;
@@ -420,6 +473,7 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   A.field = field.dev; A.rcx = rcx.dev; A.rcz = rcz.dev; A.scx = scx.dev; A.scz = scz.dev;
   A.period = period.dev; A.kidx = kidx.dev; A.veln = veln.dev; A.ttn = ttn.dev; A.ttnr = ttnr.dev;
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
+  A.lsen = joint ? lsen.dev : nullptr;
   {  // dpl, inv/CalSurfG.f90:1829-1833 (host libm sin, geometry only)
     float dpl = g.dnx * EARTH;
     float rd1 = g.dnz * EARTH * sinf(g.gox);
@@ -442,7 +496,7 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   A.nlist = (int *)p;
   if ((rc = dz_scratch(ctx, "rays.lcell", nr1 * A.LK * 2, &p))) return rc;
   A.lcell = (unsigned short *)p;
-  if ((rc = dz_scratch(ctx, "rays.lval", nr1 * A.LK * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "rays.lval", nr1 * A.LK * 4 * (joint ? 3 : 1), &p))) return rc;
   A.lval = (float *)p;
   int64_t *rowptr = nullptr;
   DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + 1) * 8));
@@ -450,9 +504,11 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
   A.col = nullptr;
-  const size_t lds = (size_t)(g.nvx + 2) * (g.nvz + 2) * 4 + (size_t)g.nvx * g.nvz * 2 + 16;
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = (size_t)(g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1) + (size_t)g.nvx * g.nvz * 2 + 16;
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)(160 * 1024 / (lds + 256));
   if (per_cu > 32) per_cu = 32;
   if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS Frechet grid");
@@ -462,7 +518,10 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
   if (nray > 0) {
-    hipLaunchKernelGGL(rays_kernel<false>, dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    if (joint)
+      hipLaunchKernelGGL((rays_kernel<false, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((rays_kernel<false, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
   }
   {  // exclusive scan of the row counts -> rowptr
@@ -480,7 +539,10 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
   A.val = val;
   A.col = col;
   if (nray > 0) {
-    hipLaunchKernelGGL(rays_kernel<true>, dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    if (joint)
+      hipLaunchKernelGGL((rays_kernel<true, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
+    else
+      hipLaunchKernelGGL((rays_kernel<true, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
   }
   t.stop();
@@ -506,6 +568,32 @@ extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float 
     (void)hipFree(col);
     return err;
   }
-  const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1);
+  const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1);
   return dazim_csr_adopt(ctx, m, n, nnz, rowptr, col, val, G);
+}
+
+// = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields
+extern "C" int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+                                  float dvzd, int kmax, const float *vels, int nfield, const float *scx,
+                                  const float *scz, const int *period, const int *kidx, const float *veln,
+                                  const float *ttn, const float *ttnr, const int *nstsr, const dazim_refbox *boxes,
+                                  int64_t nray, const int *field, const float *rcx, const float *rcz,
+                                  const double *svs, const double *svp, const double *srho, float *dsurf,
+                                  dazim_csr **G, int64_t *nnz_out, int *n_boundary) {
+  return rays_build_impl(ctx, nx, ny, nz, goxd, gozd, dvxd, dvzd, kmax, vels, nfield, scx, scz, period, kidx, veln, ttn, ttnr,
+                         nstsr, boxes, nray, field, rcx, rcz, svs, svp, srho, nullptr, dsurf, G, nnz_out, n_boundary);
+}
+// = the receiver loop of CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:680-752): rpathsAzim and rows
+// with the three column blocks dVs | Gc | Gs; lsen = Lsen_Gsc from depthkernelTI (TI kernels, an input)
+extern "C" int dazim_rays_build_G_joint(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+                                        float dvzd, int kmax, const float *vels, int nfield, const float *scx,
+                                        const float *scz, const int *period, const int *kidx, const float *veln,
+                                        const float *ttn, const float *ttnr, const int *nstsr,
+                                        const dazim_refbox *boxes, int64_t nray, const int *field, const float *rcx,
+                                        const float *rcz, const double *svs, const double *svp, const double *srho,
+                                        const float *lsen, float *dsurf, dazim_csr **G, int64_t *nnz_out,
+                                        int *n_boundary) {
+  if (!lsen) return dz_fail(ctx, DAZIM_E_BAD_ARG, "joint mode needs Lsen_Gsc");
+  return rays_build_impl(ctx, nx, ny, nz, goxd, gozd, dvxd, dvzd, kmax, vels, nfield, scx, scz, period, kidx, veln, ttn, ttnr,
+                         nstsr, boxes, nray, field, rcx, rcz, svs, svp, srho, lsen, dsurf, G, nnz_out, n_boundary);
 }

@@ -19,7 +19,7 @@ module dazim_mod
   use iso_c_binding
   implicit none
   private
-  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, aprod, LSMR, dazim_handle
+  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
 
@@ -67,6 +67,20 @@ module dazim_mod
       integer(c_int64_t), value :: nray
       real(c_float), value :: goxd, gozd, dvxd, dvzd
       real(c_float) :: vels(*), scx(*), scz(*), rcx(*), rcz(*), tpred(*)
+      integer(c_int) :: period_idx(*), kernel_idx(*), field_of_ray(*), nboundary
+      real(c_double) :: svs(*), svp(*), srho(*)
+      type(c_ptr) :: G
+      integer(c_int64_t) :: nnz
+    end function
+    integer(c_int) function dazim_rays_build_G_joint(ctx, nx, ny, nz, goxd, gozd, dvxd, dvzd, kmax, vels, nfield, scx, scz, &
+        period_idx, kernel_idx, veln, ttn, ttnr, nstsr, boxes, nray, field_of_ray, rcx, rcz, svs, svp, srho, lsen, &
+        tpred, G, nnz, nboundary) bind(C, name="dazim_rays_build_G_joint")
+      import
+      type(c_ptr), value :: ctx, veln, ttn, ttnr, nstsr, boxes
+      integer(c_int), value :: nx, ny, nz, kmax, nfield
+      integer(c_int64_t), value :: nray
+      real(c_float), value :: goxd, gozd, dvxd, dvzd
+      real(c_float) :: vels(*), scx(*), scz(*), rcx(*), rcz(*), tpred(*), lsen(*)
       integer(c_int) :: period_idx(*), kernel_idx(*), field_of_ray(*), nboundary
       real(c_double) :: svs(*), svp(*), srho(*)
       type(c_ptr) :: G
@@ -170,6 +184,35 @@ contains
     real*8 :: tRc(*)
     integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
+    real :: nolsen(1)
+    call build_G(.false., nx, ny, nz, vels, iw, rw, col, dsurf, nolsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
+                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar)
+  end subroutine
+
+  ! joint rows dVs | Gc | Gs (receiver loop of inv/CalSurfGAniso_Joint.f90:209) given Lsen_Gsc; pv2 optional out
+  subroutine dazim_calsurfg_joint(nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
+                                  periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+    integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
+    real :: vels(nx, ny, nz), rw(*), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
+    integer :: iw(*), col(*)
+    real*8 :: tRc(*)
+    integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
+    real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
+    real*8, optional :: pvout(nx*ny, kmaxRc)
+    call build_G(.true., nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
+                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+  end subroutine
+
+  subroutine build_G(joint, nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
+                     periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+    logical :: joint
+    integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
+    real :: vels(nx, ny, nz), rw(*), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
+    integer :: iw(*), col(*)
+    real*8 :: tRc(*)
+    integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
+    real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
+    real*8, optional :: pvout(nx*ny, kmaxRc)
     real*8, allocatable :: pv(:, :), svs(:, :, :), svp(:, :, :), srho(:, :, :)
     real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
     integer, allocatable :: per(:), kidx(:), fray(:), irow(:)
@@ -209,9 +252,16 @@ contains
     call check(dazim_malloc(dazim_handle, d_box, int(48, c_size_t)*nfield), 'malloc')
     call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, pv, nfield, scx, scz, per, &
                                d_veln, d_ttn, d_ttnr, d_nstsr, d_box, c_null_ptr), 'CalSurfG/travel')
-    call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
-                                  per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
-                                  svs, svp, srho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+    if (joint) then
+      call check(dazim_rays_build_G_joint(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
+                                    per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
+                                    svs, svp, srho, lsen, dsurf, G, nnz64, nb), 'CalSurfGAnisoJoint/rpathsAzim')
+    else
+      call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
+                                    per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
+                                    svs, svp, srho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+    end if
+    if (present(pvout)) pvout = pv
     nar = int(nnz64)
     allocate (irow(max(nar, 1)))
     call check(dazim_csr_to_coo(dazim_handle, G, irow, col, rw), 'CalSurfG/coo')

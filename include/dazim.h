@@ -157,6 +157,21 @@ int dazim_rays_build_G(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float
                        const double *sen_rho, float *tpred, dazim_csr **G, int64_t *nnz,
                        int *n_boundary);
 
+/* joint Vsv + 2-psi mode: = the receiver loop of CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:680-752):
+ * rpathsAzim (inv/rpathsAzim.f90:16: the same ray plus per-step azimuth psi from azdist :687 and
+ * cos/sin(2 psi)-weighted Frechet grids) and rows with three column blocks dVs | Gc | Gs, so
+ * n = 3*(nx-2)*(ny-2)*(nz-1).  Lsen_Gsc [nz-1][kmax][nx*ny] fp32 (= Fortran Lsen_Gsc(nx*ny,kmax,nz-1))
+ * are the TI depth kernels of depthkernelTI/tregn96 (inv/depthkernelTI.f90:2), an INPUT here
+ * (SURVEY 8f N1).  Other arguments as dazim_rays_build_G.                                        */
+int dazim_rays_build_G_joint(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, float gozd, float dvxd,
+                             float dvzd, int kmax, const float *vels, int nfield, const float *scx,
+                             const float *scz, const int *period_idx, const int *kernel_idx,
+                             const float *veln, const float *ttn, const float *ttnr, const int *nstsr,
+                             const dazim_refbox *boxes, int64_t nray, const int *field_of_ray,
+                             const float *rcx, const float *rcz, const double *sen_vs,
+                             const double *sen_vp, const double *sen_rho, const float *Lsen_Gsc,
+                             float *tpred, dazim_csr **G, int64_t *nnz, int *n_boundary);
+
 /* = aprod (inv/aprod.f90:7): mode 1: y(m) += A*x(n) ; mode 2: x(n) += A^T*y(m)                    */
 int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y);
 

@@ -73,6 +73,18 @@ int orc_srtimes(const orc_geom *g, const float *veln, const float *ttn, float sc
 int orc_rpaths(const orc_geom *g, const orc_refbox *box, const float *veln, const float *ttn,
                const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
                float *fdm, int *rb);
+/* inv/rpathsAzim.f90:16 ; as orc_rpaths plus the cos/sin(2 psi)-weighted grids fdmc, fdms */
+int orc_rpaths_azim(const orc_geom *g, const orc_refbox *box, const float *veln, const float *ttn,
+                    const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
+                    float *fdm, float *fdmc, float *fdms, int *rb);
+/* source loop of inv/CalSurfGAniso_Joint.f90:209 given Lsen_Gsc (lsen[nz-1][kmax][nx*ny], fp32):
+ * rows have three column blocks dVs | Gc | Gs, n = 3*(nx-2)*(ny-2)*(nz-1) */
+int orc_calsurfg_joint(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,
+                       float dvzd, int kmax, const double *tRc, const float *depz, float minthk,
+                       int nsrc, int nrcf, const float *scxf, const float *sczf, const float *rcxf,
+                       const float *rczf, const int *nrc1, const int *nsrc1, const int *periods,
+                       const float *lsen, int64_t maxnar, float *rw, int *irow, int *icol, float *dsurf,
+                       int64_t *nar, int *nboundary);
 /* inv/CalSurfG.f90:909 (whole iso G assembly).  Layouts as the Fortran arrays:
  * vels[nz][ny][nx]; scxf[kmax][nsrc]; rcxf[kmax][nsrc][nrcf]; nrc1/periods[kmax][nsrc]; nsrc1[kmax].
  * COO out: rw/irow/icol (1-based like iw/col), dsurf[dall]. returns 0 or reference-STOP code. */

@@ -126,6 +126,34 @@ class Oracle:
                                  C.c_float(scx), C.c_float(scz), C.c_float(rcx), C.c_float(rcz), pf(fdm), C.byref(rb))
         return rc, fdm, rb.value
 
+    def rpaths_azim(self, g, box, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz):
+        f = [np.zeros((g.nvx + 2, g.nvz + 2), f32) for _ in range(3)]
+        rb = C.c_int(0)
+        rc = self.lib.orc_rpaths_azim(C.byref(g), C.byref(box), pf(veln), pf(ttn), pf(ttnr), pi(nstsr),
+                                      C.c_float(scx), C.c_float(scz), C.c_float(rcx), C.c_float(rcz),
+                                      pf(f[0]), pf(f[1]), pf(f[2]), C.byref(rb))
+        return rc, f[0], f[1], f[2], rb.value
+
+    def calsurfg_joint(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf,
+                       nrc1, nsrc1, periods, lsen, maxnar):
+        vels = np.ascontiguousarray(vels, f32)
+        nz, ny, nx = vels.shape
+        kmax, nsrc = scxf.shape
+        nrcf = rcxf.shape[2]
+        dall = int(sum(int(nrc1[k, :nsrc1[k]].sum()) for k in range(kmax)))
+        rw = np.zeros(maxnar, f32); irow = np.zeros(maxnar, i32); icol = np.zeros(maxnar, i32)
+        dsurf = np.zeros(dall, f32)
+        nar = C.c_int64(0); nb = C.c_int(0)
+        tRc = np.ascontiguousarray(tRc, f64); depz = np.ascontiguousarray(depz, f32)
+        lsen = np.ascontiguousarray(lsen, f32)
+        rc = self.lib.orc_calsurfg_joint(nx, ny, nz, pf(vels), C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
+                                         C.c_float(dvzd), kmax, pd(tRc), pf(depz), C.c_float(minthk), nsrc, nrcf,
+                                         pf(scxf), pf(sczf), pf(rcxf), pf(rczf), pi(nrc1), pi(nsrc1), pi(periods),
+                                         pf(lsen), C.c_int64(maxnar), pf(rw), pi(irow), pi(icol), pf(dsurf),
+                                         C.byref(nar), C.byref(nb))
+        n = nar.value
+        return rc, rw[:n].copy(), irow[:n].copy(), icol[:n].copy(), dsurf, nb.value
+
     def calsurfg(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf,
                  nrc1, nsrc1, periods, maxnar):
         vels = np.ascontiguousarray(vels, f32)
@@ -207,7 +235,7 @@ class Ref:
                                  pd(s[0]), pd(s[1]), pd(s[2]))
         return pv, s
 
-    def fmm_field(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, rcx=(), rcz=()):
+    def fmm_field(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, rcx=(), rcz=(), azim=False):
         nvx, nvz = nx - 2, ny - 2
         nnx, nnz = (nvx - 1) * 5 + 1, (nvz - 1) * 5 + 1
         pv = np.ascontiguousarray(pv, f64)
@@ -219,12 +247,39 @@ class Ref:
         nrc = len(rcx)
         dsurf = np.zeros(max(nrc, 1), f32)
         fdm = np.zeros((max(nrc, 1), nvx + 2, nvz + 2), f32)
+        fdmc = np.zeros_like(fdm); fdms = np.zeros_like(fdm)
         rb = C.c_int(0)
         self.lib.ref_fmm_field(nx, ny, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd), C.c_float(dvzd), pd(pv),
                                C.c_float(scx), C.c_float(scz), pf(veln), pf(ttn), pf(ttnr), pi(nstsr), pf(velnr),
-                               pi(box), pf(gor), nrc, pf(rcx), pf(rcz), pf(dsurf), pf(fdm), C.byref(rb))
+                               pi(box), pf(gor), nrc, pf(rcx), pf(rcz), pf(dsurf), pf(fdm), C.byref(rb),
+                               1 if azim else 0, pf(fdmc), pf(fdms))
         return dict(veln=veln, ttn=ttn, ttnr=ttnr, nstsr=nstsr, velnr=velnr, box=box, gor=gor,
-                    dsurf=dsurf[:nrc], fdm=fdm[:nrc], rb=rb.value)
+                    dsurf=dsurf[:nrc], fdm=fdm[:nrc], fdmc=fdmc[:nrc], fdms=fdms[:nrc], rb=rb.value)
+
+    def calsurfg_joint(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf,
+                       nrc1, nsrc1, periods, maxnar):
+        """CalSurfGAnisoJoint -> (rw, irow, icol, dsurf, Lsen_Gsc[nz-1][kmax][nx*ny])"""
+        vels = np.ascontiguousarray(vels, f32)
+        nz, ny, nx = vels.shape
+        kmax, nsrc = scxf.shape
+        nrcf = rcxf.shape[2]
+        dall = int(sum(int(nrc1[k, :nsrc1[k]].sum()) for k in range(kmax)))
+        rw = np.zeros(maxnar, f32); irow = np.zeros(maxnar, i32); icol = np.zeros(maxnar, i32)
+        dsurf = np.zeros(dall, f32)
+        lsen = np.zeros((nz - 1, kmax, nx * ny), f32)
+        nar = C.c_int(0)
+        tRc = np.ascontiguousarray(tRc, f64); depz = np.ascontiguousarray(depz, f32)
+        rmax = 1   # CalRmax (inv/Main_Jt.f90:838): number of refined layers incl. half-space
+        for i in range(nz - 1):
+            thk = np.float32(depz[i + 1] - depz[i])
+            rmax += int((thk + np.float32(1e-4)) / (thk / np.float32(minthk))) + 1
+        a = [np.array(x, copy=True) for x in (scxf, sczf, rcxf, rczf)]
+        self.lib.ref_calsurfg_joint(nx, ny, nz, pf(vels), C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd),
+                                    C.c_float(dvzd), kmax, pd(tRc), pf(depz), C.c_float(minthk), rmax, nsrc, nrcf,
+                                    pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]), pi(nrc1), pi(nsrc1), pi(periods),
+                                    dall, maxnar, pf(rw), pi(irow), pi(icol), pf(dsurf), C.byref(nar), pf(lsen))
+        n = nar.value
+        return rw[:n].copy(), irow[:n].copy(), icol[:n].copy(), dsurf, lsen
 
     def calsurfg(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf,
                  nrc1, nsrc1, periods, maxnar):

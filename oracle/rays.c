@@ -104,16 +104,44 @@ int orc_srtimes(const orc_geom *g, const float *veln, const float *ttn, float sc
   return 0;
 }
 
-/* inv/CalSurfG.f90:1735-2283 (asgr=1 branch; cfd always on) */
-int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
-               const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
-               float *fdm, int *rb) {
+/* azdist, inv/rpathsAzim.f90:687-793, with the reference's implicit typing: the arguments, piby2 and
+ * predel are REAL*4, pi is the double of a single-precision literal.  Only `az` is returned. */
+static float azdist_az(float stalat, float stalon, float evtlat, float evtlon) {
+  const double pi = (double)3.1415926535898f;
+  const float piby2 = (float)(pi / (double)2.f);
+  const double rad = (double)2.f * pi / (double)360.f;
+  const double sph = (double)(1.0f / 298.257f);
+  const double scolat = (double)piby2 - atan((1. - sph) * (1. - sph) * tan((double)stalat * rad));
+  const double ecolat = (double)piby2 - atan((1. - sph) * (1. - sph) * tan((double)evtlat * rad));
+  const double slon = (double)stalon * rad, elon = (double)evtlon * rad;
+  const double a = sin(scolat) * cos(slon), b = sin(scolat) * sin(slon), c = cos(scolat);
+  const double dd = sin(elon), ee = -cos(elon), cc = cos(ecolat);
+  const double gg = -cc * ee, hh = cc * dd, kk = -sin(ecolat);
+  const double rhs1 = (a - dd) * (a - dd) + (b - ee) * (b - ee) + c * c - (double)2.f;
+  const double rhs2 = (a - gg) * (a - gg) + (b - hh) * (b - hh) + (c - kk) * (c - kk) - (double)2.f;
+  double daz = atan2(rhs1, rhs2);
+  if (daz < 0.0) daz = daz + 2 * pi;
+  float az = (float)(daz / rad);
+  if (fabsf(az - 360.f) < .00001f) az = 0.0f;
+  return az;
+}
+
+/* inv/CalSurfG.f90:1735-2283 (asgr=1 branch; cfd always on); with fdmc/fdms != NULL it is
+ * rpathsAzim (inv/rpathsAzim.f90:16-684): the same ray plus cos/sin(2 psi)-weighted grids */
+static int rpaths_impl(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
+                       const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
+                       float *fdm, float *fdmc, float *fdms, int *rb) {
   int nnx = g->nnx, nnz = g->nnz, nvz = g->nvz, nvx = g->nvx;
   float gox = g->gox, goz = g->goz, dnx = g->dnx, dnz = g->dnz, dvx = g->dvx, dvz = g->dvz;
   float goxr = b->goxr, gozr = b->gozr, dnxr = b->dnxr, dnzr = b->dnzr;
   int nnxr = b->nnxr, nnzr = b->nnzr;
   int ldf = nvz + 2;
   memset(fdm, 0, sizeof(float) * (size_t)ldf * (nvx + 2));
+  if (fdmc) {
+    memset(fdmc, 0, sizeof(float) * (size_t)ldf * (nvx + 2));
+    memset(fdms, 0, sizeof(float) * (size_t)ldf * (nvx + 2));
+  }
+  const float PI_F = 3.1415926535898f;
   int isx = (int)((scx - goxr) / dnxr) + 1;
   int isz = (int)((scz - gozr) / dnzr) + 1;
   float dpl = 0.5f * min_cell(g);
@@ -180,6 +208,15 @@ int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const 
     if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; *rb = 1; }
     if (ipz < 1) { z1 = goz; ipz = 1; *rb = 1; }
     if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; *rb = 1; }
+    float c2psi = 0.0f, s2psi = 0.0f;
+    if (fdmc) { /* inv/rpathsAzim.f90:415-423 */
+      const float rgx1 = (PI_F / 2 - x0) * 180.0f / PI_F, rgz1 = z0 * 180.0f / PI_F;
+      const float rgx2 = (PI_F / 2 - x1) * 180.0f / PI_F, rgz2 = z1 * 180.0f / PI_F;
+      const float az = azdist_az(rgx2, rgz2, rgx1, rgz1);
+      const float rgpsi = az / 180 * PI_F;
+      c2psi = cosf(2.0f * rgpsi);
+      s2psi = sinf(2.0f * rgpsi);
+    }
     /* Frechet part, :2077-2229 */
     int ivx = (ipx - 1) / GDX + 1, ivz = (ipz - 1) / GDZ + 1;
     int ivxo = (ipxo - 1) / GDX + 1, ivzo = (ipzo - 1) / GDZ + 1;
@@ -242,11 +279,17 @@ int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const 
       float dinc = (k == 1) ? vrat[0] * dpl : (vrat[k - 1] - vrat[k - 2]) * dpl;
       for (int l = 1; l <= 4; l++)
         for (int m = 1; m <= 4; m++) {
-          float r1 = vi[m - 1] * wi[l - 1] / (vel * vel);
-          float r2 = vio[m - 1] * wio[l - 1] / (velo * velo);
-          r1 = -(r1 + r2) * dinc / 2.0f;
-          float *f = &fdm[(size_t)(ivxt - 2 + m) * ldf + (ivzt - 2 + l)];
-          *f = r1 + *f;
+          const float rdc1 = vi[m - 1] * wi[l - 1] / (vel * vel);
+          const float rdc2 = vio[m - 1] * wio[l - 1] / (velo * velo);
+          float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
+          const size_t fi = (size_t)(ivxt - 2 + m) * ldf + (ivzt - 2 + l);
+          fdm[fi] = r1 + fdm[fi];
+          if (fdmc) { /* inv/rpathsAzim.f90:580-586 */
+            r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
+            fdmc[fi] = r1 + fdmc[fi];
+            r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
+            fdms[fi] = r1 + fdms[fi];
+          }
         }
     }
     x0 = x1;
@@ -255,15 +298,28 @@ int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const 
   return 0;
 }
 
+int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
+               const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
+               float *fdm, int *rb) {
+  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, NULL, NULL, rb);
+}
+int orc_rpaths_azim(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
+                    const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
+                    float *fdm, float *fdmc, float *fdms, int *rb) {
+  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, fdmc, fdms, rb);
+}
+
 /* G-row of one ray: inv/CalSurfG.f90:1339-1364.  sen_*[nz][kmax][nx*ny]; kidx 0-based period.
  * appends (1-based) COO entries; returns #appended or -1 if it would overflow maxnar. */
-static long emit_row(int nx, int ny, int nz, const float *vels, const float *fdm, const double *svs,
+static long emit_row(int nx, int ny, int nz, const float *vels, const float *fdm, const float *fdmc,
+                     const float *fdms, const float *lsen, const double *svs,
                      const double *svp, const double *srho, int kmax, int kidx, int rowid,
                      float *row, int64_t nar, int64_t maxnar, float *rw, int *irow, int *icol) {
   const float ftol = 1e-4f;
   int nvx = nx - 2, nvz = ny - 2, nparpi = nvx * nvz * (nz - 1);
+  const int nblk = fdmc ? 3 : 1; /* joint: dVs | Gc | Gs column blocks, inv/CalSurfGAniso_Joint.f90:728-738 */
   size_t ncol = (size_t)nx * ny;
-  memset(row, 0, sizeof(float) * nparpi);
+  memset(row, 0, sizeof(float) * nparpi * nblk);
   for (int jj = 1; jj <= nvz; jj++)
     for (int kk = 1; kk <= nvx; kk++) {
       float f = fdm[(size_t)kk * (nvz + 2) + jj];
@@ -280,10 +336,15 @@ static long emit_row(int nx, int ny, int nz, const float *vels, const float *fdm
         size_t si = ((size_t)(k - 1) * kmax + kidx) * ncol + cell;
         double r = (svp[si] * (double)coe_a + srho[si] * (double)coe_rho + svs[si]) * (double)f;
         row[(size_t)(k - 1) * nvz * nvx + (jj - 1) * nvx + kk - 1] = (float)r;
+        if (fdmc) {
+          const float L = lsen[si];
+          row[(size_t)nparpi + (size_t)(k - 1) * nvz * nvx + (jj - 1) * nvx + kk - 1] = L * fdmc[(size_t)kk * (nvz + 2) + jj];
+          row[(size_t)2 * nparpi + (size_t)(k - 1) * nvz * nvx + (jj - 1) * nvx + kk - 1] = L * fdms[(size_t)kk * (nvz + 2) + jj];
+        }
       }
     }
   long cnt = 0;
-  for (int nn = 1; nn <= nparpi; nn++)
+  for (int nn = 1; nn <= nparpi * nblk; nn++)
     if (fabsf(row[nn - 1]) > ftol) {
       if (nar + cnt >= maxnar) return -1;
       rw[nar + cnt] = row[nn - 1];
@@ -294,11 +355,14 @@ static long emit_row(int nx, int ny, int nz, const float *vels, const float *fdm
   return cnt;
 }
 
-/* inv/CalSurfG.f90:909-1422 */
-int orc_calsurfg(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,
+/* inv/CalSurfG.f90:909-1422 ; with lsen != NULL the source loop of CalSurfGAnisoJoint
+ * (inv/CalSurfGAniso_Joint.f90:488-792): rpathsAzim and three column blocks per row.
+ * lsen[nz-1][kmax][nx*ny] = Lsen_Gsc from depthkernelTI (TI kernels are an input here). */
+static int calsurfg_impl(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,
                  float dvzd, int kmax, const double *tRc, const float *depz, float minthk,
                  int nsrc, int nrcf, const float *scxf, const float *sczf, const float *rcxf,
                  const float *rczf, const int *nrc1, const int *nsrc1, const int *periods,
+                 const float *lsen,
                  int64_t maxnar, float *rw, int *irow, int *icol, float *dsurf, int64_t *nar_out,
                  int *nboundary) {
   orc_geom g;
@@ -312,8 +376,9 @@ int orc_calsurfg(int nx, int ny, int nz, const float *vels, float goxd, float go
   float *veln = (float *)malloc(sizeof(float) * nn), *ttn = (float *)malloc(sizeof(float) * nn);
   float *ttnr = (float *)malloc(sizeof(float) * nr), *velnr = (float *)malloc(sizeof(float) * nr);
   int *nstsr = (int *)malloc(sizeof(int) * nr);
-  float *fdm = (float *)malloc(sizeof(float) * (size_t)(g.nvx + 2) * (g.nvz + 2));
-  float *row = (float *)malloc(sizeof(float) * (size_t)g.nvx * g.nvz * (nz - 1));
+  size_t nfd = (size_t)(g.nvx + 2) * (g.nvz + 2);
+  float *fdm = (float *)malloc(sizeof(float) * nfd * 3), *fdmc = lsen ? fdm + nfd : NULL, *fdms = lsen ? fdm + 2 * nfd : NULL;
+  float *row = (float *)malloc(sizeof(float) * (size_t)g.nvx * g.nvz * (nz - 1) * 3);
   int64_t nar = 0;
   int count1 = 0, rc = 0, rbindex = 0;
   int rb = 0; /* rbint is never reset inside CalSurfG (:1061), so it latches */
@@ -332,8 +397,8 @@ int orc_calsurfg(int nx, int ny, int nz, const float *vels, float goxd, float go
         if ((rc = orc_srtimes(&g, veln, ttn, x, z, rx, rz, &t))) break;
         count1++;
         dsurf[count1 - 1] = t;
-        if ((rc = orc_rpaths(&g, &box, veln, ttn, ttnr, nstsr, x, z, rx, rz, fdm, &rb))) break;
-        long c = emit_row(nx, ny, nz, vels, fdm, svs, svp, srho, kmax, knumi, count1, row, nar, maxnar, rw, irow, icol);
+        if ((rc = rpaths_impl(&g, &box, veln, ttn, ttnr, nstsr, x, z, rx, rz, fdm, fdmc, fdms, &rb))) break;
+        long c = emit_row(nx, ny, nz, vels, fdm, fdmc, fdms, lsen, svs, svp, srho, kmax, knumi, count1, row, nar, maxnar, rw, irow, icol);
         if (c < 0) { rc = 4; break; }
         nar += c;
       }
@@ -344,4 +409,23 @@ int orc_calsurfg(int nx, int ny, int nz, const float *vels, float goxd, float go
   free(pv); free(svs); free(svp); free(srho); free(veln); free(ttn); free(ttnr); free(velnr);
   free(nstsr); free(fdm); free(row);
   return rc;
+}
+
+int orc_calsurfg(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,
+                 float dvzd, int kmax, const double *tRc, const float *depz, float minthk,
+                 int nsrc, int nrcf, const float *scxf, const float *sczf, const float *rcxf,
+                 const float *rczf, const int *nrc1, const int *nsrc1, const int *periods,
+                 int64_t maxnar, float *rw, int *irow, int *icol, float *dsurf, int64_t *nar_out,
+                 int *nboundary) {
+  return calsurfg_impl(nx, ny, nz, vels, goxd, gozd, dvxd, dvzd, kmax, tRc, depz, minthk, nsrc, nrcf, scxf, sczf, rcxf,
+                       rczf, nrc1, nsrc1, periods, NULL, maxnar, rw, irow, icol, dsurf, nar_out, nboundary);
+}
+int orc_calsurfg_joint(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,
+                       float dvzd, int kmax, const double *tRc, const float *depz, float minthk,
+                       int nsrc, int nrcf, const float *scxf, const float *sczf, const float *rcxf,
+                       const float *rczf, const int *nrc1, const int *nsrc1, const int *periods,
+                       const float *lsen, int64_t maxnar, float *rw, int *irow, int *icol, float *dsurf,
+                       int64_t *nar_out, int *nboundary) {
+  return calsurfg_impl(nx, ny, nz, vels, goxd, gozd, dvxd, dvzd, kmax, tRc, depz, minthk, nsrc, nrcf, scxf, sczf, rcxf,
+                       rczf, nrc1, nsrc1, periods, lsen, maxnar, rw, irow, icol, dsurf, nar_out, nboundary);
 }

@@ -48,12 +48,13 @@ contains
   !         [vnl,vnr,vnt,vnb,nnxr,nnzr,isx,isz]; gor(4) = [goxr,gozr,dnxr,dnzr]
   !         dsurf(nrc) receiver times; fdm(0:nvz+1,0:nvx+1,nrc) Frechet weights; rb = rbint flag
   subroutine ref_fmm_field(nx, ny, goxdf, gozdf, dvxdf, dvzdf, pv, scx, scz, &
-       veln_c, ttn_c, ttnr_o, nstsr_o, velnr_o, box, gor, nrc, rcx, rcz, dsurf, fdm, rb) &
+       veln_c, ttn_c, ttnr_o, nstsr_o, velnr_o, box, gor, nrc, rcx, rcz, dsurf, fdm, rb, azim, fdmc, fdms) &
        bind(C, name="ref_fmm_field")
     use globalp
     use traveltime
-    integer(c_int), value :: nx, ny, nrc
+    integer(c_int), value :: nx, ny, nrc, azim   ! azim=1: rpathsAzim (inv/rpathsAzim.f90:16) instead of rpaths
     real(c_float), value :: goxdf, gozdf, dvxdf, dvzdf, scx, scz
+    real(c_float), intent(out) :: fdmc(*), fdms(*)
     real(c_double), intent(in) :: pv(*)
     real(c_float), intent(out) :: veln_c(*), ttn_c(*), ttnr_o(129, 129), velnr_o(129, 129)
     integer(c_int), intent(out) :: nstsr_o(129, 129), box(8), rb
@@ -61,7 +62,9 @@ contains
     real(c_float), intent(in) :: rcx(*), rcz(*)
     integer :: sgs, mx, mz, nnxc, nnzc, isx, isz, k, l, i, j, maxbt, nf
     real(4) :: x, z, goxc, gozc, dnxc, dnzc, rx, rz, t
-    real(4), allocatable :: fd(:, :)
+    real(4), allocatable :: fd(:, :), fc(:, :), fs(:, :)
+    logical :: wp
+    real(8) :: tper
 
     ! constants as set in inv/CalSurfG.f90:1005-1038
     gdx = 5; gdz = 5; asgr = 1; sgdl = 8; sgs = 8; earth = 6371.0; fom = 1; snb = 0.5
@@ -158,20 +161,29 @@ contains
     end do
     ! receivers: srtimes + rpaths exactly as inv/CalSurfG.f90:1326-1338
     nf = (nvz + 2)*(nvx + 2)
-    allocate (fd(0:nvz + 1, 0:nvx + 1))
+    allocate (fd(0:nvz + 1, 0:nvx + 1), fc(0:nvz + 1, 0:nvx + 1), fs(0:nvz + 1, 0:nvx + 1))
+    wp = .false.; tper = 0
     do i = 1, nrc
       rx = rcx(i); rz = rcz(i)
       call srtimes(x, z, rx, rz, t)
       dsurf(i) = t
-      call rpaths(x, z, fd, rx, rz)
+      if (azim .eq. 1) then
+        call rpathsAzim(x, z, fd, fc, fs, rx, rz, wp, tper)
+      else
+        call rpaths(x, z, fd, rx, rz)
+      end if
       do k = 0, nvx + 1
         do l = 0, nvz + 1
           fdm((i - 1)*nf + k*(nvz + 2) + l + 1) = fd(l, k)
+          if (azim .eq. 1) then
+            fdmc((i - 1)*nf + k*(nvz + 2) + l + 1) = fc(l, k)
+            fdms((i - 1)*nf + k*(nvz + 2) + l + 1) = fs(l, k)
+          end if
         end do
       end do
     end do
     rb = rbint
-    deallocate (fd, velv, veln, ttn, nsts, velnb, ttnr, nstsr, btg)
+    deallocate (fd, fc, fs, velv, veln, ttn, nsts, velnb, ttnr, nstsr, btg)
   end subroutine
 
   ! ---- whole CalSurfG (inv/CalSurfG.f90:909) ----------------------------------------------------
@@ -198,6 +210,34 @@ contains
                   scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar)
     irow(1:nar) = iw(2:nar + 1)
     deallocate (iw, GVs)
+  end subroutine
+
+  ! ---- whole CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:209): three column blocks dVs, Gc, Gs.
+  !      lsen = Lsen_Gsc(nx*ny,kmax,nz-1) out (depthkernelTI + tregn96, inv/depthkernelTI.f90:2)
+  subroutine ref_calsurfg_joint(nx, ny, nz, vels, goxd, gozd, dvxd, dvzd, kmax, tRc, depz, minthk, rmax, &
+       nsrc, nrcf, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods, dall, maxnar, &
+       rw, irow, icol, dsurf, nar, lsen) bind(C, name="ref_calsurfg_joint")
+    integer(c_int), value :: nx, ny, nz, kmax, nsrc, nrcf, dall, maxnar, rmax
+    real(c_float), value :: goxd, gozd, dvxd, dvzd, minthk
+    real(c_float), intent(in) :: vels(nx, ny, nz), depz(nz)
+    real(c_double), intent(in) :: tRc(kmax)
+    real(c_float), intent(in) :: scxf(nsrc, kmax), sczf(nsrc, kmax)
+    real(c_float), intent(in) :: rcxf(nrcf, nsrc, kmax), rczf(nrcf, nsrc, kmax)
+    integer(c_int), intent(in) :: nrc1(nsrc, kmax), nsrc1(kmax), periods(nsrc, kmax)
+    real(c_float), intent(out) :: rw(maxnar), dsurf(dall), lsen(nx*ny, kmax, nz - 1)
+    integer(c_int), intent(out) :: irow(maxnar), icol(maxnar), nar
+    integer, allocatable :: iw(:)
+    real(4), allocatable :: GVs(:, :), GGc(:, :), GGs(:, :)
+    real(8), allocatable :: tRcV(:, :)
+    integer :: nparpi
+    nparpi = (nx - 2)*(ny - 2)*(nz - 1)
+    allocate (iw(maxnar + 1), GVs(dall, nparpi), GGc(dall, nparpi), GGs(dall, nparpi), tRcV((nx - 2)*(ny - 2), kmax))
+    iw = 0; GVs = 0; GGc = 0; GGs = 0; rw = 0; icol = 0; tRcV = 0
+    call CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, icol, dsurf, GVs, GGc, GGs, lsen, dall, rmax, tRcV, &
+                            goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
+                            scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar, 0)
+    irow(1:nar) = iw(2:nar + 1)
+    deallocate (iw, GVs, GGc, GGs, tRcV)
   end subroutine
 
   ! ---- aprod (inv/aprod.f90:7) and LSMR (inv/lsmrModule.f90:36) ---------------------------------

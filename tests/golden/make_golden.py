@@ -110,6 +110,13 @@ def main():
                         info_iso=np.array([info_iso[k] for k in ("istop", "itn", "normA", "condA", "normr", "normAr", "normx")], np.float64),
                         info_jt=np.array([info_jt[k] for k in ("istop", "itn", "normA", "condA", "normr", "normAr", "normx")], np.float64),
                         xv=xv, y1=y1, x2v=x2v)
+    # ---- (7) joint mode: rpathsAzim grids for one field + whole CalSurfGAnisoJoint (incl. Lsen_Gsc) ----
+    rcv = [2, 3, 5, 7, 9]
+    r = ref.fmm_field(nx, ny, goxd, gozd, dv, dv, pv[0], sx[4], sz[4], sx[rcv], sz[rcv], azim=True)
+    rwj, irj, icj, dsj, lsen = ref.calsurfg_joint(vel, depz, goxd, gozd, dv, dv, t3, 2.0, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods, 500000)
+    np.savez_compressed(os.path.join(HERE, "joint_small.npz"), pv0=pv[0], scx=sx[4], scz=sz[4], rcx=sx[rcv], rcz=sz[rcv],
+                        fdm=r["fdm"], fdmc=r["fdmc"], fdms=r["fdms"], t=t3, scxf=scxf, sczf=sczf, rcxf=rcxf, rczf=rczf,
+                        nrc1=nrc1, nsrc1=nsrc1, periods=periods, lsen=lsen, rw=rwj, irow=irj, icol=icj, dsurf=dsj)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -125,3 +125,22 @@ def test_edge_cases(orc):
     assert e == 0 and not fdm.any()
     e, _ = orc.srtimes(g, veln, ttn, sx[1], sz[1], sx[0], sz[0])
     assert e == 2
+
+
+def test_joint_golden(orc):
+    """rpathsAzim grids and whole CalSurfGAnisoJoint rows (Lsen_Gsc from the reference's
+    depthkernelTI/tregn96 stored in the fixture) -- exact"""
+    a = load("test1_authors.npz")
+    d = load("joint_small.npz")
+    g = orc.geometry(17, 17, 26.5, 101.25, 0.25, 0.25)
+    pvk = d["pv0"]
+    veln = orc.gridder(g, pvk)
+    rc, ttn, ttnr, nstsr, velnr, box = orc.fmm_field(g, pvk, veln, float(d["scx"]), float(d["scz"]))
+    for r in range(len(d["rcx"])):
+        e, f, fc, fs, rb = orc.rpaths_azim(g, box, veln, ttn, ttnr, nstsr, float(d["scx"]), float(d["scz"]), float(d["rcx"][r]), float(d["rcz"][r]))
+        assert e == 0 and np.array_equal(f, d["fdm"][r]) and np.array_equal(fc, d["fdmc"][r]) and np.array_equal(fs, d["fdms"][r])
+    rc, rw, irow, icol, dsurf, nb = orc.calsurfg_joint(a["vel"], a["depz"], 26.5, 101.25, 0.25, 0.25, d["t"], 2.0, d["scxf"], d["sczf"],
+                                                       d["rcxf"], d["rczf"], d["nrc1"], d["nsrc1"], d["periods"], d["lsen"], 500000)
+    assert rc == 0 and np.array_equal(dsurf, d["dsurf"])
+    assert np.array_equal(rw, d["rw"]) and np.array_equal(irow, d["irow"]) and np.array_equal(icol, d["icol"])
+    assert icol.max() > 2 * 15 * 15 * 3   # entries in the Gs block exist

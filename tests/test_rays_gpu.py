@@ -109,3 +109,36 @@ def test_receiver_outside_is_an_error(ctx, orc):
         ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, sx, sz, np.array([1], np.int32),
                          np.array([0, 0], np.int32), rx, rz, sen)
     assert e.value.code == 2  # DAZIM_E_RECEIVER_OUTSIDE, inv/CalSurfG.f90:1649-1655
+
+
+def test_joint_G_matches_oracle(ctx, orc):
+    """joint Vsv + 2-psi rows (CalSurfGAnisoJoint): rpathsAzim on the device (azdist in fp64, cos/sin of
+    2 psi) and the three column blocks dVs | Gc | Gs against the oracle's restatement, both fed the
+    same Lsen_Gsc.  Same tolerances as the isotropic case; the Gc/Gs blocks additionally absorb the
+    device's correctly rounded cos/sin versus libm's (<= 1 ulp of a factor of magnitude <= 1)."""
+    nx = ny = 15
+    depz = np.array([0.0, 8.0, 20.0, 40.0, 70.0], np.float32)
+    kmax, minthk = 2, 3.0
+    goxd, gozd, dv = 30.0, 100.0, 0.25
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 9, 6, seed=33)
+    t = np.array([7.0, 25.0])
+    rng = np.random.default_rng(7)
+    lsen = (0.02 + 0.9 * rng.random((len(depz) - 1, kmax, nx * ny))).astype(np.float32)   # stand-in TI kernels
+    rc, rw_o, ir_o, ic_o, ds_o, nb_o = orc.calsurfg_joint(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
+                                                          nrc1, nsrc1, periods, lsen, 4_000_000)
+    assert rc == 0
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+    m, nvp = len(ds_o), (nx - 2) * (ny - 2) * (len(depz) - 1)
+    assert (G.m, G.n) == (m, 3 * nvp)
+    assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
+    ir, ic, rw = G.to_coo()
+    D, Do = dense(m, 3 * nvp, ir, ic, rw), dense(m, 3 * nvp, ir_o, ic_o, rw_o)
+    assert np.abs(D - Do).max() <= 2e-4
+    for b in range(3):   # every block on its own: dVs, Gc, Gs
+        blk, blko = D[:, b * nvp:(b + 1) * nvp], Do[:, b * nvp:(b + 1) * nvp]
+        assert np.linalg.norm(blko) > 0
+        assert np.linalg.norm(blk - blko) <= 1e-4 * np.linalg.norm(blko), b
+    G.free()
