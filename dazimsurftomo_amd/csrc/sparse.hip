@@ -414,6 +414,12 @@ __global__ void k_offset_ptr(int64_t n, const int64_t *src, int64_t add, int64_t
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[i] + add;
 }
 
+// the CSC copy is only needed by the gather form of A^T*y: it is built on first use
+int invalidate_transpose(dazim_csr *A) {
+  for (void **pp : {(void **)&A->colptr, (void **)&A->row, (void **)&A->tval, (void **)&A->tperm})
+    if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
+  return 0;
+}
 // build the stable transpose (colptr,row,tval,tperm) of A's CSR arrays
 int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
   const int64_t nnz = A->nnz, n = A->n, m = A->m;
@@ -489,6 +495,10 @@ bool use_scatter(dazim_ctx *ctx, const dazim_csr *A) {
 int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax, float *out, const float *beta_p,
                  float beta_sign, double *sumsq, int *npart) {
   if (!use_scatter(ctx, A)) {
+    if (!A->colptr) {
+      int rc0 = build_transpose(ctx, const_cast<dazim_csr *>(A));
+      if (rc0) return rc0;
+    }
     const int gn = spmv_blocks(ctx, A->n, A->m);
     if (npart) *npart = gn;
     return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn);
@@ -606,8 +616,8 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   } else {
     DZ_HIP(hipMemsetAsync(A->rowptr, 0, (m + 1) * 8, ctx->stream));
   }
-  if ((rc = build_transpose(ctx, A))) return rc;
   if ((rc = build_colblocks(ctx, A))) return rc;
+  if ((rc = invalidate_transpose(A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -621,8 +631,8 @@ int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *
   A->m = m; A->n = n; A->nnz = nnz;
   A->rowptr = rowptr; A->col = col; A->val = val;
   int rc;
-  if ((rc = build_transpose(ctx, A))) return rc;
   if ((rc = build_colblocks(ctx, A))) return rc;
+  if ((rc = invalidate_transpose(A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -666,8 +676,8 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   (void)hipFree(A->val);
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
-  if ((rc = build_transpose(ctx, A))) return rc;
   if ((rc = build_colblocks(ctx, A))) return rc;
+  if ((rc = invalidate_transpose(A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -703,7 +713,7 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   int rc;
   if ((rc = w.init(ctx, w_u, A->m, true, false))) return rc;
   hipLaunchKernelGGL(k_scale_rows, dim3(spmv_blocks(ctx, A->m, -1)), dim3(64 * WPB), 0, ctx->stream, A->m, A->rowptr, A->val, w.dev);
-  hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
+  if (A->tperm) hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return build_colblocks(ctx, A);

@@ -1,0 +1,60 @@
+"""-m gpu: the bundled real-data example test4_Yunnan (38x42x18 model, 36 periods, 1469 sources,
+20 877 rays) through the whole device path -- dispersion + depth kernels, eikonal fields on the
+176x196 grid, rays, G, Tikhonov rows, LSMR -- against the run of the UNMODIFIED reference on the same
+inputs (tests/golden/test4_yunnan.npz, made by tests/golden/make_test4_golden.py).
+
+Tolerances: pvRc as in test_disp_gpu.py; predicted traveltimes rel <= 1e-5 (they inherit the rare
+1-ulp differences of pvRc through the velocity grid); G cannot be stored (17.7 M entries), so its
+nnz (<= 0.1 %: entries sitting on the 1e-4 threshold), per-row and per-column |G| sums (rel-L2 <= 1e-4)
+are compared; the LSMR model update of [G; 20*Laplacian] x = t_obs - t_pred must agree to rel-L2 <= 1e-2
+with the same istop and itn within +-3 (fp32 LSMR on two matrices that differ at the 1e-4 level).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tests.test_rays_gpu import flatten
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "test4_yunnan.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD), reason="test4 golden not generated")
+def test_test4_yunnan_iso_iteration(ctx, orc):
+    d = np.load(GOLD)
+    nx, ny, nz = int(d["nx"]), int(d["ny"]), int(d["nz"])
+    goxd, gozd, dv, minthk = float(d["goxd"]), float(d["gozd"]), float(d["dv"]), float(d["minthk"])
+    vel, depz, t = d["vel"], d["depz"], d["t"]
+    pv, sen, nfail = ctx.depthkernel(vel, depz, t, minthk)
+    assert nfail == 0
+    dpv = np.abs(pv - d["pv"].astype(np.float64))
+    assert dpv.max() <= 4e-6 and (pv.astype(np.float32) == d["pv"]).mean() >= 0.995
+    scx, scz, per, ray_f, rx, rz = flatten(d["scxf"], d["sczf"], d["rcxf"], d["rczf"], d["nrc1"], d["nsrc1"], d["periods"])
+    assert len(scx) == 1469 and len(rx) == 20877
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    dsurf = d["dsurf"]
+    assert np.abs(tpred - dsurf).max() <= 1e-5 * np.abs(dsurf).max()
+    dall, n = len(dsurf), (nx - 2) * (ny - 2) * (nz - 1)
+    assert (G.m, G.n) == (dall, n)
+    assert abs(G.nnz - int(d["nnz"])) <= 1e-3 * int(d["nnz"])
+    ir, ic, rw = G.to_coo()
+    rowsum = np.bincount(ir - 1, weights=np.abs(rw).astype(np.float64), minlength=dall)
+    colsum = np.bincount(ic - 1, weights=np.abs(rw).astype(np.float64), minlength=n)
+    assert np.linalg.norm(rowsum - d["rowsum"]) <= 1e-4 * np.linalg.norm(d["rowsum"])
+    assert np.linalg.norm(colsum - d["colsum"]) <= 1e-4 * np.linalg.norm(d["colsum"])
+    del ir, ic, rw
+    # Tikhonov rows exactly as the reference appends them (inv/TikhRegul.f90:2, weight 20 = para.in)
+    e = np.zeros(0, np.float32)
+    c3, rwT, irT, icT = orc.tikhonov_iso(nx, ny, nz, dall, 20.0, e, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert c3 == int(d["c3"])
+    G.append_coo(c3, irT, icT, rwT)
+    b = np.zeros(dall + c3, np.float32)
+    b[:dall] = d["obst"] - tpred
+    x, info = ctx.lsmr(G, b, 0.0, 1e-3, 1e-3, 1200.0, 1000, 64)
+    gi = d["info"]
+    assert info["istop"] == int(gi[0]) and abs(info["itn"] - int(gi[1])) <= 3
+    assert np.linalg.norm(x - d["x"]) <= 1e-2 * np.linalg.norm(d["x"])
+    assert abs(info["normr"] - gi[4]) <= 1e-3 * gi[4]
+    G.free()
