@@ -158,9 +158,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # DAZIM_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, row-partitioned LSMR with
+    # all-reduce) even with a single rank, so that it can be exercised on a 1-GPU box
+    force_dist = os.environ.get("DAZIM_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -168,7 +176,7 @@ def main():
     import dazimsurftomo_amd as dz
     if rank == 0:
         dz.build()                      # no-op when the prebuilt library is current
-    if world > 1:
+    if use_dist:
         dist.barrier()
     ctx = dz.Context(local)
 
@@ -195,7 +203,7 @@ def main():
     n_model = (NX - 2) * (NY - 2) * (nz - 1)
     c3_all, t_ir, t_ic, t_rw = tikhonov_rows(NX, NY, nz, nray, 2.0)
     c3 = c3_all
-    if world > 1:   # every rank keeps its own ray rows + an even slice of the Tikhonov rows
+    if use_dist:   # every rank keeps its own ray rows + an even slice of the Tikhonov rows
         from dazimsurftomo_amd.distributed import GpuLocalOps, lsmr_distributed, shard_rows
         r0, r1 = shard_rows(c3_all, world, rank)
         keep = (t_ir > nray + r0) & (t_ir <= nray + r1)
@@ -218,7 +226,7 @@ def main():
         stats["nnz_data"] = G.nnz
         G.append_coo(c3, t_ir, t_ic, t_rw)
         stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
-        if world == 1:
+        if not use_dist:
             x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
             stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
@@ -233,7 +241,7 @@ def main():
         G.free()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -245,7 +253,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -289,9 +297,18 @@ def main():
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
             out["speedup_vs_cpu_1core_forward"] = (nfield / (stats["disp_s"] + stats["fmm_s"] + stats["rays_s"])) / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
-    if world > 1:
+        # the JSON line must be the last thing on stdout: flush whatever native libraries (RCCL's version
+        # banner) still hold in C stdio first, and tear the process group down before printing
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

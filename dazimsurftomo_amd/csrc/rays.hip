@@ -129,7 +129,13 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
   float *s_fdmc = s_fdm + nf, *s_fdms = s_fdm + 2 * nf;   // joint mode only
   unsigned short *s_list = reinterpret_cast<unsigned short *>(s_fdm + (AZIM ? 3 : 1) * nf);
   const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
-  for (long ray = blockIdx.x; ray < A.nray; ray += gridDim.x) {
+  // XCD-aware ray order (speed only): workgroup b runs on XCD b % 8, and the 32 or so rays of one field
+  // read the same traveltime grids, so each XCD gets one contiguous eighth of the rays and its
+  // workgroups walk it together -- the fields in flight per XCD then fit its 4 MB L2.
+  const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
+  const long xcd = blockIdx.x % nxcd, wg_in_xcd = blockIdx.x / nxcd, wgs_per_xcd = gridDim.x / nxcd;
+  const long r_lo = A.nray * xcd / nxcd, r_hi = A.nray * (xcd + 1) / nxcd;
+  for (long ray = r_lo + wg_in_xcd; ray < r_hi; ray += wgs_per_xcd) {
     const int f = A.field[ray];
     const float scx = A.scx[f], scz = A.scz[f], rcx = A.rcx[ray], rcz = A.rcz[ray];
     const float *veln = A.veln + (size_t)(A.period[f] - 1) * nnx * nnz;
@@ -514,6 +520,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS Frechet grid");
   long nwg = (long)ctx->num_cu * per_cu;
   if (nwg > nray) nwg = nray;
+  if (nwg >= 8) nwg -= nwg % 8;   // the XCD-aware ray order wants a multiple of 8
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
