@@ -159,16 +159,17 @@ struct Heap {
       }
     }
   }
+  // All 16 lanes of the group hold the same (slot, key, node): the LDS entry is written by all of them
+  // (same address, same value -- no exec-mask branch inside the sift loops); the HBM back-pointer
+  // and spill stores are issued by lane 0 only.
   __device__ __forceinline__ void put(int slot, float key, int node) {
-    if (g0) {
-      if (SPILL && slot >= CAP)
-        ovf[slot - CAP] = HEnt{key, node};
-      else {
-        keys[slot] = key;
-        nodes[slot] = NodeCodec<NT>::enc(node);
-      }
-      rec[idx(node)].s = slot;
+    if (SPILL && slot >= CAP) {
+      if (g0) ovf[slot - CAP] = HEnt{key, node};
+    } else {
+      keys[slot] = key;
+      nodes[slot] = NodeCodec<NT>::enc(node);
     }
+    if (g0) rec[idx(node)].s = slot;
   }
   // sift (key,node) up from slot c.  If `track`, entries that move down are compared with the
   // pending neighbours' node ids so that their slots stay current (nbs[m] for m > from).
@@ -199,13 +200,11 @@ struct Heap {
   }
   // LDS-only write of a heap entry (the HBM back-pointer is deferred by the caller)
   __device__ __forceinline__ void put_lds(int slot, float key, int node) {
-    if (g0) {
-      if (SPILL && slot >= CAP)
-        ovf[slot - CAP] = HEnt{key, node};
-      else {
-        keys[slot] = key;
-        nodes[slot] = NodeCodec<NT>::enc(node);
-      }
+    if (SPILL && slot >= CAP) {
+      if (g0) ovf[slot - CAP] = HEnt{key, node};
+    } else {
+      keys[slot] = key;
+      nodes[slot] = NodeCodec<NT>::enc(node);
     }
   }
   // downtree.  The back-pointer stores of the entries that move are NOT issued here: move #i is

@@ -45,14 +45,32 @@ struct RayArgs {
   int *nlist;              // [nray]  cells with |fdm| >= ftol saved by the count pass (-1: did not fit, retrace)
   unsigned short *lcell;   // [nray][LK] their (jj,kk) cell ids, ascending
   float *lval;             // [nray][LK] (x3 in joint mode) their fdm (, fdmc, fdms) values
+  float *fdm_scratch;      // [nwg*4][(nvx+2)*(nvz+2)] (x3 in joint mode): one Frechet grid slot per 16-lane group
   int LK;
   const long *rowptr;      // [nray+1] (emit pass in)
   float *val;
   int *col;
 };
 
-// sin of a colatitude: evaluated in fp64 and rounded, i.e. the correctly rounded fp32 sine.
-__device__ __forceinline__ float dz_sinf(float x) { return (float)sin((double)x); }
+// sin of a colatitude x in (0, pi): sin x = cos(x - pi/2), an even Taylor polynomial to y^18 in fp64
+// (remainder < 3e-14 for |y| <= pi/2), rounded to fp32 -- the correctly rounded fp32 sine up to ties
+// nobody will hit, at a tenth of the cost of the general fp64 sin.  Outside (0, pi) fall back to it.
+__device__ __forceinline__ float dz_sinf(float x) {
+  if (!(x > 0.0f && x < 3.1415927f)) return (float)sin((double)x);
+  const double y = (double)x - 1.5707963267948966192;
+  const double y2 = y * y;
+  double p = -1.5619206968586226e-16;            // -1/18!
+  p = fma(p, y2, 4.7794773323873853e-14);        //  1/16!
+  p = fma(p, y2, -1.1470745597729725e-11);       // -1/14!
+  p = fma(p, y2, 2.0876756987868099e-09);        //  1/12!
+  p = fma(p, y2, -2.7557319223985891e-07);       // -1/10!
+  p = fma(p, y2, 2.4801587301587302e-05);        //  1/8!
+  p = fma(p, y2, -1.3888888888888889e-03);       // -1/6!
+  p = fma(p, y2, 4.1666666666666664e-02);        //  1/4!
+  p = fma(p, y2, -0.5);
+  p = fma(p, y2, 1.0);
+  return (float)p;
+}
 
 // azimuth of the step (x0,z0) -> (x1,z1): azdist (inv/rpathsAzim.f90:687-793) with the reference's
 // implicit typing, called as at inv/rpathsAzim.f90:415-423; returns cos(2 psi), sin(2 psi)
@@ -89,6 +107,16 @@ __device__ __forceinline__ void basis(float v, float b[4]) {  // inv/CalSurfG.f9
   b[3] = v * v * v / 6.0f;
 }
 
+// element i (0..3) of the cubic B-spline basis at v, inv/CalSurfG.f90:2145-2148
+__device__ __forceinline__ float basis1(float v, int i) {
+  const float om = 1.0f - v;
+  const float b0 = om * om * om / 6.0f;
+  const float b1 = (4.0f - 6.0f * (v * v) + 3.0f * (v * v * v)) / 6.0f;
+  const float b2 = (1.0f + 3.0f * v + 3.0f * (v * v) - 3.0f * (v * v * v)) / 6.0f;
+  const float b3 = v * v * v / 6.0f;
+  return i == 0 ? b0 : (i == 1 ? b1 : (i == 2 ? b2 : b3));
+}
+
 // bilinear velocity inside coarse cell (ipx,ipz), inv/CalSurfG.f90:2129-2137
 __device__ __forceinline__ float vel_at(const dazim_geom &g, const float *veln, int ipx, int ipz, float drx, float drz) {
   float vel = 0.0f;
@@ -120,22 +148,38 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   return biv;
 }
 
+constexpr int GP = 16;  // lanes per ray
+constexpr int RPW = 4;  // rays per wavefront
+__device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier (same-wave ops are in order)
+
+// One 16-lane group per ray, four rays per wavefront (the kernel is VALU-issue bound: ~330 k
+// instructions per ray when one wavefront traced one ray, and all of that work is per-ray scalar
+// work except the 4x4 B-spline scatter, which is exactly 16 lanes wide).  The Frechet grid(s) of a
+// ray live in an HBM scratch slot; the 4x4 block currently being updated is cached in registers,
+// one cell per lane, and written back when the ray moves to another B-spline cell (every ~10 steps),
+// so every cell still sees its contributions in the reference's order (fdm = r1 + fdm).
 template <bool EMIT, bool AZIM>
 __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float s_fdm[];  // fdm [(nvx+2)*(nvz+2)] (, fdmc, fdms) then cell list
+  extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][nvx*nvz] cell lists
   const dazim_geom g = A.g;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
+  const int lm = gl & 3, ll = gl >> 2;  // this lane's (m,l) of the 4x4 scatter
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
-  float *s_fdmc = s_fdm + nf, *s_fdms = s_fdm + 2 * nf;   // joint mode only
-  unsigned short *s_list = reinterpret_cast<unsigned short *>(s_fdm + (AZIM ? 3 : 1) * nf);
+  constexpr int NG = AZIM ? 3 : 1;
+  unsigned short *s_list = s_lists + (size_t)grp * nvx * nvz;
+  float *gfdm = A.fdm_scratch + ((size_t)blockIdx.x * RPW + grp) * nf * NG;
+  float *gfdmc = gfdm + nf, *gfdms = gfdm + 2 * nf;
   const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
-  // XCD-aware ray order (speed only): workgroup b runs on XCD b % 8, and the 32 or so rays of one field
-  // read the same traveltime grids, so each XCD gets one contiguous eighth of the rays and its
-  // workgroups walk it together -- the fields in flight per XCD then fit its 4 MB L2.
+  const unsigned gmask_shift = grp * GP;
+  // XCD-aware order (speed only): workgroup b runs on XCD b % 8, and the rays of one field read the
+  // same traveltime grids, so each XCD gets one contiguous eighth of the ray quads
+  const long nquad = (A.nray + RPW - 1) / RPW;
   const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
   const long xcd = blockIdx.x % nxcd, wg_in_xcd = blockIdx.x / nxcd, wgs_per_xcd = gridDim.x / nxcd;
-  const long r_lo = A.nray * xcd / nxcd, r_hi = A.nray * (xcd + 1) / nxcd;
-  for (long ray = r_lo + wg_in_xcd; ray < r_hi; ray += wgs_per_xcd) {
+  const long q_lo = nquad * xcd / nxcd, q_hi = nquad * (xcd + 1) / nxcd;
+  for (long quad = q_lo + wg_in_xcd; quad < q_hi; quad += wgs_per_xcd) {
+    const long ray = quad * RPW + grp;
+    if (ray >= A.nray) continue;
     const int f = A.field[ray];
     const float scx = A.scx[f], scz = A.scz[f], rcx = A.rcx[ray], rcz = A.rcz[ray];
     const float *veln = A.veln + (size_t)(A.period[f] - 1) * nnx * nnz;
@@ -144,10 +188,9 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     const int *nstsr = A.nstsr + (size_t)f * RM * RM;
     const dazim_refbox bx = A.boxes[f];
     const int saved = EMIT ? A.nlist[ray] : -1;   // EMIT: reuse the count pass's Frechet cells when they fit
-    __syncthreads();
     if (saved < 0)
-      for (int i = lane; i < (AZIM ? 3 : 1) * nf; i += 64) s_fdm[i] = 0.0f;
-    __syncthreads();
+      for (int i = gl; i < nf * NG; i += GP) gfdm[i] = 0.0f;
+    cbar();
     int status = 0, rb = 0;
     // ---------------- srtimes, inv/CalSurfG.f90:1644-1711 ----------------
     if (!EMIT) {
@@ -180,7 +223,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
               trr = trr + ttn[(size_t)(irx - 2 + k) * nnz + (irz - 2 + l)] * produ;
             }
         }
-        if (lane == 0) A.dsurf[ray] = trr;
+        if (gl == 0) A.dsurf[ray] = trr;
       }
     }
     // ---------------- rpaths, inv/CalSurfG.f90:1818-2236 ----------------
@@ -192,26 +235,35 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     if (ipx < 1 || ipx >= nnx || ipz < 1 || ipz >= nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
     if (!status && saved < 0) {
       float x0 = rcx, z0 = rcz;
+      float sinx0 = dz_sinf(x0);
       int sw = 0;
       float sred = ((scx - x0) * EARTH) * ((scx - x0) * EARTH);
-      float e2 = (scz - z0) * EARTH * dz_sinf(x0);
+      float e2 = (scz - z0) * EARTH * sinx0;
       sred = sqrtf(sred + e2 * e2);
       if (sred < 2.0f * dpl) sw = 1;
       int ipxr = (int)((rcx - goxr) / dnxr) + 1, ipzr = (int)((rcz - gozr) / dnzr) + 1;
       auto in_refined = [&](int px, int pz) -> int {
         if (px < 1 || px >= nnxr || pz < 1 || pz >= nnzr) return 0;
-        const int *s = nstsr + (size_t)(px - 1) * RM + (pz - 1);
-        if (s[0] != 0 || s[1] != 0) return 0;
-        if (s[RM] != 0 || s[RM + 1] != 0) return 0;
+        const int *sp = nstsr + (size_t)(px - 1) * RM + (pz - 1);
+        if (sp[0] != 0 || sp[1] != 0) return 0;
+        if (sp[RM] != 0 || sp[RM + 1] != 0) return 0;
         return 1;
       };
       int igref = in_refined(ipxr, ipzr);
       if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
+      // register-cached 4x4 block of the Frechet grid(s): this lane's cell is (bz+ll, bx+lm)
+      int cbx = -100, cbz = -100;
+      float acc = 0.0f, accc = 0.0f, accs = 0.0f;
+      auto flush = [&]() {
+        if (cbx > -100) {
+          const int fi = (cbx + lm) * ldf + (cbz + ll);
+          gfdm[fi] = acc;
+          if (AZIM) { gfdmc[fi] = accc; gfdms[fi] = accs; }
+        }
+      };
       const long maxrp = (long)nnx * nnz;
-      const int lm = lane & 3, ll = (lane >> 2) & 3;  // this lane's (m,l) of the 4x4 scatter
       for (long j = 1; j <= maxrp; j++) {
         if (sw == 1) break;
-        const float sinx0 = dz_sinf(x0);
         float dtx, dtz;
         if (igref == 1) {
           const float *t = ttnr + (size_t)(ipxr - 1) * RM + (ipzr - 1);
@@ -239,16 +291,19 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
         igref = in_refined(ipxr, ipzr);
         ipx = (int)((x1 - gox) / dnx) + 1;
         ipz = (int)((z1 - goz) / dnz) + 1;
+        float sinx1 = dz_sinf(x1);
         sred = ((scx - x1) * EARTH) * ((scx - x1) * EARTH);
-        e2 = (scz - z1) * EARTH * dz_sinf(x1);
+        e2 = (scz - z1) * EARTH * sinx1;
         sred = sqrtf(sred + e2 * e2);
         sw = 0;
         if (sred < 2.0f * dpl) sw = 1;
         if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
-        if (ipx < 1) { x1 = gox; ipx = 1; rb = 1; }
-        if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; rb = 1; }
+        bool clipx = false;
+        if (ipx < 1) { x1 = gox; ipx = 1; rb = 1; clipx = true; }
+        if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; rb = 1; clipx = true; }
         if (ipz < 1) { z1 = goz; ipz = 1; rb = 1; }
         if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; rb = 1; }
+        if (clipx) sinx1 = dz_sinf(x1);   // the next step starts from the clipped point
         float c2psi = 0.0f, s2psi = 0.0f;
         if (AZIM) step_azimuth(x0, z0, x1, z1, c2psi, s2psi);
         // ---- Frechet weights, :2077-2229 ----
@@ -287,10 +342,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
         float vel = vel_at(g, veln, ipxo, ipzo, drx, drz);
         drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
         drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
-        float bv[4], bw[4];
-        basis(drx / dvx, bv);
-        basis(drz / dvz, bw);
-        float vi = bv[lm], wi = bw[ll];  // this lane's vi(m), wi(l)
+        float vi = basis1(drx / dvx, lm), wi = basis1(drz / dvz, ll);  // this lane's vi(m), wi(l)
         int ivxt = ivxo, ivzt = ivzo;
         for (int k = 1; k <= nhp; k++) {
           const float velo = vel, vio = vi, wio = wi;
@@ -309,88 +361,96 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
           vel = vel_at(g, veln, ipxt, ipzt, drx, drz);
           drx = (rigx - gox) - (float)(ivxt - 1) * dvx;
           drz = (rigz - goz) - (float)(ivzt - 1) * dvz;
-          basis(drx / dvx, bv);
-          basis(drz / dvz, bw);
-          vi = bv[lm];
-          wi = bw[ll];
+          vi = basis1(drx / dvx, lm);
+          wi = basis1(drz / dvz, ll);
           const float dinc = (k == 1) ? vrk * dpl : (vrk - vrp) * dpl;
-          if (lane < 16) {
-            const float rdc1 = vi * wi / (vel * vel);
-            const float rdc2 = vio * wio / (velo * velo);
-            float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
-            const int fi = (ivxt - 2 + (lm + 1)) * ldf + (ivzt - 2 + (ll + 1));
-            s_fdm[fi] = r1 + s_fdm[fi];
-            if (AZIM) {   // inv/rpathsAzim.f90:580-586
-              r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
-              s_fdmc[fi] = r1 + s_fdmc[fi];
-              r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
-              s_fdms[fi] = r1 + s_fdms[fi];
-            }
+          // block of this sub-segment: cells (ivzt-2+l, ivxt-2+m), l,m = 1..4
+          const int nbx = ivxt - 1, nbz = ivzt - 1;
+          if (nbx != cbx || nbz != cbz) {
+            flush();
+            cbar();
+            cbx = nbx;
+            cbz = nbz;
+            const int fi = (cbx + lm) * ldf + (cbz + ll);
+            acc = gfdm[fi];
+            if (AZIM) { accc = gfdmc[fi]; accs = gfdms[fi]; }
+          }
+          const float rdc1 = vi * wi / (vel * vel);
+          const float rdc2 = vio * wio / (velo * velo);
+          float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
+          acc = r1 + acc;
+          if (AZIM) {   // inv/rpathsAzim.f90:580-586
+            r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
+            accc = r1 + accc;
+            r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
+            accs = r1 + accs;
           }
         }
         x0 = x1;
         z0 = z1;
+        sinx0 = sinx1;
       }
+      flush();
     }
-    __syncthreads();
-    if (!EMIT && lane == 0) {
+    cbar();
+    if (!EMIT && gl == 0) {
       A.status[ray] = status;
       A.rbflag[ray] = rb;
     }
     // ---------------- G row, inv/CalSurfG.f90:1339-1364 ----------------
-    // cells with |fdm| >= ftol in (jj,kk) order -> LDS list
+    // cells with |fdm| >= ftol in (jj,kk) order -> this group's LDS list
     int nlist = 0;
     if (saved >= 0) {
       nlist = saved;
-      const size_t o = (size_t)ray * A.LK, ov = o * (AZIM ? 3 : 1);
-      for (int i = lane; i < nlist; i += 64) {
+      const size_t o = (size_t)ray * A.LK, ov = o * NG;
+      for (int i = gl; i < nlist; i += GP) {
         const int c = A.lcell[o + i];
         const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
         s_list[i] = (unsigned short)c;
-        s_fdm[kk * ldf + jj] = A.lval[ov + i];
+        gfdm[kk * ldf + jj] = A.lval[ov + i];
         if (AZIM) {
-          s_fdmc[kk * ldf + jj] = A.lval[ov + A.LK + i];
-          s_fdms[kk * ldf + jj] = A.lval[ov + 2 * A.LK + i];
+          gfdmc[kk * ldf + jj] = A.lval[ov + A.LK + i];
+          gfdms[kk * ldf + jj] = A.lval[ov + 2 * A.LK + i];
         }
       }
     } else if (!status) {
-      for (int base = 0; base < nvz * nvx; base += 64) {
-        const int c = base + lane;
+      for (int base = 0; base < nvz * nvx; base += GP) {
+        const int c = base + gl;
         bool keep = false;
         if (c < nvz * nvx) {
           const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
-          keep = fabsf(s_fdm[kk * ldf + jj]) >= FTOL;
+          keep = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
         }
-        const unsigned long long m = __ballot(keep);
-        if (keep) s_list[nlist + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)c;
-        nlist += __popcll(m);
+        const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
+        if (keep) s_list[nlist + __popc(m & ((1u << gl) - 1u))] = (unsigned short)c;
+        nlist += __popc(m);
       }
     }
-    __syncthreads();
+    cbar();
     if (!EMIT) {   // hand the Frechet cells to the emit pass so that it need not trace the ray again
-      const size_t o = (size_t)ray * A.LK, ov = o * (AZIM ? 3 : 1);
+      const size_t o = (size_t)ray * A.LK, ov = o * NG;
       if (nlist <= A.LK)
-        for (int i = lane; i < nlist; i += 64) {
+        for (int i = gl; i < nlist; i += GP) {
           const int c = s_list[i];
           const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
           A.lcell[o + i] = (unsigned short)c;
-          A.lval[ov + i] = s_fdm[kk * ldf + jj];
+          A.lval[ov + i] = gfdm[kk * ldf + jj];
           if (AZIM) {
-            A.lval[ov + A.LK + i] = s_fdmc[kk * ldf + jj];
-            A.lval[ov + 2 * A.LK + i] = s_fdms[kk * ldf + jj];
+            A.lval[ov + A.LK + i] = gfdmc[kk * ldf + jj];
+            A.lval[ov + 2 * A.LK + i] = gfdms[kk * ldf + jj];
           }
         }
-      if (lane == 0) A.nlist[ray] = (status || nlist <= A.LK) ? (status ? 0 : nlist) : -1;
+      if (gl == 0) A.nlist[ray] = (status || nlist <= A.LK) ? (status ? 0 : nlist) : -1;
     }
     const size_t ncol = (size_t)A.nx * A.ny;
     const int kslot = A.kidx[f] - 1;
     long cnt = 0;
     const long rstart = EMIT ? A.rowptr[ray] : 0;
     const int nparpi = nvx * nvz * (A.nz - 1);
-    for (int blk = 0; blk < (AZIM ? 3 : 1); blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
+    for (int blk = 0; blk < NG; blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
       for (int k = 1; k <= A.nz - 1; k++) {
-        for (int base = 0; base < nlist; base += 64) {
-          const int li = base + lane;
+        for (int base = 0; base < nlist; base += GP) {
+          const int li = base + gl;
           bool keep = false;
           float rowv = 0.0f;
           int nn = 0;
@@ -399,7 +459,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
             const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
             const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
             if (blk == 0) {
-              const float fd = s_fdm[kk * ldf + jj];
+              const float fd = gfdm[kk * ldf + jj];
               const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
               const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
               const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
@@ -408,21 +468,21 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
               const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
               rowv = (float)r;
             } else {
-              rowv = A.lsen[si] * (blk == 1 ? s_fdmc : s_fdms)[kk * ldf + jj];
+              rowv = A.lsen[si] * (blk == 1 ? gfdmc : gfdms)[kk * ldf + jj];
             }
             keep = fabsf(rowv) > FTOL;
             nn = blk * nparpi + (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
           }
-          const unsigned long long m = __ballot(keep);
+          const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
           if (EMIT && keep) {
-            const long pos = rstart + cnt + __popcll(m & ((1ull << lane) - 1ull));
+            const long pos = rstart + cnt + __popc(m & ((1u << gl) - 1u));
             A.val[pos] = rowv;
             A.col[pos] = nn - 1;
           }
-          cnt += __popcll(m);
+          cnt += __popc(m);
         }
       }
-    if (!EMIT && lane == 0) A.count[ray] = cnt;
+    if (!EMIT && gl == 0) A.count[ray] = cnt;
   }
 }
 
@@ -510,17 +570,20 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
   A.col = nullptr;
-  const size_t lds = (size_t)(g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1) + (size_t)g.nvx * g.nvz * 2 + 16;
+  const size_t lds = (size_t)g.nvx * g.nvz * 2 * 4 + 16;   // four cell lists (one per ray of the wavefront)
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)(160 * 1024 / (lds + 256));
-  if (per_cu > 32) per_cu = 32;
-  if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS Frechet grid");
+  if (per_cu > 16) per_cu = 16;
+  if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS cell lists");
   long nwg = (long)ctx->num_cu * per_cu;
-  if (nwg > nray) nwg = nray;
+  if (nwg > (nray + 3) / 4) nwg = (nray + 3) / 4;
   if (nwg >= 8) nwg -= nwg % 8;   // the XCD-aware ray order wants a multiple of 8
+  if (nwg < 1) nwg = 1;
+  if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * 4 * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
+  A.fdm_scratch = (float *)p;
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
