@@ -20,7 +20,7 @@ namespace {
 constexpr int NL = 200;       // inv/surfdisp96.f:57
 constexpr int NP = 60;        // inv/surfdisp96.f:59
 constexpr int NZMAX = 64;     // knots per column we accept
-constexpr int DT = 128;       // threads per workgroup
+constexpr int DT = 256;       // threads per workgroup
 constexpr int NEVN = 11;      // Neville points kept (x(1..11), inv/surfdisp96.f:569,655)
 
 struct Layer {   // per refined layer, geometry only
