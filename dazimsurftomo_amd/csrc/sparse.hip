@@ -240,6 +240,10 @@ __global__ void k_scale_rows(int64_t nrows, const int64_t *ptr, float *val, cons
     for (int64_t i = ptr[r] + lane; i < ptr[r + 1]; i += 64) val[i] *= a;
   }
 }
+// out[col[i]] += |val[i]|: the reference's DWS, norm(col(i))=norm(col(i))+abs(rw(i)), inv/Main_Jt.f90:477-481
+__global__ void k_col_abs_sums(int64_t n, const int *col, const float *val, float *out) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) atomicAdd(&out[col[i]], fabsf(val[i]));
+}
 __global__ void k_gather_f(int64_t n, const unsigned *perm, const float *src, float *dst) {
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]];
 }
@@ -717,6 +721,19 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return build_colblocks(ctx, A);
+}
+
+int dazim_csr_col_abs_sums(dazim_ctx *ctx, const dazim_csr *A, float *out_u) {
+  if (!ctx || !A || !out_u) return DAZIM_E_BAD_ARG;
+  DzBuf<float> out;
+  int rc;
+  if ((rc = out.init(ctx, out_u, A->n, false, true))) return rc;
+  DZ_HIP(hipMemsetAsync(out.dev, 0, (size_t)A->n * 4, ctx->stream));
+  if (A->nnz) hipLaunchKernelGGL(k_col_abs_sums, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->col, A->val, out.dev);
+  DZ_HIP(hipGetLastError());
+  if ((rc = out.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 // aprod, inv/aprod.f90:7

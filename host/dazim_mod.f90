@@ -20,6 +20,9 @@ module dazim_mod
   implicit none
   private
   public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle
+  ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
+  public :: dazim_assemble_G, dazim_check, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
+            dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
 
@@ -109,6 +112,19 @@ module dazim_mod
     integer(c_int) function dazim_csr_free(ctx, A) bind(C, name="dazim_csr_free")
       import; type(c_ptr), value :: ctx, A
     end function
+    integer(c_int) function dazim_csr_scale_rows(ctx, A, w) bind(C, name="dazim_csr_scale_rows")
+      import; type(c_ptr), value :: ctx, A; real(c_float) :: w(*)
+    end function
+    integer(c_int) function dazim_csr_col_abs_sums(ctx, A, out) bind(C, name="dazim_csr_col_abs_sums")
+      import; type(c_ptr), value :: ctx, A; real(c_float) :: out(*)
+    end function
+    integer(c_int) function dazim_csr_append_coo(ctx, A, extra_m, nnz, irow, icol, rw) bind(C, name="dazim_csr_append_coo")
+      import
+      type(c_ptr), value :: ctx, A
+      integer(c_int64_t), value :: extra_m, nnz
+      integer(c_int) :: irow(*), icol(*)
+      real(c_float) :: rw(*)
+    end function
     integer(c_int) function dazim_aprod(ctx, mode, A, x, y) bind(C, name="dazim_aprod")
       import
       type(c_ptr), value :: ctx, A
@@ -138,6 +154,12 @@ contains
   subroutine dazim_finalize()
     if (c_associated(dazim_handle)) call dazim_destroy(dazim_handle)
     dazim_handle = c_null_ptr
+  end subroutine
+
+  subroutine dazim_check(rc, what)
+    integer(c_int), intent(in) :: rc
+    character(len=*), intent(in) :: what
+    call check(rc, what)
   end subroutine
 
   subroutine check(rc, what)
@@ -213,18 +235,44 @@ contains
     integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     real*8, optional :: pvout(nx*ny, kmaxRc)
-    real*8, allocatable :: pv(:, :), svs(:, :, :), svp(:, :, :), srho(:, :, :)
+    real*8, allocatable :: pv(:, :)
+    integer, allocatable :: irow(:)
+    type(c_ptr) :: G
+    allocate (pv(nx*ny, kmaxRc))
+    call dazim_assemble_G(joint, nx, ny, nz, vels, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, minthk, &
+                          scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nar, pv)
+    if (present(pvout)) pvout = pv
+    allocate (irow(max(nar, 1)))
+    call check(dazim_csr_to_coo(dazim_handle, G, irow, col, rw), 'CalSurfG/coo')
+    iw(2:nar + 1) = irow(1:nar)             ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
+    call check(dazim_csr_free(dazim_handle, G), 'free')
+  end subroutine
+
+  ! The whole of CalSurfG (inv/CalSurfG.f90:909) / the GPU part of CalSurfGAnisoJoint on the device; G stays in HBM
+  ! (handle returned), dsurf(dall) and pv(nx*ny,kmaxRc) come back to the host.
+  subroutine dazim_assemble_G(joint, nx, ny, nz, vels, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, &
+                              minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nar, pv)
+    logical :: joint
+    integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
+    real :: vels(nx, ny, nz), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
+    real*8 :: tRc(*)
+    integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
+    real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
+    type(c_ptr) :: G
+    real*8 :: pv(nx*ny, kmaxRc)
+    real*8, allocatable :: svs(:, :, :), svp(:, :, :), srho(:, :, :)
     real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
-    integer, allocatable :: per(:), kidx(:), fray(:), irow(:)
-    type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box, G
+    integer, allocatable :: per(:), kidx(:), fray(:)
+    type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box
     integer :: nfield, nray, k, s, r, f, nnx, nnz
     integer(c_int) :: nfail, nb
     integer(c_int64_t) :: nnz64
     integer(c_size_t) :: nn
     call dazim_init(0)
-    allocate (pv(nx*ny, kmaxRc), svs(nx*ny, kmaxRc, nz), svp(nx*ny, kmaxRc, nz), srho(nx*ny, kmaxRc, nz))
+    allocate (svs(nx*ny, kmaxRc, nz), svp(nx*ny, kmaxRc, nz), srho(nx*ny, kmaxRc, nz))
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, svs, svp, srho, nfail), &
                'CalSurfG/depthkernel')
+    if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
     ! flatten the (period, source, receiver) loops in the reference's order (:1114-1326)
     nfield = sum(nsrcsurf1(1:kmax)); nray = 0
     do k = 1, kmax
@@ -261,13 +309,8 @@ contains
                                     per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
                                     svs, svp, srho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
     end if
-    if (present(pvout)) pvout = pv
     nar = int(nnz64)
-    allocate (irow(max(nar, 1)))
-    call check(dazim_csr_to_coo(dazim_handle, G, irow, col, rw), 'CalSurfG/coo')
-    iw(2:nar + 1) = irow(1:nar)             ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
     if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
-    call check(dazim_csr_free(dazim_handle, G), 'free')
     call check(dazim_free(dazim_handle, d_veln), 'free'); call check(dazim_free(dazim_handle, d_ttn), 'free')
     call check(dazim_free(dazim_handle, d_ttnr), 'free'); call check(dazim_free(dazim_handle, d_nstsr), 'free')
     call check(dazim_free(dazim_handle, d_box), 'free')

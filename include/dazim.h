@@ -127,6 +127,9 @@ int dazim_csr_dims(const dazim_csr *A, int64_t *m, int64_t *n, int64_t *nnz);
 /* multiply every stored entry of row i by w[i] (rw(i)=rw(i)*datweight(iw(1+i)), inv/Main_Jt.f90:467) */
 int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w);
 
+/* out[n] = column sums of |A|: the reference's DWS (norm(col(i))+=abs(rw(i)), inv/Main_Jt.f90:477-481) */
+int dazim_csr_col_abs_sums(dazim_ctx *ctx, const dazim_csr *A, float *out);
+
 /* device arrays in, ownership taken: rowptr[m+1] int64, col[nnz] 0-based int32, val[nnz] fp32   */
 int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
                     float *val, dazim_csr **A);

@@ -314,6 +314,12 @@ class Ref:
         return x, dict(istop=istop.value, itn=itn.value, normA=sc[0].value, condA=sc[1].value,
                        normr=sc[2].value, normAr=sc[3].value, normx=sc[4].value)
 
+    def ddatsigma(self, obst, cbst):
+        obst = np.ascontiguousarray(obst, f32); cbst = np.ascontiguousarray(cbst, f32)
+        sig = np.zeros(len(obst), f32); mean = C.c_float(0)
+        self.lib.ref_ddatsigma(len(obst), pf(obst), pf(cbst), pf(sig), C.byref(mean))
+        return sig, mean.value
+
     def tikhonov_iso(self, nx, ny, nz, dall, weight, rw, irow, icol):
         nvp = (nx - 2) * (ny - 2) * (nz - 1)
         cap = len(rw) + 7 * nvp

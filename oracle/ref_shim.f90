@@ -270,6 +270,15 @@ contains
     deallocate (iw)
   end subroutine
 
+  ! ---- data sigma (inv/CalSigamNorm.f90:2) ---------------------------------------------------------
+  subroutine ref_ddatsigma(dall, obst, cbst, sigmaT, meandeltaT) bind(C, name="ref_ddatsigma")
+    integer(c_int), value :: dall
+    real(c_float), intent(in) :: obst(dall), cbst(dall)
+    real(c_float), intent(out) :: sigmaT(dall), meandeltaT
+    external CalDdatSigma
+    call CalDdatSigma(dall, obst, cbst, sigmaT, meandeltaT)
+  end subroutine
+
   ! ---- Tikhonov rows (inv/TikhRegul.f90:2) --------------------------------------------------------
   subroutine ref_tikhonov(nx, ny, nz, maxvp, dall, nar, maxnar, rw, irow, icol, count3, lame) &
        bind(C, name="ref_tikhonov")
