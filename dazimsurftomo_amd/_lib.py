@@ -30,7 +30,7 @@ def build(force=False):
             return LIB_PATH
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("DAZIM_HIPCC_EXTRA", "").split() + ["-o", LIB_PATH] + srcs
     if any(open(s).read().find("rccl.h") >= 0 for s in srcs):
         cmd += ["-lrccl"]
     subprocess.check_call(cmd)

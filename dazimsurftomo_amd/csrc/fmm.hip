@@ -110,6 +110,14 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // same-wave LDS/VMEM operations execute in program order, so no s_waitcnt is needed for lane 0's
 // stores to be seen by the group's later loads.
 
+// Cross-lane moves inside a 16-lane group as DPP modifiers on a v_mov (no LDS crossbar round trip):
+// quad_perm swaps for the xor-1 / xor-2 exchanges and row_newbcast (gfx90a+) to broadcast lane L of each row.
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+constexpr int DPP_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
+
 // LDS layout is structure-of-arrays: fp32 keys + node ids.  NT = unsigned short packs the node as
 // (ix-1)<<8 | (iz-1), possible when both grid sides are <= 256 (the S-256 case: 6 bytes per entry,
 // a third more fields in flight per CU); NT = int keeps (ix<<16)|iz for larger grids.
@@ -265,6 +273,90 @@ struct Heap {
       if (mv.node == nbn[n]) nbm[n] = p;
     nmoves++;
   }
+
+  // downtree for the all-in-LDS heap, three levels per step.  Which child a hole descends to does not depend
+  // on the moving entry (always the smaller child, ties to the left, :857-866), only the stopping depth does,
+  // so 14 lanes of the group read the 2+4+8 descendants of the hole at once, the sibling comparisons and the
+  // comparisons with the moving key are exchanged with two ballots, and every lane that sits on the chosen
+  // path copies its entry into its parent slot.  Same comparisons, same final array as the sequential loop.
+  // A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child tail.
+  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
+  // a moved pending neighbour n leaves its new slot in nbq[n] (LDS, zeroed by the caller).
+  static constexpr int NSTEP = 4;   // 3 levels each: reaches slot 4095
+  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int *nbq, int (&cnode)[NSTEP],
+                                               int (&cslot)[NSTEP], int &fin_node, int &fin_slot) {
+    static_assert(CAP <= 4096, "pop_root_par covers 12 levels");
+    const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
+#pragma unroll
+    for (int b = 0; b < NSTEP; b++) cslot[b] = 0;
+    fin_slot = 0;
+    fin_node = 0;
+    if (ntr == 1) {
+      ntr = 0;
+      return;
+    }
+    const float mvk = keys[ntr];
+    const NT mvc = nodes[ntr];
+    ntr--;
+    const int r = gl + 2;                                 // position in the 3-level subtree: 2..15 (lanes 14,15 idle)
+    const int d = r >= 8 ? 3 : (r >= 4 ? 2 : 1);
+    const int o = r - (1 << d);
+    // lane constants: this lane's entry moves up iff every sibling comparison on the way down from the hole
+    // chose its ancestor line ((gt & G) == E: bit 2a-2 of gt says "children of subtree position a: go right")
+    // and it and its ancestors are all smaller than the moving key ((lt & A) == A: bit r-2 per position r)
+    unsigned G = 1u << (2 * (r >> 1) - 2), E = (unsigned)(r & 1) << (2 * (r >> 1) - 2), A = 1u << (r - 2);
+    if (d >= 2) {
+      G |= 1u << (2 * (r >> 2) - 2);
+      E |= (unsigned)((r >> 1) & 1) << (2 * (r >> 2) - 2);
+      A |= 1u << ((r >> 1) - 2);
+    }
+    if (d == 3) {
+      G |= 1u;
+      E |= (unsigned)((r >> 2) & 1);
+      A |= 1u << ((r >> 2) - 2);
+    }
+    if (gl >= 14) A = 0x10000u;                           // idle lanes never match
+    int p = 1;
+    bool active = true;
+#pragma unroll
+    for (int b = 0; b < NSTEP; b++) {
+      if (b > 0 && __ballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
+      // straight-line code: lanes with nothing to read use slot 0 (never a heap entry), lanes with nothing
+      // to move write their entry to slot 0 and their "neighbour slot" to the spare nbq[4]
+      const int slot = (p << d) + o;
+      const bool valid = active && slot <= ntr;
+      const int rs = valid ? slot : 0;
+      const float kr = keys[rs];
+      const NT c = nodes[rs];
+      const float k = valid ? kr : INFINITY;
+      const float ksib = dpp_f<DPP_XOR1>(k);              // right sibling's key on even lanes
+      const unsigned long long gtm = __ballot(k > ksib);  // even lanes: left child strictly greater -> go right
+      const unsigned long long ltm = __ballot(k < mvk);
+      const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & 0xffffu;
+      const bool mine = active && (gt & G) == E && (lt & A) == A;
+      const int dst = mine ? slot >> 1 : 0;
+      keys[dst] = k;
+      nodes[dst] = c;
+      const int nd = NodeCodec<NT>::dec(c);
+      cnode[b] = nd;
+      cslot[b] = dst;
+      const int which = nd == nbn[0] ? 0 : (nd == nbn[1] ? 1 : (nd == nbn[2] ? 2 : (nd == nbn[3] ? 3 : 4)));
+      nbq[mine ? which : 4] = dst;
+      const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
+      if (mb != 0) {
+        const int rt = 33 - __clz(mb);                    // deepest entry that moved: the hole is there now
+        const int dt = 31 - __clz(rt);
+        p = (p << dt) + rt - (1 << dt);
+        active = dt == 3 && 2 * p <= ntr;
+      } else {
+        active = false;
+      }
+    }
+    keys[p] = mvk;
+    nodes[p] = mvc;
+    fin_node = NodeCodec<NT>::dec(mvc);
+    fin_slot = p;
+  }
 };
 
 // fouds2 for one quadrant: inv/CalSurfG.f90:586-723.  (tj,sj) = neighbour along x, (tj2,sj2) the
@@ -342,13 +434,26 @@ __device__ __forceinline__ float quadrant_time(float vel, float risti, float dnx
   return (tref + tdsh) / tdiv;
 }
 
+#ifdef DZ_FMM_PROF   // experiment-only build: per-phase shader-clock totals of the marching loop
+__device__ unsigned long long g_fmm_prof[8];
+#define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pa_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
+#define PROF_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PROF_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_fmm_prof[i_], pa_[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_WAIT
+#define PROF_FLUSH
+#endif
+
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
 template <int CAP, bool SPILL, class NT, bool REFINED>
 __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ veln,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
-                                      int ex, int lane) {
+                                      int ex, int lane, int *nbq) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
   const int nb = gl >> 2, q = gl & 3;
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
@@ -357,8 +462,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
   Node *rec = H.rec;
   const int ld = H.ld;
   bool overflow = false;
+  PROF_DECL;
   while (H.ntr > 0 && !overflow) {
     cbar();
+    PROF(7);
     const HEnt root = H.get(1);
     const int ix = root.node >> 16, iz = root.node & 0xffff;
     if (REFINED) {
@@ -399,49 +506,120 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       nbm[n] = 0;
     }
     int mynode = 0, myslot = 0, nmoves = 0;
-    H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
+    int cnode[Heap<CAP, SPILL, NT>::NSTEP], cslot[Heap<CAP, SPILL, NT>::NSTEP], fin_node = 0, fin_slot = 0;
+    PROF(0);
+    if (SPILL) {
+      H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
+    } else {
+      if (gl < 4) nbq[gl] = 0;
+      cbar();
+      H.pop_root_par(lane, nbn, nbq, cnode, cslot, fin_node, fin_slot);
+      cbar();
+    }
+    PROF(1);
+    PROF_WAIT;
+    PROF(2);
     // keep the compiler from sinking the loads behind a test of the first one and from hoisting
     // the deferred stores above this point: all results are "used" here, together
     asm volatile("" ::"v"(nself.t), "v"(nself.s), "v"(nj.t), "v"(nj.s), "v"(nj2.t), "v"(nj2.s), "v"(nk.t), "v"(nk.s),
                  "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
                  : "memory");
-    if (gl < nmoves) rec[H.idx(mynode)].s = myslot;   // deferred back-pointers of the sift-down
+    if (SPILL) {
+      if (gl < nmoves) rec[H.idx(mynode)].s = myslot;   // deferred back-pointers of the sift-down
+    } else {
+#pragma unroll
+      for (int b = 0; b < Heap<CAP, SPILL, NT>::NSTEP; b++)
+        if (cslot[b] > 0) rec[H.idx(cnode[b])].s = cslot[b];
+      if (H.g0 && fin_slot > 0) rec[H.idx(fin_node)].s = fin_slot;
+    }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
     if (!vj2) nj2.s = -1;
     if (!vk) nk.s = -1;
     if (!vk2) nk2.s = -1;
     float trav = INFINITY;
+    PROF(3);
     if (vj && vk && nself.s != 0) trav = quadrant_time(vel, risti, dnx, dnz, nj, nj2, nk, nk2, vj2, vk2);
-    trav = fminf(trav, __shfl_xor(trav, 1));
-    trav = fminf(trav, __shfl_xor(trav, 2));
+    trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
+    trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
+    PROF(4);
     // ---- the (up to) four heap updates in the reference's order (x-1, x+1, z-1, z+1) ----
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-      const int ux = nbn[n] >> 16, uz = nbn[n] & 0xffff;
-      const bool ok = ux >= 1 && ux <= nnx && uz >= 1 && uz <= nnz;
-      int st = ok ? __shfl(nself.s, gbase + 4 * n) : 0;   // status: -1 far, 0 alive, >0 heap slot
-      if (st > 0 && nbm[n] > 0) st = nbm[n];               // its entry moved during the sift-down
-      nbs[n] = st;
-      nbt[n] = __shfl(trav, gbase + 4 * n);
-    }
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-      if (nbs[n] == 0) continue;
-      const int node = nbn[n];
-      if (H.g0) rec[H.idx(node)].t = nbt[n];
-      if (nbs[n] < 0) {
-        if (H.full()) {
-          overflow = true;
-          break;
-        }
-        H.ntr++;
-        H.template sift_up<true>(H.ntr, nbt[n], node, nbn, nbs, n);
-      } else {
-        H.template sift_up<true>(nbs[n], nbt[n], node, nbn, nbs, n);
+    // Lane (nb, q=0) "owns" neighbour nb: it holds that node's status (nself.s) and new time (trav).
+    bool fast = false;
+    int n0 = 0;                                            // first neighbour handled by the sequential code
+    int stfix = nself.s;                                   // -1 far, 0 alive / outside, >0 heap slot
+    if (!SPILL) {
+      // all-in-LDS heap.  Usual case: none of the four entries has to rise above its parent (the new times
+      // lie at the far side of the band), so the four addtree/updtree calls reduce to independent writes,
+      // done by the owner lanes.  A parent that is itself an earlier neighbour (m < nb) is compared with
+      // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
+      const bool owner = q == 0;
+      int mvd = nbq[nb];                                   // new slot if the sift-down moved this neighbour
+      const int mynode = (nix << 16) | niz;
+      if (fin_slot > 0 && fin_node == mynode) mvd = fin_slot;
+      if (stfix > 0 && mvd > 0) stfix = mvd;
+      const bool act = stfix != 0, isnew = stfix < 0;
+      const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
+      const int cnt = __popc(newb);
+      const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
+      const bool room = H.ntr + cnt < CAP;
+      const int pc = c >> 1;
+      float pk = H.keys[(act && room) ? pc : 0];
+      const int cact = act ? c : 0;
+      const int c0 = dpp_i<DPP_BCAST0 + 0>(cact), c1 = dpp_i<DPP_BCAST0 + 4>(cact), c2 = dpp_i<DPP_BCAST0 + 8>(cact);
+      const float t0 = dpp_f<DPP_BCAST0 + 0>(trav), t1 = dpp_f<DPP_BCAST0 + 4>(trav), t2 = dpp_f<DPP_BCAST0 + 8>(trav);
+      if (nb > 0 && pc == c0) pk = t0;
+      if (nb > 1 && pc == c1) pk = t1;
+      if (nb > 2 && pc == c2) pk = t2;
+      const bool rise = owner && act && c > 1 && trav < pk;
+      const unsigned riseb = (unsigned)(__ballot(rise) >> gbase) & 0xffffu;
+      // neighbours before the first rising one (n < n0) are written directly; from n0 on, sequentially
+      n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) >> 2) : 4);
+      fast = n0 == 4;
+      {
+        const bool wr = owner && act && nb < n0;
+        const int dst = wr ? c : 0;                        // slot 0 is never a heap entry
+        H.keys[dst] = trav;
+        H.nodes[dst] = NodeCodec<NT>::enc(mynode);
+        if (wr) rec[H.idx(mynode)] = Node{trav, c};
+        H.ntr += __popc(newb & ((1u << (4 * n0)) - 1u));
       }
     }
+#ifdef DZ_FMM_PROF
+    PROF(5);
+    if (__ballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
+    pa_[7] += 1000000;                        // iterations (x1e6) on top of the loop-top ticks
+#endif
+    if (!fast) {
+      nbs[0] = dpp_i<DPP_BCAST0 + 0>(stfix); nbs[1] = dpp_i<DPP_BCAST0 + 4>(stfix);
+      nbs[2] = dpp_i<DPP_BCAST0 + 8>(stfix); nbs[3] = dpp_i<DPP_BCAST0 + 12>(stfix);
+      nbt[0] = dpp_f<DPP_BCAST0 + 0>(trav); nbt[1] = dpp_f<DPP_BCAST0 + 4>(trav);
+      nbt[2] = dpp_f<DPP_BCAST0 + 8>(trav); nbt[3] = dpp_f<DPP_BCAST0 + 12>(trav);
+      if (SPILL) {
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+          if (nbs[n] > 0 && nbm[n] > 0) nbs[n] = nbm[n];   // its entry moved during the sift-down
+      }
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        if (nbs[n] == 0 || n < n0) continue;
+        const int node = nbn[n];
+        if (H.g0) rec[H.idx(node)].t = nbt[n];
+        int c = nbs[n];
+        if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
+          if (H.full()) {
+            overflow = true;
+            break;
+          }
+          H.ntr++;
+          c = H.ntr;
+        }
+        H.template sift_up<true>(c, nbt[n], node, nbn, nbs, n);
+      }
+    }
+    PROF(6);
   }
+  PROF_FLUSH;
   return overflow;
 }
 
@@ -449,6 +627,7 @@ template <int CAP, bool SPILL, class NT>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
+  __shared__ __attribute__((aligned(16))) int s_nbq[FPW][8];   // [4..7]: write-only spare  // new slots of pending neighbours moved by a sift-down
   __shared__ unsigned s_base;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
@@ -575,7 +754,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        bool ovf = march<CAP, SPILL, NT, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, s_nbq[grp]);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -647,7 +826,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, s_nbq[grp]);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -714,6 +893,16 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
+#ifdef DZ_FMM_PROF
+  {
+    unsigned long long h[8];
+    DZ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fmm_prof), sizeof h));
+    fprintf(stderr, "fmm prof (memtime ticks): setup+loads %llu popdown %llu loadwait %llu fix %llu quadrant %llu siftups-fast %llu siftups-slow %llu - looptop %llu\n",
+            h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    unsigned long long z[8] = {0};
+    DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fmm_prof), z, sizeof z));
+  }
+#endif
   return 0;
 }
 

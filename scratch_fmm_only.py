@@ -2,7 +2,8 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import dazimsurftomo_amd as dz
 from tests import synth
-nx = ny = 54; kmax = 16; nsrc = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+import os
+nx = ny = int(os.environ.get('NX','54')); kmax = 16; nsrc = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pv = synth.phase_velocity_maps(nx, ny, kmax)
 lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc)
@@ -13,10 +14,10 @@ dev = torch.device("cuda:0")
 ctx = dz.Context(0)
 t = lambda a: torch.from_numpy(a).to(dev)
 d_pv, d_scx, d_scz, d_per = t(pv), t(scx), t(scz), t(per)
-d_ttn = torch.empty((nf, 256, 256), dtype=torch.float32, device=dev)
+d_ttn = torch.empty((nf, (nx-3)*5+1, (ny-3)*5+1), dtype=torch.float32, device=dev)
 d_ttnr = torch.empty((nf, 129, 129), dtype=torch.float32, device=dev)
 d_nstsr = torch.empty((nf, 129, 129), dtype=torch.int32, device=dev)
-d_veln = torch.empty((kmax, 256, 256), dtype=torch.float32, device=dev)
+d_veln = torch.empty((kmax, (nx-3)*5+1, (ny-3)*5+1), dtype=torch.float32, device=dev)
 d_box = torch.empty((nf, 12), dtype=torch.int32, device=dev)
 d_st = torch.empty((nf,), dtype=torch.int32, device=dev)
 import os
