@@ -372,7 +372,7 @@ int orc_refine_layers(float minthk0, int mmax, const float *dep, const float *vp
   return k + 1;
 }
 
-static void brocher(float vs, float *vp, float *rho) { /* inv/CalSurfG.f90:49-53 */
+void orc_brocher(float vs, float *vp, float *rho) { /* inv/CalSurfG.f90:49-53 */
   float v2 = vs * vs, v3 = v2 * vs, v4 = v3 * vs;
   float p = 0.9409f + 2.0947f * vs - 0.8206f * v2 + 0.2683f * v3 - 0.0251f * v4;
   float p2 = p * p, p3 = p2 * p, p4 = p3 * p, p5 = p4 * p;
@@ -401,7 +401,7 @@ int orc_depthkernel(int nx, int ny, int nz, const float *vel, int kmax, const do
       double cg0[ORC_NP], cg1[ORC_NP], cg2[ORC_NP];
       for (int k = 0; k < nz; k++) {
         vsz[k] = vel[((size_t)k * ny + jj) * nx + ii];
-        brocher(vsz[k], &vpz[k], &rhoz[k]);
+        orc_brocher(vsz[k], &vpz[k], &rhoz[k]);
         vsm[k] = vsz[k];
         vpm[k] = vpz[k];
         rhom[k] = rhoz[k];

@@ -40,6 +40,19 @@ int orc_depthkernel(int nx, int ny, int nz, const float *vel, int kmax, const do
                     const float *depz, float minthk, double *pv, double *svs, double *svp,
                     double *srho);
 
+/* inv/CalSurfG.f90:49-53 (Brocher Vp(Vs), rho(Vp), fp32) */
+void orc_brocher(float vs, float *vp, float *rho);
+
+/* ---- TI eigenfunction kernels (tregn.c) ------------------------------------------------------ */
+/* inv/tregn96.f:52 as depthkernelTI calls it (Rayleigh, mode 1, iflsph=1, dogam, hs=hr=0, solid layers):
+ * d,TA,TC,TF,TL,TN,rho fp32[nl]; t,cp fp32[nt]; outputs fp32 [nt][nl].  returns 0 / 3 (fluid layer) */
+int orc_tregn96(int nl, const float *d, const float *TA, const float *TC, const float *TF, const float *TL,
+                const float *TN, const float *rho, int nt, const float *t, const float *cp, float *dcdah,
+                float *dcdbv, float *dcdn);
+/* inv/depthkernelTI.f90:2 ; pv[kmax][nx*ny] (nullable), lsen[nz-1][kmax][nx*ny] fp32 (= Lsen_Gsc) */
+int orc_depthkernel_ti(int nx, int ny, int nz, const float *vel, int kmax, const double *t,
+                       const float *depz, float minthk, double *pv, float *lsen);
+
 /* ---- eikonal (fmm.c) ----------------------------------------------------------------------- */
 typedef struct {
   int nvx, nvz;             /* B-spline vertices (nx-2, ny-2)              */

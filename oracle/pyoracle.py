@@ -90,6 +90,18 @@ class Oracle:
         return pv, s
 
     # ---- eikonal ----
+    def depthkernel_ti(self, vel, depz, t, minthk):
+        vel = np.ascontiguousarray(vel, f32)
+        nz, ny, nx = vel.shape
+        t = np.ascontiguousarray(t, f64)
+        pv = np.zeros((len(t), ny * nx), f64)
+        lsen = np.zeros((nz - 1, len(t), ny * nx), f32)
+        rc = self.lib.orc_depthkernel_ti(nx, ny, nz, pf(vel), len(t), pd(t), pf(np.ascontiguousarray(depz, f32)),
+                                         C.c_float(minthk), pd(pv), pf(lsen))
+        if rc:
+            raise RuntimeError(f"orc_depthkernel_ti rc={rc}")
+        return pv, lsen
+
     def geometry(self, nx, ny, goxd, gozd, dvxd, dvzd):
         g = Geom()
         self.lib.orc_geometry(nx, ny, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd), C.c_float(dvzd), C.byref(g))
@@ -313,6 +325,16 @@ class Ref:
                           C.byref(itn), *[C.byref(s) for s in sc])
         return x, dict(istop=istop.value, itn=itn.value, normA=sc[0].value, condA=sc[1].value,
                        normr=sc[2].value, normAr=sc[3].value, normx=sc[4].value)
+
+    def depthkernel_ti(self, vel, depz, t, minthk):
+        vel = np.ascontiguousarray(vel, f32)
+        nz, ny, nx = vel.shape
+        t = np.ascontiguousarray(t, f64)
+        pv = np.zeros((len(t), ny * nx), f64)
+        lsen = np.zeros((nz - 1, len(t), ny * nx), f32)
+        self.lib.ref_depthkernelti(nx, ny, nz, pf(vel), len(t), pd(t), pf(np.ascontiguousarray(depz, f32)),
+                                   C.c_float(minthk), pd(pv), pf(lsen))
+        return pv, lsen
 
     def ddatsigma(self, obst, cbst):
         obst = np.ascontiguousarray(obst, f32); cbst = np.ascontiguousarray(cbst, f32)

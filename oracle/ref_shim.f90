@@ -270,6 +270,18 @@ contains
     deallocate (iw)
   end subroutine
 
+  ! ---- TI depth kernels (inv/depthkernelTI.f90:2 -> inv/tregn96.f:52) --------------------------------
+  subroutine ref_depthkernelti(nx, ny, nz, vel, kmax, t, depz, minthk, pv, lsen) bind(C, name="ref_depthkernelti")
+    integer(c_int), value :: nx, ny, nz, kmax
+    real(c_float), intent(in) :: vel(nx, ny, nz), depz(nz)
+    real(c_float), value :: minthk
+    real(c_double), intent(in) :: t(kmax)
+    real(c_double), intent(out) :: pv(nx*ny, kmax)
+    real(c_float), intent(out) :: lsen(nx*ny, kmax, nz - 1)
+    external depthkernelTI
+    call depthkernelTI(nx, ny, nz, vel, pv, 2, 0, kmax, t, depz, minthk, lsen)
+  end subroutine
+
   ! ---- data sigma (inv/CalSigamNorm.f90:2) ---------------------------------------------------------
   subroutine ref_ddatsigma(dall, obst, cbst, sigmaT, meandeltaT) bind(C, name="ref_ddatsigma")
     integer(c_int), value :: dall

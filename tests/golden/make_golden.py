@@ -30,8 +30,13 @@ def main():
     vel = np.array(toks[nz:nz + nx * ny * nz], np.float32).reshape(nz, ny, nx)
     g = np.loadtxt(os.path.join(REFDIR, "output", "period_Azm_tomo.real"))
     t36 = np.arange(5, 41, dtype=np.float64)
+    # true Gc/L, Gs/L models of the example (inner cells, [nz-1][ny-2][nx-2]) and the authors' azimuthal columns
+    # 5-9 (angle, relative amplitude, amplitude, A1=sum Lsen*Gc, A2=sum Lsen*Gs): pins depthkernelTI/tregn96
+    gc = np.loadtxt(os.path.join(REFDIR, "MODGc.true")).reshape(nz - 1, ny - 2, nx - 2).astype(np.float32)
+    gs = np.loadtxt(os.path.join(REFDIR, "MODGs.true")).reshape(nz - 1, ny - 2, nx - 2).astype(np.float32)
     np.savez_compressed(os.path.join(HERE, "test1_authors.npz"), depz=depz, vel=vel, periods=t36,
-                        pv_inner=g[:, 3].reshape(36, ny - 2, nx - 2).astype(np.float32))
+                        pv_inner=g[:, 3].reshape(36, ny - 2, nx - 2).astype(np.float32), gc=gc, gs=gs,
+                        azim=g[:, 4:9].reshape(36, ny - 2, nx - 2, 5).astype(np.float32))
     # ---- (2) depthkernel on test1 model, a few periods, every column ----
     t5 = np.array([5.0, 10.0, 20.0, 30.0, 40.0])
     pv, sen = ref.depthkernel(vel, depz, t5, 2.0)

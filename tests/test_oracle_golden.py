@@ -144,3 +144,36 @@ def test_joint_golden(orc):
     assert rc == 0 and np.array_equal(dsurf, d["dsurf"])
     assert np.array_equal(rw, d["rw"]) and np.array_equal(irow, d["irow"]) and np.array_equal(icol, d["icol"])
     assert icol.max() > 2 * 15 * 15 * 3   # entries in the Gs block exist
+
+
+def test_ti_kernels_authors_fixture(orc):
+    """example/test1_syn_foward/output/period_Azm_tomo.real columns 5-9 (authors' gfortran build, 5 decimals): the
+    2-psi period maps A1 = sum_k Lsen_Gsc*Gc, A2 = sum_k Lsen_Gsc*Gs (inv/FwdAzimuthalAniMap.f90:37-46) of the true
+    models MODVs/MODGc/MODGs.true, i.e. depthkernelTI -> tregn96 on all 15x15 inner cells x 36 periods"""
+    d = load("test1_authors.npz")
+    nz, ny, nx = d["vel"].shape
+    pv, lsen = orc.depthkernel_ti(d["vel"], d["depz"], d["periods"], 2.0)
+    L = lsen.reshape(nz - 1, 36, ny, nx)[:, :, 1:-1, 1:-1]
+    A1 = np.zeros((36, ny - 2, nx - 2), np.float32)
+    A2 = A1.copy()
+    for k in range(nz - 1):   # fp32 accumulation over depth like the reference's cosTmp/sinTmp
+        A1 = (A1 + L[k] * d["gc"][k][None]).astype(np.float32)
+        A2 = (A2 + L[k] * d["gs"][k][None]).astype(np.float32)
+    az = d["azim"]
+    assert np.abs(az[..., 3]).max() > 0.02                       # the fixture is not trivially zero
+    assert np.abs(A1 - az[..., 3]).max() <= 0.5e-5 + 1e-7        # half a unit of the last printed digit
+    assert np.abs(A2 - az[..., 4]).max() <= 0.5e-5 + 1e-7
+    amp = np.sqrt(A1.astype(np.float64) ** 2 + A2.astype(np.float64) ** 2)
+    assert np.abs(amp - az[..., 2]).max() <= 0.5e-5 + 1e-7
+    iso = pv.reshape(36, ny, nx)[:, 1:-1, 1:-1]
+    assert np.abs(amp / iso - az[..., 1]).max() <= 0.5e-5 + 1e-7
+
+
+def test_ti_kernels_golden(orc):
+    """Lsen_Gsc of the reference's depthkernelTI on the test1 model at 3 periods (stored in joint_small.npz): the
+    restated compound-matrix factorisation agrees to fp32 rounding"""
+    a = load("test1_authors.npz")
+    d = load("joint_small.npz")
+    _, lsen = orc.depthkernel_ti(a["vel"], a["depz"], d["t"], 2.0)
+    assert lsen.shape == d["lsen"].shape
+    assert np.abs(lsen - d["lsen"]).max() <= 2e-7 * np.abs(d["lsen"]).max() + 1e-12

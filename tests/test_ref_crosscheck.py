@@ -54,3 +54,30 @@ def test_lsmr_random_system(orc, ref):
         xo, io = orc.lsmr(m, n, irow, icol, rw, b, 0.05, 1e-6, 1e-6, 1e6, 300, ls)
         assert ir["itn"] == io["itn"] and ir["istop"] == io["istop"]
         assert np.array_equal(xr, xo)
+
+
+def test_ti_kernels_test4_columns(orc, ref):
+    """depthkernelTI/tregn96 on columns of the test4 model (18 knots, 4 sublayers -> 86 layers, 36 periods):
+    oracle restatement vs the reference to fp32 rounding of the output"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "test4_yunnan.npz"))
+    vel = g["vel"][:, 20:22, 8:12].copy()
+    t = np.arange(5, 41, dtype=np.float64)
+    pv_r, ls_r = ref.depthkernel_ti(vel, g["depz"], t, 4.0)
+    pv_o, ls_o = orc.depthkernel_ti(vel, g["depz"], t, 4.0)
+    assert np.array_equal(pv_r, pv_o)
+    assert np.abs(ls_r - ls_o).max() <= 2e-7 * np.abs(ls_r).max()
+
+
+def test_ti_kernels_random_columns(orc, ref):
+    rng = np.random.default_rng(7)
+    nz, ny, nx = 6, 3, 4
+    depz = np.array([0.0, 3.0, 8.0, 15.0, 30.0, 60.0], np.float32)
+    v1d = np.array([2.9, 3.2, 3.5, 3.7, 4.1, 4.5], np.float32)
+    vel = (v1d[:, None, None] * (1 + 0.06 * rng.standard_normal((nz, ny, nx)))).astype(np.float32)
+    t = np.array([4.0, 7.0, 12.0, 20.0, 33.0, 50.0])
+    for minthk in (2.0, 3.0, 5.0):
+        pv_r, ls_r = ref.depthkernel_ti(vel, depz, t, minthk)
+        pv_o, ls_o = orc.depthkernel_ti(vel, depz, t, minthk)
+        assert np.array_equal(pv_r, pv_o)
+        assert np.abs(ls_r - ls_o).max() <= 2e-7 * np.abs(ls_r).max()
