@@ -122,6 +122,28 @@ class Context:
         self._check(rc)
         return pv, (sen if kernels else None), nf.value
 
+    # ---- N1 --------------------------------------------------------------------------------
+    def ti_kernels(self, vel, depz, tRc, minthk, pv, lsen=None):
+        """depthkernelTI/tregn96 (inv/depthkernelTI.f90:2): vel[nz][ny][nx] and pvRc[kmax][nx*ny] (output of
+        depthkernel) -> Lsen_Gsc[nz-1][kmax][nx*ny] fp32."""
+        nz, ny, nx = vel.shape
+        depz = np.ascontiguousarray(depz, np.float32)
+        tRc = np.ascontiguousarray(tRc, np.float64)
+        kmax = len(tRc)
+        if _is_torch(vel):
+            import torch
+            if lsen is None:
+                lsen = torch.empty((nz - 1, kmax, nx * ny), dtype=torch.float32, device=vel.device)
+        else:
+            vel = np.ascontiguousarray(vel, np.float32)
+            pv = np.ascontiguousarray(pv, np.float64)
+            if lsen is None:
+                lsen = np.zeros((nz - 1, kmax, nx * ny), np.float32)
+        rc = self.lib.dazim_ti_kernels(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk), kmax,
+                                       _ptr(tRc), _ptr(pv), _ptr(lsen))
+        self._check(rc)
+        return lsen
+
     # ---- K2+K3 -----------------------------------------------------------------------------
     def fmm_batch(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, period_idx,
                   veln=None, ttn=None, ttnr=None, nstsr=None, boxes=None, status=None,

@@ -59,6 +59,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Whichever copy is mapped first serves the
+    # whole process, and torch cannot find the GPU through the system copy ("No HIP GPUs are available"), so when
+    # torch is installed its libraries are mapped before ours.  Nothing else of torch is used here.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     lib.dazim_last_error.restype = C.c_char_p
     lib.dazim_last_kernel_seconds.restype = C.c_double

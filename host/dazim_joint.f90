@@ -1,10 +1,7 @@
-! dazim_joint.f90 -- drop-in for the reference's CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:209).
-!
-! Not built by host/Makefile: it links against the reference's own depthkernelTI.f90 + tregn96.f
-! (kept on the CPU; the TI eigenfunction kernels are row N1 of SURVEY.md section 8f), which supply
-! Lsen_Gsc.  Everything else -- dispersion + depth kernels, eikonal fields, rpathsAzim, the three
-! column blocks dVs | Gc | Gs -- runs on the GPU through dazim_rays_build_G_joint.  The dense copies
-! GVs/GGc/GGs are not filled (see INTEGRATION.md).
+! dazim_joint.f90 -- drop-in for the reference's CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:209), all on the GPU:
+! TI depth kernels Lsen_Gsc (depthkernelTI/tregn96 -> dazim_ti_kernels), dispersion + depth kernels, eikonal fields,
+! rpathsAzim and the three column blocks dVs | Gc | Gs (dazim_rays_build_G_joint).  The dense copies GVs/GGc/GGs are
+! not filled (see INTEGRATION.md).  host/Makefile compiles it (object only) to keep it honest.
 subroutine CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, col, dsurf, GVs, GGc, GGs, Lsen_Gsc, dall, rmax, tRcV, &
                               goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, minthk, &
                               scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, writepath)
@@ -20,10 +17,8 @@ subroutine CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, col, dsurf, GVs,
   real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
   real*8, allocatable :: pv2(:, :)
   integer :: ii, jj, tt
-  external depthkernelTI                      ! the reference's CPU routine, inv/depthkernelTI.f90:2
   allocate (pv2(nx*ny, kmaxRc))
-  Lsen_Gsc = 0.0
-  call depthkernelTI(nx, ny, nz, vels, pv2, 2, 0, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+  call dazim_lsen_gsc(nx, ny, nz, vels, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
   call dazim_calsurfg_joint(nx, ny, nz, vels, iw, rw, col, dsurf, Lsen_Gsc, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
                             periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pv2)
   do tt = 1, kmaxRc                           ! tRcV = inner-cell phase velocities, inv/CalSurfGAniso_Joint.f90:803-811

@@ -5,15 +5,15 @@
 ! lsmr.txt) in the reference's formats.
 !
 ! What runs where, per outer iteration (inv/Main_Jt.f90:360-770):
-!   device : dispersion + depth kernels, eikonal fields, rays + G rows (dazim_assemble_G), data weighting of G
+!   device : dispersion + depth kernels, TI eigenfunction kernels (joint mode), eikonal fields, rays + G rows (dazim_assemble_G), data weighting of G
 !            (dazim_csr_scale_rows), DWS (dazim_csr_col_abs_sums), the Tikhonov rows appended to the resident
 !            CSR (dazim_csr_append_coo), LSMR (dazim_lsmr) and the G*dv diagnostics (dazim_aprod).  G never
 !            leaves HBM; only O(m)+O(n) vectors cross PCIe.
 !   host   : parsing, residual statistics, CalDdatSigma, the O(n) regularisation stencil, the clamped model
 !            update and the writers.
-! Joint (iso-mode F) inversions need the TI depth kernels Lsen_Gsc (SURVEY 8f row N1); they come from the
-! procedure dazim_ti_kernels, which host/Makefile links either to ti_none.f90 (STOPs with a message) or, in the
-! build container, to ti_ref.f90 (the reference's own CPU depthkernelTI/tregn96 compiled where they lie).
+! Joint (iso-mode F) inversions take the TI depth kernels Lsen_Gsc from the procedure ti_depth_kernels, which
+! host/Makefile links to ti_hip.f90 (the device kernels of ti.hip) or, for cross-checks inside the build container,
+! to ti_ref.f90 (the reference's own CPU depthkernelTI/tregn96 compiled where they lie: `make refti`).
 program DAzimSurfTomo_amd
   use iso_c_binding
   use dazim_mod
@@ -222,7 +222,7 @@ program DAzimSurfTomo_amd
 
     ! ---- forward problem + sensitivity matrix on the device (CalSurfG / CalSurfGAnisoJoint) ---------------
     dsyn = 0; tRcV = 0
-    if (.not. iso_mod) call dazim_ti_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+    if (.not. iso_mod) call ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
     call dazim_assemble_G(.not. iso_mod, nx, ny, nz, vsf, dsyn, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
                           minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv)
     if (.not. iso_mod) then                       ! inv/CalSurfGAniso_Joint.f90:801-811 (the iso branch leaves tRcV = 0)

@@ -21,7 +21,7 @@ module dazim_mod
   private
   public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
-  public :: dazim_assemble_G, dazim_check, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
+  public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
@@ -49,6 +49,25 @@ module dazim_mod
       real(c_float), value :: sublayers
       real(c_float) :: vel(*), depz(*)
       real(c_double) :: periods(*), pv(*), svs(*), svp(*), srho(*)
+      integer(c_int) :: nfail
+    end function
+    integer(c_int) function dazim_ti_kernels(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, pv, lsen) &
+        bind(C, name="dazim_ti_kernels")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nx, ny, nz, kmax
+      real(c_float), value :: sublayers
+      real(c_float) :: vel(*), depz(*), lsen(*)
+      real(c_double) :: periods(*), pv(*)
+    end function
+    integer(c_int) function dazim_dispersion_only(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, &
+        pv, svs, svp, srho, nfail) bind(C, name="dazim_dispersion_kernels")
+      import
+      type(c_ptr), value :: ctx, svs, svp, srho
+      integer(c_int), value :: nx, ny, nz, kmax
+      real(c_float), value :: sublayers
+      real(c_float) :: vel(*), depz(*)
+      real(c_double) :: periods(*), pv(*)
       integer(c_int) :: nfail
     end function
     integer(c_int) function dazim_fmm_batch(ctx, nx, ny, goxd, gozd, dvxd, dvzd, kmax, pv, nfield, scx, scz, &
@@ -195,6 +214,21 @@ contains
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pvRc, &
                                         sen_vsRc, sen_vpRc, sen_rhoRc, nfail), 'depthkernel')
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
+  end subroutine
+
+  ! ---- inv/depthkernelTI.f90:2 (Lsen_Gsc only; the phase velocities are recomputed like the reference does) -------
+  subroutine dazim_lsen_gsc(nx, ny, nz, vel, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+    integer :: nx, ny, nz, kmaxRc
+    real :: vel(nx, ny, nz), depz(nz), minthk
+    real*4 :: Lsen_Gsc(nx*ny, kmaxRc, nz - 1)
+    real*8 :: tRc(kmaxRc)
+    real*8, allocatable :: pv(:, :)
+    integer(c_int) :: nfail
+    call dazim_init(0)
+    allocate (pv(nx*ny, kmaxRc))
+    call check(dazim_dispersion_only(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
+                                     c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
+    call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, Lsen_Gsc), 'depthkernelTI/tregn96')
   end subroutine
 
   ! ---- inv/CalSurfG.f90:909 ----------------------------------------------------------------------

@@ -1,6 +1,7 @@
-! ti_ref.f90 -- TI depth kernels for host/dazim_main.f90 from the reference's own CPU routine
-! (inv/depthkernelTI.f90:2 -> tregn96, inv/tregn96.f:52), compiled where it lies by `make joint`.
-subroutine dazim_ti_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+! ti_ref.f90 -- alternative provider of the TI depth kernels for host/dazim_main.f90: the reference's own CPU
+! routine (inv/depthkernelTI.f90:2 -> tregn96, inv/tregn96.f:52), compiled where it lies by `make refti`.
+! Only for cross-checking the device kernels inside the build container.
+subroutine ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
   implicit none
   integer :: nx, ny, nz, kmaxRc
   real :: vsf(nx, ny, nz), depz(nz), minthk

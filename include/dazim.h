@@ -66,7 +66,7 @@ int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dazim_sync(dazim_ctx *ctx);
 void *dazim_stream(dazim_ctx *ctx); /* the hipStream_t every kernel of this ctx is launched on */
 /* seconds spent in the last call's kernels, measured with HIP events on the ctx stream; name
- * selects the kernel ("fmm", "gridder", "disp", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
+ * selects the kernel ("fmm", "gridder", "disp", "ti", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
 double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
 /* tuning / test knobs.  "fmm.cap": LDS heap slots per field (0 = automatic from the grid size; 64
  * exercises the HBM spill path on small grids); "fmm.force_spill": 1 = run every field through
@@ -91,6 +91,17 @@ int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float
                              const float *depz, float sublayers, int kmax, const double *periods,
                              double *pvRc, double *sen_vs, double *sen_vp, double *sen_rho,
                              int *n_failed);
+
+/* ---- N1: TI eigenfunction partials -> azimuthal depth kernels ---------------------------------------
+ * = depthkernelTI (inv/depthkernelTI.f90:2) calling tregn96 (inv/tregn96.f:52) once per column: Rayleigh fundamental-mode
+ *   eigenfunctions of the flattened TI column (A=C=rho*Vp^2, L=N=rho*Vs^2, F=A-2L), partials dc/dah, dc/dbv, dc/dn with the
+ *   causal-Q shift (Qp=150, Qs=50) and sprayl's sphericity factors, combined over the sub-layers of each inversion layer into
+ *   Lsen_Gsc = dc/dA*A + dc/dL*L, the sensitivity of c to Gc/L, Gs/L.  Solid layers only (the reference's models are).
+ *  vel, depz, sublayers, periods as for dazim_dispersion_kernels; pvRc [kmax][nx*ny] = its output (the reference recomputes
+ *  the same surfdisp96 curve inside depthkernelTI); Lsen_Gsc out [nz-1][kmax][nx*ny] fp32 = Fortran Lsen_Gsc(nx*ny,kmax,nz-1),
+ *  0 where pvRc is 0.                                                                                             */
+int dazim_ti_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel, const float *depz,
+                     float sublayers, int kmax, const double *periods, const double *pvRc, float *Lsen_Gsc);
 
 /* ---- K2+K3: batched eikonal fields -----------------------------------------------------------
  * = gridder (inv/CalSurfG.f90:1423) once per period + per (source,period): bsplrefine (:1525),

@@ -336,6 +336,17 @@ class Ref:
                                    C.c_float(minthk), pd(pv), pf(lsen))
         return pv, lsen
 
+    def tikhonov_joint(self, nx, ny, nz, dall, wgcs, wvs, rw, irow, icol):
+        nvp = (nx - 2) * (ny - 2) * (nz - 1)
+        cap = len(rw) + 7 * 3 * nvp
+        rw2 = np.zeros(cap, f32); ir2 = np.zeros(cap, i32); ic2 = np.zeros(cap, i32)
+        rw2[:len(rw)] = rw; ir2[:len(rw)] = irow; ic2[:len(rw)] = icol
+        nar = C.c_int(len(rw)); c3 = C.c_int(0); narvs = C.c_int(0)
+        self.lib.ref_tikhonov_joint(nx, ny, nz, nvp, dall, C.byref(nar), cap, pf(rw2), pi(ir2), pi(ic2), C.byref(narvs),
+                                    C.byref(c3), C.c_float(wgcs), C.c_float(wvs))
+        n = nar.value
+        return c3.value, rw2[:n].copy(), ir2[:n].copy(), ic2[:n].copy()
+
     def ddatsigma(self, obst, cbst):
         obst = np.ascontiguousarray(obst, f32); cbst = np.ascontiguousarray(cbst, f32)
         sig = np.zeros(len(obst), f32); mean = C.c_float(0)

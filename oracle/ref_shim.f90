@@ -270,6 +270,25 @@ contains
     deallocate (iw)
   end subroutine
 
+  ! ---- joint Tikhonov rows (inv/TikhRegul.f90:108) ----------------------------------------------------
+  subroutine ref_tikhonov_joint(nx, ny, nz, maxvp, dall, nar, maxnar, rw, irow, icol, narvs, count3, lamegcs, lamevs) &
+       bind(C, name="ref_tikhonov_joint")
+    integer(c_int), value :: nx, ny, nz, maxvp, dall, maxnar
+    real(c_float), value :: lamegcs, lamevs
+    integer(c_int), intent(inout) :: nar, irow(maxnar), icol(maxnar)
+    real(c_float), intent(inout) :: rw(maxnar)
+    integer(c_int), intent(out) :: count3, narvs
+    integer, allocatable :: iw(:)
+    real(4) :: lg, lv
+    external TikhRegul_joint
+    allocate (iw(2*maxnar + 1))
+    iw = 0; iw(2:nar + 1) = irow(1:nar)
+    lg = lamegcs; lv = lamevs; count3 = 0; narvs = 0
+    call TikhRegul_joint(nx, ny, nz, maxvp, dall, nar, rw, iw, icol, narvs, count3, lg, lv)
+    irow(1:nar) = iw(2:nar + 1)
+    deallocate (iw)
+  end subroutine
+
   ! ---- TI depth kernels (inv/depthkernelTI.f90:2 -> inv/tregn96.f:52) --------------------------------
   subroutine ref_depthkernelti(nx, ny, nz, vel, kmax, t, depz, minthk, pv, lsen) bind(C, name="ref_depthkernelti")
     integer(c_int), value :: nx, ny, nz, kmax

@@ -165,5 +165,44 @@ cccccccccc periods
     print("dall", len(obst), "saved", os.path.getsize(os.path.join(HERE, "inversion_iso_small.npz")) // 1024, "KiB")
 
 
+
+    # ---- the same data in joint mode (iso-mode F): dVs | Gc | Gs, inv/Main_Jt.f90:399-403, 548-553, 593-618 ----
+    wgcs, jiter = 4.0, 2
+    para_j = para.replace("\nT  ", "\nF  ").replace("0                                    c: smoothing for Gc,s",
+                                                    "%.1f                                  c: smoothing for Gc,s" % wgcs)
+    para_j = para_j.replace("%d                                   c: maximum of iteration" % maxiter,
+                            "%d                                   c: maximum of iteration" % jiter)
+    assert para_j != para and "\nF  " in para_j
+    vsf = np.array(mod.split()[nz:], f32).reshape(nz, ny, nx)
+    models, gcs, gss, itns, istops, stats = [], [], [], [], [], []
+    for it in range(jiter):
+        rw, irow, icol, dsyn, lsen = ref.calsurfg_joint(vsf, depz, goxd, gozd, dv, dv, tRc, minthk, geo["scxf"], geo["sczf"],
+                                                        geo["rcxf"], geo["rczf"], geo["nrc1"], geo["nsrc1"], geo["periods"], 6000000)
+        dall = len(dsyn)
+        cbst = (obst - dsyn).astype(f32)
+        stats.append(float(np.sqrt(np.mean(cbst.astype(np.float64) ** 2))))
+        sig, _ = ref.ddatsigma(obst, cbst)
+        w = (f32(1) / sig).astype(f32)
+        rw = (rw * w[irow - 1]).astype(f32)
+        c3, rwT, irT, icT = ref.tikhonov_joint(nx, ny, nz, dall, wgcs, wvs, rw, irow, icol)
+        m = dall + c3
+        rhs = np.zeros(m, f32); rhs[:dall] = cbst * w
+        x, info = ref.lsmr(m, 3 * nvp, irT, icT, rwT, rhs, damp, 1e-5, 1e-4, 200, 500, 10)
+        xv = x[:nvp].copy()
+        xv = np.where(xv >= f32(0.5), f32(0.5), xv); xv = np.where(xv <= f32(-0.5), f32(-0.5), xv)
+        xv = np.where(np.abs(xv) < f32(1e-5), f32(0), xv).astype(f32)
+        inner = vsf[:nz - 1, 1:ny - 1, 1:nx - 1]
+        inner += xv.reshape(nz - 1, ny - 2, nx - 2)
+        np.clip(inner, f32(minvel), f32(maxvel), out=inner)
+        models.append(vsf.copy()); itns.append(info["itn"]); istops.append(info["istop"])
+        gcs.append(x[nvp:2 * nvp].reshape(nz - 1, ny - 2, nx - 2).copy()); gss.append(x[2 * nvp:].reshape(nz - 1, ny - 2, nx - 2).copy())
+        if it == 0:
+            lsen1 = lsen.copy()
+        print("joint iter", it + 1, info, "max|dVs| %.4f max|Gc| %.4f max|Gs| %.4f" % (np.abs(xv).max(), np.abs(gcs[-1]).max(), np.abs(gss[-1]).max()))
+    np.savez_compressed(os.path.join(HERE, "inversion_joint_small.npz"), para=para_j, data=data, mod=mod, nx=nx, ny=ny, nz=nz,
+                        depz=depz, models=np.array(models), gc=np.array(gcs), gs=np.array(gss), itn=np.array(itns),
+                        istop=np.array(istops), rms_in=np.array(stats), lsen1=lsen1)
+
+
 if __name__ == "__main__":
     main()
