@@ -2,11 +2,14 @@
 // back-tracing with B-spline Frechet weights (rpaths, :1735) and G-row assembly (:1339-1364) for a
 // batch of rays whose eikonal fields are already resident in HBM (output of dazim_fmm_batch).
 //
-// One wavefront per ray.  The Frechet grid fdm(0:nvz+1,0:nvx+1) of the ray lives in LDS; the
-// half-cell stepping is inherently serial and is executed redundantly by all lanes, while the
-// 4x4 B-spline scatter of every sub-segment is spread over lanes 0..15.  Rows are emitted straight
-// into CSR in the reference's column order (depth-major, then jj, kk) by a count pass, an exclusive
-// scan and an emit pass -- no atomics, so G is reproducible.  fp32 without FMA like the reference.
+// Four rays per wavefront, one per 16-lane group (the kernel is VALU-issue bound, so SIMT across groups
+// quarters the instruction count per ray).  The half-cell stepping is inherently serial and is executed
+// redundantly by the 16 lanes of a group, while the 4x4 B-spline scatter of every sub-segment is spread over
+// them: each lane keeps one cell of the current 4x4 block of the Frechet grid(s) in registers and the block is
+// written back to the ray's grid in HBM scratch only when the ray leaves it.  Touched cells are collected in an
+// LDS cell list.  Rows are emitted straight into CSR in the reference's column order (depth-major, then jj,
+// kk) by a count pass, an exclusive scan and an emit pass that reuses the saved cell lists -- no atomics, so G
+// is reproducible.  fp32 without FMA like the reference.
 #include <cmath>
 
 #include "dazim_internal.h"
