@@ -50,6 +50,8 @@ struct RayArgs {
   float *lval;             // [nray][LK] (x3 in joint mode) their fdm (, fdmc, fdms) values
   float *fdm_scratch;      // [nwg*4][(nvx+2)*(nvz+2)] (x3 in joint mode): one Frechet grid slot per 16-lane group
   int LK;
+  int keep_small;          // 1: keep every non-zero row entry of the |fdm| >= ftol cells (the forward program's dense GGc/GGs,
+                           // fwd/FwdTraveltimeCPS.f90:694-712); 0: the inversion's second |row| > ftol threshold
   const long *rowptr;      // [nray+1] (emit pass in)
   float *val;
   int *col;
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
             } else {
               rowv = A.lsen[si] * (blk == 1 ? gfdmc : gfdms)[kk * ldf + jj];
             }
-            keep = fabsf(rowv) > FTOL;
+            keep = A.keep_small ? (rowv != 0.0f) : (fabsf(rowv) > FTOL);
             nn = blk * nparpi + (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
           }
           const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
@@ -561,6 +563,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = dz_scratch(ctx, "rays.count", (size_t)(m + 1) * 8, &p))) return rc;
   A.count = (long *)p;
   A.LK = g.nvx * g.nvz < 512 ? g.nvx * g.nvz : 512;
+  A.keep_small = ctx->opts.count("rays.keep_small") && ctx->opts["rays.keep_small"] ? 1 : 0;
   if ((rc = dz_scratch(ctx, "rays.nlist", nr1 * 4, &p))) return rc;
   A.nlist = (int *)p;
   if ((rc = dz_scratch(ctx, "rays.lcell", nr1 * A.LK * 2, &p))) return rc;

@@ -21,7 +21,7 @@ module dazim_mod
   private
   public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
-  public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
+  public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
@@ -50,6 +50,9 @@ module dazim_mod
       real(c_float) :: vel(*), depz(*)
       real(c_double) :: periods(*), pv(*), svs(*), svp(*), srho(*)
       integer(c_int) :: nfail
+    end function
+    integer(c_int) function dazim_set_option(ctx, name, value) bind(C, name="dazim_set_option")
+      import; type(c_ptr), value :: ctx; character(kind=c_char) :: name(*); integer(c_int), value :: value
     end function
     integer(c_int) function dazim_ti_kernels(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, pv, lsen) &
         bind(C, name="dazim_ti_kernels")
