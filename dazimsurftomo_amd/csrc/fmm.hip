@@ -141,7 +141,8 @@ struct Heap {
   int ntr;
   bool g0;     // lane 0 of the group
 
-  __device__ __forceinline__ int idx(int node) const { return ((node >> 16) - 1) * ld + ((node & 0xffff) - 1); }
+  // operands < 2^15: v_mad_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
+  __device__ __forceinline__ int idx(int node) const { return __mul24((node >> 16) - 1, ld) + ((node & 0xffff) - 1); }
   // SPILL=false: the whole band lives in LDS (no VMEM load inside the sift loops, so the back-pointer
   // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
@@ -475,11 +476,11 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) rec[(ix - 1) * ld + (iz - 1)].s = 0;
+        if (H.g0) rec[__mul24(ix - 1, ld) + (iz - 1)].s = 0;
         break;
       }
     }
-    if (H.g0) rec[(ix - 1) * ld + (iz - 1)].s = 0;
+    if (H.g0) rec[__mul24(ix - 1, ld) + (iz - 1)].s = 0;
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
@@ -489,13 +490,16 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     const int j = nix + jd, j2 = nix + 2 * jd, k = niz + kd, k2 = niz + 2 * kd;
     const bool vj = nvalid && j >= 1 && j <= nnx, vj2 = vj && j2 >= 1 && j2 <= nnx;
     const bool vk = nvalid && k >= 1 && k <= nnz, vk2 = vk && k2 >= 1 && k2 <= nnz;
-    const int iroot = (ix - 1) * ld + (iz - 1);
-    Node nself = rec[nvalid ? (nix - 1) * ld + (niz - 1) : iroot];
-    Node nj = rec[vj ? (j - 1) * ld + (niz - 1) : iroot];
-    Node nj2 = rec[vj2 ? (j2 - 1) * ld + (niz - 1) : iroot];
-    Node nk = rec[vk ? (nix - 1) * ld + (k - 1) : iroot];
-    Node nk2 = rec[vk2 ? (nix - 1) * ld + (k2 - 1) : iroot];
-    const float vel = veln[nvalid ? (nix - 1) * ld + (niz - 1) : iroot];
+    const int iroot = __mul24(ix - 1, ld) + (iz - 1);
+    // record indices by offsets from the neighbour's own record (one multiply for all seven loads)
+    const int iself = iroot + __mul24(dix, ld) + diz;
+    const int sj = jd > 0 ? ld : -ld;
+    Node nself = rec[nvalid ? iself : iroot];
+    Node nj = rec[vj ? iself + sj : iroot];
+    Node nj2 = rec[vj2 ? iself + 2 * sj : iroot];
+    Node nk = rec[vk ? iself + kd : iroot];
+    Node nk2 = rec[vk2 ? iself + 2 * kd : iroot];
+    const float vel = veln[nvalid ? iself : iroot];
     const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];

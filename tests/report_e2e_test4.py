@@ -1,3 +1,5 @@
+"""Timing + parity report of the bundled test4_Yunnan example through the host-array API (not collected by pytest; run on the GPU box:
+python tests/report_e2e_test4.py).  Uses the oracle for the Tikhonov rows, hence lives under tests/."""
 import sys, time, numpy as np
 sys.path.insert(0, "/root/repo")
 import dazimsurftomo_amd as dz

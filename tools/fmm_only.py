@@ -1,3 +1,6 @@
+"""Eikonal kernel alone on the S-256 synthetic (or NX=<nx> grids): python tools/fmm_only.py <sources> <reps>; env CAP / WPC set the
+fmm.cap / fmm.wg_per_cu options.  With a library built by DAZIM_HIPCC_EXTRA=-DDZ_FMM_PROF the per-phase shader-clock totals of the
+marching loop are printed to stderr."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import dazimsurftomo_amd as dz
