@@ -58,3 +58,58 @@ def test_test4_yunnan_iso_iteration(ctx, orc):
     assert np.linalg.norm(x - d["x"]) <= 1e-2 * np.linalg.norm(d["x"])
     assert abs(info["normr"] - gi[4]) <= 1e-3 * gi[4]
     G.free()
+
+
+GOLD_J = os.path.join(os.path.dirname(__file__), "golden", "test4_yunnan_joint.npz")
+
+
+@pytest.mark.skipif(not (os.path.exists(GOLD) and os.path.exists(GOLD_J)), reason="test4 joint golden not generated")
+def test_test4_yunnan_joint_iteration(ctx, orc):
+    """The example as its own para.in runs it (iso-mode F): TI depth kernels, rows dVs | Gc | Gs (53 M entries), 1/sigma
+    weights, joint Tikhonov rows (20 / 30) and the joint LSMR controls, against the reference routines' first outer iteration
+    (tests/golden/make_test4_joint_golden.py).  Lsen_Gsc <= 1e-6*max (a handful of columns see a pvRc that differs by an fp32
+    ulp: 2e-5); weighted-G row/column |.| sums rel-L2 <= 1e-4; LSMR stops with the same istop, itn within 5 %, and the three
+    blocks of the solution agree to rel-L2 <= 2e-2 (fp32 LSMR, ~170 iterations on matrices that differ at the 1e-4 threshold)."""
+    d, j = np.load(GOLD), np.load(GOLD_J)
+    nx, ny, nz = int(d["nx"]), int(d["ny"]), int(d["nz"])
+    goxd, gozd, dv, minthk = float(d["goxd"]), float(d["gozd"]), float(d["dv"]), float(d["minthk"])
+    vel, depz, t = d["vel"], d["depz"], d["t"]
+    pv, sen, nfail = ctx.depthkernel(vel, depz, t, minthk)
+    lsen = ctx.ti_kernels(vel, depz, t, minthk, pv)
+    dl = np.abs(lsen - j["lsen"])
+    assert dl.max() <= 2e-5 * np.abs(j["lsen"]).max() and (dl <= 1e-6 * np.abs(j["lsen"]).max()).mean() >= 0.995
+    scx, scz, per, ray_f, rx, rz = flatten(d["scxf"], d["sczf"], d["rcxf"], d["rczf"], d["nrc1"], d["nsrc1"], d["periods"])
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+    dall, nvp = len(tpred), (nx - 2) * (ny - 2) * (nz - 1)
+    assert (G.m, G.n) == (dall, 3 * nvp)
+    assert abs(G.nnz - int(j["nnz"])) <= 1e-3 * int(j["nnz"])
+    # data weights exactly as the reference formed them (CalDdatSigma on the reference's residuals)
+    G.scale_rows(j["w"])
+    ir, ic, rw = G.to_coo()
+    rowsum = np.bincount(ir - 1, weights=np.abs(rw).astype(np.float64), minlength=dall)
+    colsum = np.bincount(ic - 1, weights=np.abs(rw).astype(np.float64), minlength=3 * nvp)
+    del ir, ic, rw
+    assert np.linalg.norm(rowsum - j["rowsum"]) <= 1e-4 * np.linalg.norm(j["rowsum"])
+    assert np.linalg.norm(colsum - j["colsum"]) <= 1e-4 * np.linalg.norm(j["colsum"])
+    # joint Tikhonov rows: dVs block with 20, Gc and Gs blocks with 30 (inv/TikhRegul.f90:108)
+    e = np.zeros(0, np.float32)
+    ei = np.zeros(0, np.int32)
+    c1, rw1, ir1, ic1 = orc.tikhonov_iso(nx, ny, nz, dall, 20.0, e, ei, ei)
+    c2, rw2, ir2, ic2 = orc.tikhonov_iso(nx, ny, nz, dall, 30.0, e, ei, ei)
+    irT = np.concatenate([ir1, ir2 + c1, ir2 + 2 * c1]).astype(np.int32)
+    icT = np.concatenate([ic1, ic2 + nvp, ic2 + 2 * nvp]).astype(np.int32)
+    rwT = np.concatenate([rw1, rw2, rw2])
+    c3 = 3 * c1
+    assert c3 == int(j["c3"])
+    G.append_coo(c3, irT, icT, rwT)
+    b = np.zeros(dall + c3, np.float32)
+    b[:dall] = (d["obst"] - tpred) * j["w"]
+    x, info = ctx.lsmr(G, b, 0.0, 1e-5, 1e-4, 200.0, 500, 10)
+    gi = j["info"]
+    assert info["istop"] == int(gi[0]) and abs(info["itn"] - int(gi[1])) <= max(3, 0.05 * gi[1])
+    for blk in range(3):
+        a, r = x[blk * nvp:(blk + 1) * nvp], j["x"][blk * nvp:(blk + 1) * nvp]
+        assert np.linalg.norm(a - r) <= 2e-2 * np.linalg.norm(r), blk
+    assert abs(info["normr"] - gi[4]) <= 1e-3 * gi[4]
+    G.free()
