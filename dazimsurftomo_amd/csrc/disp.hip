@@ -79,11 +79,17 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
 
 // inv/surfdisp96.f:767-865 with var (:868-985), dnka (:1018-1062) and normc (:989-1014) inlined;
 // llw = 1 (no water layer).  normc's log() is dead in the reference and dropped.
+// fp64 divisions are ~30 instructions each on CDNA, so three groups of them are replaced by cheaper forms that
+// differ from the reference's arithmetic only by fp64 rounding noise (the root is searched to 1e-6 relative and
+// rounded to fp32): the normalisation of the compound vector multiplies by the reciprocal of its largest entry
+// instead of dividing five times, 1/rho and 1/rho^2 are formed once per layer, and fb/omega uses the reciprocal of
+// omega hoisted out of the layer loop.
 __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, double wvno, double omga) {
   double e0, e1, e2, e3, e4;
   double omega = omga;
   if (omega < 1.0e-4) omega = 1.0e-4;
   const double wvno2 = wvno * wvno;
+  const double romega = 1.0 / omega;
   float fa, fb, frho, fd;
   layer_model(K, lay, mmax, nz, fa, fb, frho, fd);
   {
@@ -107,7 +113,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
   for (int m = mmax - 1; m >= 1; m--) {
     layer_model(K, lay, m, nz, fa, fb, frho, fd);
     const double xka = omega / (double)fa, xkb = omega / (double)fb;
-    const double t = (double)fb / omega;
+    const double t = (double)fb * romega;
     const double gammk = 2.0 * t * t;
     const double gam = gammk * wvno2;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
@@ -116,6 +122,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     wvnom = fabs(wvno - xkb);
     const double rb = sqrt(wvnop * wvnom);
     const double dpth = (double)fd, rho1 = (double)frho;
+    const double rrho1 = 1.0 / rho1, rrho2 = rrho1 * rrho1;
     const double p = ra * dpth, q = rb * dpth;
     double w, x, y, z, cosp, cosq, sinp, sinq, fac, pex = 0.0, sex = 0.0;
     if (wvno < xka) {
@@ -163,10 +170,10 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     const double twgm1 = gam + gamm1, gmgmk = gam * gammk, gmgm1 = gam * gamm1, gm1sq = gamm1 * gamm1;
     const double rho2 = rho1 * rho1, a0pq = a0 - cpcq;
     const double ca11 = cpcq - 2.0 * gmgm1 * a0pq - gmgmk * xz - wvno2 * gm1sq * wy;
-    const double ca12 = (wvno2 * cpy - cqx) / rho1;
-    const double ca13 = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) / rho1;
-    const double ca14 = (cpz - wvno2 * cqw) / rho1;
-    const double ca15 = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) / rho2;
+    const double ca12 = (wvno2 * cpy - cqx) * rrho1;
+    const double ca13 = -(twgm1 * a0pq + gammk * xz + wvno2 * gamm1 * wy) * rrho1;
+    const double ca14 = (cpz - wvno2 * cqw) * rrho1;
+    const double ca15 = -(2.0 * wvno2 * a0pq + xz + wvno2 * wvno2 * wy) * rrho2;
     const double ca21 = (gmgmk * cpz - gm1sq * cqw) * rho1;
     const double ca22 = cpcq;
     const double ca23 = gammk * cpz - gamm1 * cqw;
@@ -191,18 +198,16 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     double n2 = 0.0 + e0 * ca13;  n2 = n2 + e1 * ca23;  n2 = n2 + e2 * ca33;  n2 = n2 + e3 * ca43;  n2 = n2 + e4 * ca53;
     double n3 = 0.0 + e0 * ca14;  n3 = n3 + e1 * ca24;  n3 = n3 + e2 * ca34;  n3 = n3 + e3 * ca44;  n3 = n3 + e4 * ca54;
     double n4 = 0.0 + e0 * ca15;  n4 = n4 + e1 * ca25;  n4 = n4 + e2 * ca35;  n4 = n4 + e3 * ca45;  n4 = n4 + e4 * ca55;
-    double t1 = 0.0;
-    if (fabs(n0) > t1) t1 = fabs(n0);
-    if (fabs(n1) > t1) t1 = fabs(n1);
-    if (fabs(n2) > t1) t1 = fabs(n2);
-    if (fabs(n3) > t1) t1 = fabs(n3);
-    if (fabs(n4) > t1) t1 = fabs(n4);
+    // normc (:989-1014): scale by the reciprocal of the largest |entry| (one division instead of five; the scale must stay
+    // a continuous function of c -- the root finder interpolates the returned values)
+    double t1 = fmax(fmax(fmax(fabs(n0), fabs(n1)), fmax(fabs(n2), fabs(n3))), fabs(n4));
     if (t1 < 1.e-40) t1 = 1.0;
-    e0 = n0 / t1;
-    e1 = n1 / t1;
-    e2 = n2 / t1;
-    e3 = n3 / t1;
-    e4 = n4 / t1;
+    const double r1 = 1.0 / t1;
+    e0 = n0 * r1;
+    e1 = n1 * r1;
+    e2 = n2 * r1;
+    e3 = n3 * r1;
+    e4 = n4 * r1;
   }
   return e0;
 }
