@@ -332,26 +332,51 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int64_t r0 = nrows * chunk / nchunk, r1 = nrows * (chunk + 1) / nchunk;
-  for (int64_t r = r0 + w; r < r1; r += SCW) {
-    const int64_t s = cbptr[r * (ncb + 1) + cb], e = cbptr[r * (ncb + 1) + cb + 1];
-    if (s == e) continue;
-    const float yr = y[r];
-    int64_t s4 = (s + 3) & ~(int64_t)3;
-    if (s4 > e) s4 = e;
-    for (int64_t i = s + lane; i < s4; i += 64)
-      atomicAdd((unsigned long long *)&acc[col[i] - c0], (unsigned long long)__double2ll_rn((double)(val[i] * yr) * scale));
-    const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
-    for (int64_t i = s4 + 4 * lane; i < e4; i += 256) {
-      const float4 v = *reinterpret_cast<const float4 *>(val + i);
-      const int4 c = *reinterpret_cast<const int4 *>(col + i);
-      atomicAdd((unsigned long long *)&acc[c.x - c0], (unsigned long long)__double2ll_rn((double)(v.x * yr) * scale));
-      atomicAdd((unsigned long long *)&acc[c.y - c0], (unsigned long long)__double2ll_rn((double)(v.y * yr) * scale));
-      atomicAdd((unsigned long long *)&acc[c.z - c0], (unsigned long long)__double2ll_rn((double)(v.z * yr) * scale));
-      atomicAdd((unsigned long long *)&acc[c.w - c0], (unsigned long long)__double2ll_rn((double)(v.w * yr) * scale));
-    }
-    for (int64_t i = e4 + lane; i < e; i += 64)
-      atomicAdd((unsigned long long *)&acc[col[i] - c0], (unsigned long long)__double2ll_rn((double)(val[i] * yr) * scale));
+  // Software-pipelined over rows: the block pointers and y of the NEXT row are requested before the current row is
+  // streamed, and two 256-entry groups are in flight per wavefront, so a row costs one memory latency instead of two
+  // chained ones (the kernel is latency-bound: ~550 entries per (row, column block)).
+#define SC_ADD(cc, vv) atomicAdd((unsigned long long *)&acc[(cc) - c0], (unsigned long long)__double2ll_rn((double)((vv) * yr) * scale))
+  int64_t r = r0 + w, s = 0, e = 0;
+  float yr = 0.0f;
+  if (r < r1) {
+    s = cbptr[r * (ncb + 1) + cb];
+    e = cbptr[r * (ncb + 1) + cb + 1];
+    yr = y[r];
   }
+  for (; r < r1; r += SCW) {
+    const int64_t rn = r + SCW;
+    int64_t sn = 0, en = 0;
+    float yn = 0.0f;
+    if (rn < r1) {
+      sn = cbptr[rn * (ncb + 1) + cb];
+      en = cbptr[rn * (ncb + 1) + cb + 1];
+      yn = y[rn];
+    }
+    if (s != e) {
+      int64_t s4 = (s + 3) & ~(int64_t)3;
+      if (s4 > e) s4 = e;
+      for (int64_t i = s + lane; i < s4; i += 64) SC_ADD(col[i], val[i]);
+      const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
+      for (int64_t i = s4 + 4 * lane; i < e4; i += 512) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(val + i);
+        const int4 k0 = *reinterpret_cast<const int4 *>(col + i);
+        const bool two = i + 256 < e4;
+        float4 v1 = v0;
+        int4 k1 = k0;
+        if (two) {
+          v1 = *reinterpret_cast<const float4 *>(val + i + 256);
+          k1 = *reinterpret_cast<const int4 *>(col + i + 256);
+        }
+        SC_ADD(k0.x, v0.x); SC_ADD(k0.y, v0.y); SC_ADD(k0.z, v0.z); SC_ADD(k0.w, v0.w);
+        if (two) { SC_ADD(k1.x, v1.x); SC_ADD(k1.y, v1.y); SC_ADD(k1.z, v1.z); SC_ADD(k1.w, v1.w); }
+      }
+      for (int64_t i = e4 + lane; i < e; i += 64) SC_ADD(col[i], val[i]);
+    }
+    s = sn;
+    e = en;
+    yr = yn;
+  }
+#undef SC_ADD
   __syncthreads();
   long long *dst = part + (size_t)chunk * ncols + c0;
   for (int i = threadIdx.x; i < width; i += 64 * SCW) dst[i] = acc[i];

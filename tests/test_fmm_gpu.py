@@ -58,6 +58,11 @@ def test_fmm_256(ctx, orc):
     _run_case(ctx, orc, 54, 54, 2, 6, seed=5)
 
 
+def test_fmm_126(ctx, orc):
+    """BASELINE S-128 geometry: 28x28 -> 126x126 nodes, 8 periods"""
+    _run_case(ctx, orc, 28, 28, 8, 5, seed=13, edge_sources=True)
+
+
 def test_fmm_511(ctx, orc):
     """BASELINE S-512 geometry: 105x105 -> 511x511 nodes (32-bit node ids, heap capacity 1536, 4-step sift-down to level 11)"""
     _run_case(ctx, orc, 105, 105, 1, 5, seed=8, edge_sources=True)
