@@ -179,6 +179,13 @@ def main():
     if use_dist:
         dist.barrier()
     ctx = dz.Context(local)
+    # N > 1: the row-sharded LSMR.  Default: the Python driver over torch.distributed (backend nccl = RCCL).
+    # DAZIM_LSMR_NATIVE=1: the same algorithm inside the C library with its own RCCL communicator (dazim_comm_init).
+    native = use_dist and os.environ.get("DAZIM_LSMR_NATIVE") == "1"
+    if native:
+        box = [dz.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        ctx.comm_init(world, rank, box[0])
 
     kmax = len(PERIODS)
     vel = s256_model()
@@ -226,7 +233,7 @@ def main():
         stats["nnz_data"] = G.nnz
         G.append_coo(c3, t_ir, t_ic, t_rw)
         stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
-        if not use_dist:
+        if not use_dist or native:
             x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
             stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
@@ -303,6 +310,8 @@ def main():
     else:
         result_line = None
     if use_dist:
+        if native:
+            ctx.comm_free()
         dist.barrier()
         dist.destroy_process_group()
     import ctypes

@@ -53,6 +53,14 @@ def to_radians(lat_deg, lon_deg):
         (lon * PI_F32 / np.float32(180.0)).astype(np.float32)
 
 
+def comm_unique_id():
+    """128-byte RCCL id (rank 0 creates it and sends it to the other ranks)"""
+    buf = C.create_string_buffer(128)
+    if load().dazim_comm_unique_id(buf) != 0:
+        raise RuntimeError("ncclGetUniqueId failed")
+    return buf.raw
+
+
 def geometry(nx, ny, goxd, gozd, dvxd, dvzd):
     g = Geom()
     rc = load().dazim_geometry(nx, ny, C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd), C.c_float(dvzd), C.byref(g))
@@ -94,6 +102,16 @@ class Context:
 
     def sync(self):
         self._check(self.lib.dazim_sync(self._h))
+
+    # ---- multi-GPU solve (RCCL inside the library) -------------------------------------------
+    def comm_init(self, nranks, rank, uid):
+        """join the RCCL communicator identified by `uid` (bytes from comm_unique_id() of rank 0); afterwards
+        lsmr() treats its matrix and right-hand side as this rank's row shard of one global system"""
+        buf = C.create_string_buffer(bytes(uid), 128)
+        self._check(self.lib.dazim_comm_init(self._h, int(nranks), int(rank), buf))
+
+    def comm_free(self):
+        self._check(self.lib.dazim_comm_free(self._h))
 
     # ---- K1 ---------------------------------------------------------------------------------
     def depthkernel(self, vel, depz, tRc, minthk, kernels=True, pv=None, sen=None):

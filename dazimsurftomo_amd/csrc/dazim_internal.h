@@ -21,6 +21,9 @@ struct dazim_ctx {
   std::map<std::string, int> opts;     // dazim_set_option
   // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
   std::map<std::string, std::pair<void *, size_t>> scratch;
+  // RCCL communicator of a row-sharded solve (dazim_comm_init); nullptr = single GPU, RCCL never touched
+  void *comm = nullptr;
+  int nranks = 1, rank = 0;
 };
 
 int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);

@@ -7,6 +7,8 @@
 // a fixed order (no atomics) so that LSMR is reproducible run to run.
 #include "dazim_internal.h"
 
+#include <rccl/rccl.h>
+
 #include <rocprim/device/device_radix_sort.hpp>
 
 struct dazim_csr {
@@ -178,6 +180,19 @@ __global__ void finish_norm(const double *part, int np, float *res, double *res_
     res[0] = (float)sqrt(t);
     if (res_d) res_d[0] = t;
   }
+}
+// res[0] = sqrt(*sum) (after the all-reduce of a distributed norm)
+__global__ void k_sqrt_sum(const double *sum, float *res) { res[0] = (float)sqrt(sum[0]); }
+// v = w + sign*beta*v with the partial of ||v||^2 (distributed A^T u: w is the all-reduced product)
+__global__ void k_axpby_norm(int64_t n, const float *w, float *v, const float *beta_p, float beta_sign, double *part) {
+  const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    const float o = beta * v[i] + w[i];
+    v[i] = o;
+    sq += (double)o * o;
+  }
+  block_partial(sq, part);
 }
 __global__ void k_sumsq(int64_t n, const float *x, double *part) {
   double v = 0.0;
@@ -794,6 +809,45 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
   return 0;
 }
 
+#define DZ_NCCL(call)                                                                                        \
+  do {                                                                                                        \
+    ncclResult_t r_ = (call);                                                                                 \
+    if (r_ != ncclSuccess) return dz_fail(ctx, -2000 - (int)r_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+  } while (0)
+
+int dazim_comm_unique_id(void *id128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!id128) return DAZIM_E_BAD_ARG;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return -2000;
+  memcpy(id128, &id, sizeof id);
+  return 0;
+}
+int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128) {
+  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_init");
+  if (ctx->comm) return dz_fail(ctx, DAZIM_E_BAD_ARG, "a communicator is already attached");
+  DZ_HIP(hipSetDevice(ctx->device));
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  ncclComm_t comm;
+  DZ_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
+  ctx->comm = (void *)comm;
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return 0;
+}
+int dazim_comm_free(dazim_ctx *ctx) {
+  if (!ctx) return DAZIM_E_BAD_ARG;
+  if (ctx->comm) {
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    DZ_NCCL(ncclCommDestroy((ncclComm_t)ctx->comm));
+  }
+  ctx->comm = nullptr;
+  ctx->nranks = 1;
+  ctx->rank = 0;
+  return 0;
+}
+
 // LSMR, inv/lsmrModule.f90:36-750.  Vectors live on the device; the scalar recurrences (plane
 // rotations, norm estimates, stopping rules) run on the host in fp32 exactly as written there.
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,
@@ -806,10 +860,26 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   int rc;
   if ((rc = b.init(ctx, b_u, m, true, false))) return rc;
   if ((rc = x.init(ctx, x_u, n, false, true))) return rc;
-  int localVecs = localSize < 0 ? 0 : localSize;
-  if (m < localVecs) localVecs = (int)m;
-  if (n < localVecs) localVecs = (int)n;
+  ncclComm_t comm = (ncclComm_t)ctx->comm;   // non-null: A, b are this rank's rows of one global system
   void *p;
+  double *d_sum = nullptr;
+  float *wbuf = nullptr;
+  int64_t m_glob = m;
+  if (comm) {
+    if ((rc = dz_scratch(ctx, "lsmr.sum", 64, &p))) return rc;
+    d_sum = (double *)p;
+    if ((rc = dz_scratch(ctx, "lsmr.w", n * 4, &p))) return rc;
+    wbuf = (float *)p;
+    double hm = (double)m;
+    DZ_HIP(hipMemcpyAsync(d_sum, &hm, 8, hipMemcpyHostToDevice, ctx->stream));
+    DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(&hm, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    m_glob = (int64_t)hm;
+  }
+  int localVecs = localSize < 0 ? 0 : localSize;
+  if (m_glob < localVecs) localVecs = (int)m_glob;
+  if (n < localVecs) localVecs = (int)n;
   float *u, *v, *h, *hbar, *localV = nullptr, *d_scal;
   double *part, *part2;
   if ((rc = dz_scratch(ctx, "lsmr.u", m * 4, &p))) return rc;
@@ -835,8 +905,15 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   d_scal = (float *)p;  // [0] = last norm (beta or alpha), kept on the device for the next kernel
   float *h_scal;
   DZ_HIP(hipHostMalloc((void **)&h_scal, 64));
-  auto norm_to_host = [&](const double *pp, int np, float *res) -> int {
-    hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, (double *)nullptr);
+  // rowwise = the vector is sharded by rows (u): its squared norm is summed over the ranks first
+  auto norm_to_host = [&](const double *pp, int np, float *res, bool rowwise = false) -> int {
+    if (comm && rowwise) {
+      hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, d_sum);
+      DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
+      hipLaunchKernelGGL(k_sqrt_sum, dim3(1), dim3(1), 0, ctx->stream, d_sum, d_scal);
+    } else {
+      hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, (double *)nullptr);
+    }
     DZ_HIP(hipMemcpyAsync(h_scal, d_scal, 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
     *res = h_scal[0];
@@ -853,10 +930,18 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     hipEvent_t a = ctx->ev0, bq = ctx->ev1;
     DZ_HIP(hipEventRecord(a, ctx->stream));
     int r;
-    if (!transpose)
+    if (!transpose) {
       r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
-    else
+    } else if (!comm) {
       r = launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t);
+    } else {   // w = A_p^T u_p ; all-reduce ; v = w + sign*beta*v
+      DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
+      r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr);
+      if (r) return r;
+      DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
+      hipLaunchKernelGGL(k_axpby_norm, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, v, beta_p, sign, part);
+      gn_t = bn;
+    }
     if (r) return r;
     DZ_HIP(hipEventRecord(bq, ctx->stream));
     DZ_HIP(hipEventSynchronize(bq));
@@ -875,7 +960,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   DZ_HIP(hipMemsetAsync(hbar, 0, n * 4, ctx->stream));
   hipLaunchKernelGGL(k_sumsq, dim3(bm), dim3(VB), 0, ctx->stream, m, u, part);
   float alpha = 0.0f, beta = 0.0f;
-  if ((rc = norm_to_host(part, bm, &beta))) return rc;
+  if ((rc = norm_to_host(part, bm, &beta, true))) return rc;
   if (beta > 0.0f) {
     hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
     if ((rc = timed_spmv(true, nullptr, 1.0f))) return rc;  // v = 1*v(=0) + A^T u
@@ -906,7 +991,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
       itn++;
       // u = A v - alpha u ; beta = ||u||   (:484-487; d_scal[0] holds alpha)
       if ((rc = timed_spmv(false, d_scal, -1.0f))) return rc;
-      if ((rc = norm_to_host(part, gm, &beta))) return rc;
+      if ((rc = norm_to_host(part, gm, &beta, true))) return rc;
       if (beta > 0.0f) {
         hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
         if (localOrtho) {  // localVEnqueue :723-731

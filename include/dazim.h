@@ -191,6 +191,16 @@ int dazim_rays_build_G_joint(dazim_ctx *ctx, int nx, int ny, int nz, float goxd,
 /* = aprod (inv/aprod.f90:7): mode 1: y(m) += A*x(n) ; mode 2: x(n) += A^T*y(m)                    */
 int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y);
 
+/* ---- multi-GPU solve: rows of [G; L] sharded over ranks (one process per GPU), SURVEY 8e -----------------------
+ * dazim_comm_unique_id: rank 0 makes the 128-byte RCCL id and hands it to the other ranks (any transport: MPI,
+ * torch.distributed, a file); dazim_comm_init: every rank joins with the same id (ncclCommInitRank on the ctx's device).
+ * While a communicator is attached, dazim_lsmr treats A and b as THIS rank's row shard of one global system: per iteration
+ * one scalar all-reduce for ||u|| and one ncclAllReduce(sum) of the n fp32 of A_p^T u_p on the ctx stream; x, v, h, hbar and
+ * the reorthogonalisation window are replicated, so every rank returns the same x.  dazim_comm_free detaches.       */
+int dazim_comm_unique_id(void *id128);
+int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128);
+int dazim_comm_free(dazim_ctx *ctx);
+
 /* = LSMR (inv/lsmrModule.f90:36), fp32 like the reference; b[m] in, x[n] out.                     */
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,
                float btol, float conlim, int itnlim, int localSize, float *x, int *istop, int *itn,

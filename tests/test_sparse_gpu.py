@@ -136,6 +136,30 @@ def test_lsmr_distributed_driver_on_gpu(ctx, orc):
     A.free()
 
 
+def test_lsmr_native_rccl_single_rank(orc):
+    """dazim_lsmr with an RCCL communicator attached (world size 1: the all-reduces are identities, but every call of
+    the sharded code path runs -- scalar all-reduce of ||u||^2, all-reduce of A_p^T u_p, v = w - beta v): same answer as
+    the plain solver and the oracle.  The N > 1 arithmetic is covered by the gloo twin in tests/test_distributed_cpu.py."""
+    import dazimsurftomo_amd as dz
+    c = dz.Context(0)
+    try:
+        irow, icol, rw, m = random_system(1500, 600, 80, seed=23, tikh_rows=600)
+        b = np.zeros(m, np.float32); b[:1500] = np.random.default_rng(5).standard_normal(1500).astype(np.float32)
+        A = c.csr_from_coo(m, 600, irow, icol, rw)
+        for cfg in ((0.0, 1e-3, 1e-3, 1200.0, 1000, 150), (0.01, 1e-5, 1e-4, 200.0, 500, 10)):
+            x0, i0 = c.lsmr(A, b, *cfg)
+            c.comm_init(1, 0, dz.comm_unique_id())
+            x1, i1 = c.lsmr(A, b, *cfg)
+            c.comm_free()
+            xo, io = orc.lsmr(m, 600, irow, icol, rw, b, *cfg)
+            assert i1["istop"] == io["istop"] and abs(i1["itn"] - io["itn"]) <= 3
+            assert np.linalg.norm(x1 - xo) <= 1e-3 * np.linalg.norm(xo)
+            assert np.linalg.norm(x1 - x0) <= 1e-3 * np.linalg.norm(x0)
+        A.free()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("n", [3000, 45000])
 def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n):
     """>= 4 M entries: A*x runs with x staged in LDS (n <= 38 K) and A^T*y in the fixed-point scatter
