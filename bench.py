@@ -179,6 +179,9 @@ def main():
     if use_dist:
         dist.barrier()
     ctx = dz.Context(local)
+    for kv in os.environ.get("DAZIM_OPTS", "").split(","):   # tuning experiments: DAZIM_OPTS=rays.wg_per_cu=4,fmm.wg_per_cu=6
+        if "=" in kv:
+            ctx.set_option(*kv.split("="))
     # N > 1: the row-sharded LSMR.  Default: the Python driver over torch.distributed (backend nccl = RCCL).
     # DAZIM_LSMR_NATIVE=1: the same algorithm inside the C library with its own RCCL communicator (dazim_comm_init).
     native = use_dist and os.environ.get("DAZIM_LSMR_NATIVE") == "1"

@@ -50,6 +50,7 @@ struct RayArgs {
   float *lval;             // [nray][LK] (x3 in joint mode) their fdm (, fdmc, fdms) values
   float *fdm_scratch;      // [nwg*4][(nvx+2)*(nvz+2)] (x3 in joint mode): one Frechet grid slot per 16-lane group
   int LK;
+  int lcap;                // LDS cell-list capacity per ray
   int keep_small;          // 1: keep every non-zero row entry of the |fdm| >= ftol cells (the forward program's dense GGc/GGs,
                            // fwd/FwdTraveltimeCPS.f90:694-712); 0: the inversion's second |row| > ftol threshold
   const long *rowptr;      // [nray+1] (emit pass in)
@@ -164,14 +165,15 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // one cell per lane, and written back when the ray moves to another B-spline cell (every ~10 steps),
 // so every cell still sees its contributions in the reference's order (fdm = r1 + fdm).
 template <bool EMIT, bool AZIM>
-__global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][nvx*nvz] cell lists
+__global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][lcap] cell lists
   const dazim_geom g = A.g;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const int lm = gl & 3, ll = gl >> 2;  // this lane's (m,l) of the 4x4 scatter
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
   constexpr int NG = AZIM ? 3 : 1;
-  unsigned short *s_list = s_lists + (size_t)grp * nvx * nvz;
+  const int LC = A.lcap;   // list capacity (<= 1024 so that 12 wavefronts fit a CU); longer lists fall back to a full-grid sweep
+  unsigned short *s_list = s_lists + (size_t)grp * LC;
   float *gfdm = A.fdm_scratch + ((size_t)blockIdx.x * RPW + grp) * nf * NG;
   float *gfdmc = gfdm + nf, *gfdms = gfdm + 2 * nf;
   const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
@@ -427,7 +429,8 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
           keep = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
         }
         const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
-        if (keep) s_list[nlist + __popc(m & ((1u << gl) - 1u))] = (unsigned short)c;
+        const int pos = nlist + __popc(m & ((1u << gl) - 1u));
+        if (keep && pos < LC) s_list[pos] = (unsigned short)c;
         nlist += __popc(m);
       }
     }
@@ -452,16 +455,21 @@ __global__ __launch_bounds__(64) void rays_kernel(RayArgs A) {
     long cnt = 0;
     const long rstart = EMIT ? A.rowptr[ray] : 0;
     const int nparpi = nvx * nvz * (A.nz - 1);
+    const bool lovf = nlist > LC;                       // list did not fit: sweep the whole grid instead (rare)
+    const int ntot = lovf ? nvz * nvx : nlist;
     for (int blk = 0; blk < NG; blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
       for (int k = 1; k <= A.nz - 1; k++) {
-        for (int base = 0; base < nlist; base += GP) {
+        for (int base = 0; base < ntot; base += GP) {
           const int li = base + gl;
           bool keep = false;
           float rowv = 0.0f;
           int nn = 0;
-          if (li < nlist) {
-            const int c = s_list[li];
-            const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          bool cell = li < ntot;
+          int c = 0;
+          if (cell) c = lovf ? li : s_list[li];
+          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          if (cell && lovf) cell = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
+          if (cell) {
             const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
             if (blk == 0) {
               const float fd = gfdm[kk * ldf + jj];
@@ -576,14 +584,22 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
   A.col = nullptr;
-  const size_t lds = (size_t)g.nvx * g.nvz * 2 * 4 + 16;   // four cell lists (one per ray of the wavefront)
+  A.lcap = g.nvx * g.nvz < 1024 ? g.nvx * g.nvz : 1024;
+  const size_t lds = (size_t)A.lcap * 2 * 4 + 16;   // four cell lists (one per ray of the wavefront)
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)(160 * 1024 / (lds + 256));
+  {   // resident workgroups per CU are limited by LDS or by registers (3 wavefronts per SIMD): persistent workgroups beyond
+      // that only queue up behind the resident ones and unbalance the XCD-ordered ray ranges
+    int occ = 0;
+    const void *kf = joint ? (const void *)rays_kernel<false, true> : (const void *)rays_kernel<false, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, 64, lds) == hipSuccess && occ > 0 && occ < per_cu) per_cu = occ;
+  }
   if (per_cu > 16) per_cu = 16;
   if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS cell lists");
+  if (ctx->opts.count("rays.wg_per_cu") && ctx->opts["rays.wg_per_cu"] > 0 && ctx->opts["rays.wg_per_cu"] < per_cu) per_cu = ctx->opts["rays.wg_per_cu"];
   long nwg = (long)ctx->num_cu * per_cu;
   if (nwg > (nray + 3) / 4) nwg = (nray + 3) / 4;
   if (nwg >= 8) nwg -= nwg % 8;   // the XCD-aware ray order wants a multiple of 8
