@@ -101,6 +101,31 @@ def test_fmm_properties_full_size(ctx):
         assert ttn[f].max() < 14.0 * 111.2 * 1.5 / 2.5
 
 
+def test_fmm_homogeneous_medium_great_circle(ctx):
+    """known-answer test without any reference code: in a homogeneous medium (c = 3.5 km/s) the first-arrival time is the
+    great-circle distance on the 6371 km sphere divided by c.  The mixed-order scheme with the refined source grid is good to a
+    fraction of a per cent (0.25 deg cells / 5 nodes per cell): measured 0.07 % in the mean and 1.0 % at worst beyond 50 km;
+    bars 0.2 % / 1.5 %."""
+    nx = ny = 54
+    c = 3.5
+    pv = np.full((1, nx * ny), c, np.float64)
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, 6, seed=21)
+    sx, sz = synth.radians(lat, lon)
+    out = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, sx, sz, np.ones(6, np.int32), want_refined=False)
+    g = out["geom"]
+    colat = g.gox + g.dnx * np.arange(g.nnx)          # node (ix, iz): colatitude gox + (ix-1) dnx, longitude goz + (iz-1) dnz
+    lonr = g.goz + g.dnz * np.arange(g.nnz)
+    CO, LO = np.meshgrid(colat, lonr, indexing="ij")
+    for f in range(6):
+        la1, la2 = np.pi / 2 - float(sx[f]), np.pi / 2 - CO
+        a = np.sin((la2 - la1) / 2) ** 2 + np.cos(la1) * np.cos(la2) * np.sin((LO - float(sz[f])) / 2) ** 2
+        dist = 6371.0 * 2 * np.arctan2(np.sqrt(a), np.sqrt(1 - a))
+        t = out["ttn"][f].astype(np.float64)
+        far = dist > 50.0
+        rel = np.abs(t[far] - dist[far] / c) / (dist[far] / c)
+        assert rel.max() <= 1.5e-2 and rel.mean() <= 2e-3, (f, rel.max(), rel.mean())
+
+
 def test_fmm_heap_spill_paths(ctx, orc):
     """narrow band larger than the LDS heap: with a 64-slot heap every 71x71 field overflows, is
     flagged by the fast kernel and redone by the HBM-spill instantiation -- results stay bit-exact;
