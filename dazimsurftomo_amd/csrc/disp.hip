@@ -126,10 +126,9 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     const double p = ra * dpth, q = rb * dpth;
     double w, x, y, z, cosp, cosq, sinp, sinq, fac, pex = 0.0, sex = 0.0;
     if (wvno < xka) {
-      sinp = sin(p);
+      sincos(p, &sinp, &cosp);   // one argument reduction for both
       w = sinp / ra;
       x = -ra * sinp;
-      cosp = cos(p);
     } else if (wvno == xka) {
       cosp = 1.0;
       w = dpth;
@@ -144,10 +143,9 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
       x = ra * sinp;
     }
     if (wvno < xkb) {
-      sinq = sin(q);
+      sincos(q, &sinq, &cosq);
       y = sinq / rb;
       z = -rb * sinq;
-      cosq = cos(q);
     } else if (wvno == xkb) {
       cosq = 1.0;
       y = dpth;
