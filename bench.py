@@ -16,6 +16,10 @@ The JSON line also carries `roofline` for the dominant kernel (the eikonal kerne
 its HBM fraction is reported for transparency, not as a target), `spmv` (the HBM-bound kernel the
 40 % target applies to) and `cpu_baseline` (the oracle = plain-C port of the reference, 1 thread, on
 a bounded sample of the same workload on this box's host cores).
+
+Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_LSMR_NATIVE=1 makes the N > 1
+solve use the RCCL path inside the library instead of the torch.distributed driver; DAZIM_BENCH_FORCE_DIST=1 takes the
+multi-rank code path with a single rank.
 """
 import argparse
 import json
