@@ -99,9 +99,10 @@ def test_example_test4_yunnan_joint_5_iterations(tmp_path):
     (tmp_path / "MOD").write_text(str(g["mod"]))
     out = subprocess.run([EXE, "para.in"], cwd=tmp_path, timeout=1500, capture_output=True, text=True)
     assert out.returncode == 0 and "Program finishes successfully" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
-    final = np.loadtxt(tmp_path / "DSurfTomo.inv")[:, 3].reshape(nz, ny, nx)
+    # fixed-width columns (5f8.4 / 8f10.4): depths >= 100 km fill their field and touch the previous column, like in the reference
+    final = np.genfromtxt(tmp_path / "DSurfTomo.inv", delimiter=[8, 8, 8, 8])[:, 3].reshape(nz, ny, nx)
     assert np.abs(final - g["models"][-1]).max() <= 2e-3
-    az = np.loadtxt(tmp_path / "Gc_Gs_model.inv")
+    az = np.genfromtxt(tmp_path / "Gc_Gs_model.inv", delimiter=[10] * 8)
     gc = az[:, 6].reshape(nz - 1, ny - 2, nx - 2)
     gs = az[:, 7].reshape(nz - 1, ny - 2, nx - 2)
     assert np.abs(g["gc"]).max() * 100 > 1.0
