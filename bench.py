@@ -138,7 +138,27 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
     t_field = t_f / nf
     t_ray = t_r / max(nr, 1)
     per_field = t_field + rays_per_field * t_ray + t_disp_col * ncolumns / nfield_total
+    # when the flang build of the unmodified reference travelled with the snapshot (oracle/_ref), time its own routines on a
+    # few of the same items: the port is bit-identical to it, this shows that it is also as fast (1 thread)
+    ref_extra = {}
+    try:
+        os.environ["OMP_NUM_THREADS"] = "1"
+        from oracle.pyoracle import Ref
+        if Ref.available():
+            ref = Ref()
+            t0 = time.perf_counter()
+            ref.depthkernel(np.ascontiguousarray(sub[:, :, :2]), DEPZ, PERIODS, MINTHK)
+            ref_extra["reference_depthkernel_columns_per_s"] = 2.0 / (time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            nrf = 0
+            for f in range(0, nfield_total, max(1, nfield_total // 12)):
+                ref.fmm_field(NX, NY, GOXD, GOZD, DV, DV, pv_maps[per[f] - 1], scx[f], scz[f])
+                nrf += 1
+            ref_extra["reference_fmm_fields_per_s"] = nrf / (time.perf_counter() - t0)
+    except Exception as e:   # the reference build is optional equipment
+        ref_extra["reference_note"] = f"oracle/_ref not usable here: {e}"
     return {
+        **ref_extra,
         "value": 1.0 / per_field, "unit": "fields/s", "cores": 1, "kind": "port",
         "sample": f"{ncol_s} columns of depthkernel (73 curves x 16 periods each), {nf} eikonal fields 256x256, "
                   f"{nr} rays traced (row assembly excluded); forward time per field = fmm + {rays_per_field} rays + "
