@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py -- the DAzimSurfTomo hot path on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--sources S] [--receivers R] [--no-cpu]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--sources S] [--receivers R] [--no-cpu] [--workload s128|s256|s512]
 
 One "step" = one pass of the hot path over the S-256 synthetic batch: dispersion +
 depth kernels for every model column, 16 periods x S sources eikonal fields on the 256x256 grid,
@@ -45,6 +45,22 @@ BYTES_PER_FIELD = 256 * 256 * 8 + 129 * 129 * 8   # read veln + write ttn, coars
 PROFILED = {"source": "profiles/r1_pmc_hbm_traffic.md",
             "fmm_traffic_bytes_per_field": 68.2e6,
             "spmv_ax_traffic_per_nnz": 8.20, "spmv_aty_traffic_per_nnz": 8.68}
+
+
+WORKLOADS = {   # name -> (nx = ny, periods); the metric is quoted on S-256, the others are the parity-test sizes
+    "s128": (28, np.arange(5, 41, 5, dtype=np.float64)),      # 126 x 126 nodes, 8 periods
+    "s256": (54, np.arange(5, 37, 2, dtype=np.float64)),      # 256 x 256 nodes, 16 periods
+    "s512": (105, np.arange(5, 37, 1, dtype=np.float64)),     # 511 x 511 nodes, 32 periods (the 8-GPU config: 1000 sources per GPU)
+}
+
+
+def set_workload(name):
+    global NX, NY, PERIODS, BYTES_PER_FIELD
+    NX = NY = WORKLOADS[name][0]
+    PERIODS = WORKLOADS[name][1]
+    nn = (NX - 3) * 5 + 1
+    BYTES_PER_FIELD = nn * nn * 8 + 129 * 129 * 8
+    return nn
 
 
 def s256_model(seed=20250929):
@@ -160,7 +176,7 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
     return {
         **ref_extra,
         "value": 1.0 / per_field, "unit": "fields/s", "cores": 1, "kind": "port",
-        "sample": f"{ncol_s} columns of depthkernel (73 curves x 16 periods each), {nf} eikonal fields 256x256, "
+        "sample": f"{ncol_s} columns of depthkernel (73 curves x {kmax} periods each), {nf} eikonal fields {g.nnx}x{g.nnz}, "
                   f"{nr} rays traced (row assembly excluded); forward time per field = fmm + {rays_per_field} rays + "
                   f"dispersion share of {ncolumns} columns / {nfield_total} fields",
         "fmm_fields_per_s": 1.0 / t_field, "rays_per_s": 1.0 / t_ray, "depthkernel_columns_per_s": 1.0 / t_disp_col,
@@ -176,7 +192,10 @@ def main():
     ap.add_argument("--receivers", type=int, default=32)
     ap.add_argument("--lsmr-iters", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s256")
     a = ap.parse_args()
+    nnodes = set_workload(a.workload)
+    calibrated = a.workload == "s256"      # the PMC traffic figures in profiles/ were collected on S-256
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -304,25 +323,26 @@ def main():
             "value": total_fields / (dt / a.steps), "unit": "fields/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"S-256: 54x54x12 model -> 256x256 nodes, 16 periods 5..35 s, {a.sources} sources x "
+            "config": {"workload": f"S-{ {'s128': 128, 's256': 256, 's512': 512}[a.workload] }: {NX}x{NY}x12 model -> {nnodes}x{nnodes} nodes, "
+                                   f"{len(PERIODS)} periods {PERIODS[0]:g}..{PERIODS[-1]:g} s, {a.sources} sources x "
                                    f"{rays_per_field} receivers per GPU ({nfield} fields, {nray} rays), "
                                    f"{a.lsmr_iters} LSMR iterations", "fields_per_gpu": nfield, "rays_per_gpu": nray},
             "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fmm_gbs / HBM_PEAK_GBS,
-                         "traffic": PROFILED["fmm_traffic_bytes_per_field"] * nfield,
+                         "traffic": PROFILED["fmm_traffic_bytes_per_field"] * nfield if calibrated else None,
                          "note": "issue/latency-bound by the serial heap order of fast marching, not by HBM; "
                                  f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
                                  "FETCH_SIZE+WRITE_SIZE of " + PROFILED["source"] + " scaled to this launch (8-byte "
                                  "accesses: raw counter values, the gfx950 x2 read correction is only calibrated for "
                                  "16-byte streams)"},
-            "spmv": {"kernels": {"Ax": "spmv_rows_ldsx", "ATy": "spmvT_scatter + k_scatter_combine"}, "bound": "hbm",
+            "spmv": {"kernels": {"Ax": "spmv_rows_ldsx" if n <= 38 * 1024 else "spmv_rows", "ATy": "spmvT_scatter + k_scatter_combine"}, "bound": "hbm",
                      "unit": "GB/s", "peak": HBM_PEAK_GBS,
                      "Ax": {"us": stats["spmv_s"] * 1e6, "achieved": b_ax / stats["spmv_s"] / 1e9,
                             "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS,
-                            "traffic": PROFILED["spmv_ax_traffic_per_nnz"] * nnz},
+                            "traffic": PROFILED["spmv_ax_traffic_per_nnz"] * nnz if calibrated else None},
                      "ATy": {"us": stats["spmvt_s"] * 1e6, "achieved": b_aty / stats["spmvt_s"] / 1e9,
                              "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS,
-                             "traffic": PROFILED["spmv_aty_traffic_per_nnz"] * nnz},
+                             "traffic": PROFILED["spmv_aty_traffic_per_nnz"] * nnz if calibrated else None},
                      "m": m, "n": n, "nnz": nnz},
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
