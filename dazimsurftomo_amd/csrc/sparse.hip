@@ -903,8 +903,17 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   part2 = (double *)p;
   if ((rc = dz_scratch(ctx, "lsmr.scal", 64, &p))) return rc;
   d_scal = (float *)p;  // [0] = last norm (beta or alpha), kept on the device for the next kernel
-  float *h_scal;
-  DZ_HIP(hipHostMalloc((void **)&h_scal, 64));
+  struct Guard {   // pinned scalars + the two timing events, released on every exit path
+    float *h = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~Guard() {
+      if (e0) (void)hipEventDestroy(e0);
+      if (e1) (void)hipEventDestroy(e1);
+      if (h) (void)hipHostFree(h);
+    }
+  } guard;
+  DZ_HIP(hipHostMalloc((void **)&guard.h, 64));
+  float *h_scal = guard.h;
   // rowwise = the vector is sharded by rows (u): its squared norm is summed over the ranks first
   auto norm_to_host = [&](const double *pp, int np, float *res, bool rowwise = false) -> int {
     if (comm && rowwise) {
@@ -920,9 +929,9 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     return 0;
   };
   const int bn = nblk(n, NPART), bm = nblk(m, NPART);
-  hipEvent_t e0, e1;
-  DZ_HIP(hipEventCreate(&e0));
-  DZ_HIP(hipEventCreate(&e1));
+  DZ_HIP(hipEventCreate(&guard.e0));
+  DZ_HIP(hipEventCreate(&guard.e1));
+  hipEvent_t e0 = guard.e0, e1 = guard.e1;
   DZ_HIP(hipEventRecord(e0, ctx->stream));
   double t_spmv = 0, t_spmvt = 0;
   int n_spmv = 0, n_spmvt = 0;
@@ -1087,9 +1096,6 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   ctx->ksec["lsmr"] = ms * 1e-3;
   ctx->ksec["spmv"] = n_spmv ? t_spmv / n_spmv : -1.0;
   ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipHostFree(h_scal);
   if (istop_o) *istop_o = istop;
   if (itn_o) *itn_o = itn;
   if (normA_o) *normA_o = normA;
