@@ -282,7 +282,7 @@ struct Heap {
   // path copies its entry into its parent slot.  Same comparisons, same final array as the sequential loop.
   // A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child tail.
   // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
-  // a moved pending neighbour n leaves its new slot in nbq[n] (LDS, zeroed by the caller).
+  // where a pending neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
   static constexpr int NSTEP = 4;   // 3 levels each: reaches slot 4095
   __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int *nbq, int (&cnode)[NSTEP],
                                                int (&cslot)[NSTEP], int &fin_node, int &fin_slot) {
@@ -323,7 +323,7 @@ struct Heap {
     for (int b = 0; b < NSTEP; b++) {
       if (b > 0 && __ballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
       // straight-line code: lanes with nothing to read use slot 0 (never a heap entry), lanes with nothing
-      // to move write their entry to slot 0 and their "neighbour slot" to the spare nbq[4]
+      // to move write their entry to slot 0
       const int slot = (p << d) + o;
       const bool valid = active && slot <= ntr;
       const int rs = valid ? slot : 0;
@@ -341,8 +341,6 @@ struct Heap {
       const int nd = NodeCodec<NT>::dec(c);
       cnode[b] = nd;
       cslot[b] = dst;
-      const int which = nd == nbn[0] ? 0 : (nd == nbn[1] ? 1 : (nd == nbn[2] ? 2 : (nd == nbn[3] ? 3 : 4)));
-      nbq[mine ? which : 4] = dst;
       const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
         const int rt = 33 - __clz(mb);                    // deepest entry that moved: the hole is there now
@@ -510,13 +508,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       nbm[n] = 0;
     }
     int mynode = 0, myslot = 0, nmoves = 0;
+    const int ntr_old = H.ntr;                               // slot of the entry the pop drops into the hole
     int cnode[Heap<CAP, SPILL, NT>::NSTEP], cslot[Heap<CAP, SPILL, NT>::NSTEP], fin_node = 0, fin_slot = 0;
     PROF(0);
     if (SPILL) {
       H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
     } else {
-      if (gl < 4) nbq[gl] = 0;
-      cbar();
       H.pop_root_par(lane, nbn, nbq, cnode, cslot, fin_node, fin_slot);
       cbar();
     }
@@ -558,10 +555,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       // done by the owner lanes.  A parent that is itself an earlier neighbour (m < nb) is compared with
       // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
       const bool owner = q == 0;
-      int mvd = nbq[nb];                                   // new slot if the sift-down moved this neighbour
+      // Did the sift-down move this neighbour's heap entry?  The hole went from slot 1 down to fin_slot and every entry on
+      // that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its ancestors (except the
+      // root); the last entry of the old heap is the one that was dropped into the hole.
       const int mynode = (nix << 16) | niz;
-      if (fin_slot > 0 && fin_node == mynode) mvd = fin_slot;
-      if (stfix > 0 && mvd > 0) stfix = mvd;
+      if (stfix > 1 && fin_slot > 0) {
+        const int dP = 31 - __clz(fin_slot), ds = 31 - __clz(stfix);
+        if (stfix == ntr_old) stfix = fin_slot;
+        else if (ds <= dP && (fin_slot >> (dP - ds)) == stfix) stfix >>= 1;
+      }
       const bool act = stfix != 0, isnew = stfix < 0;
       const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
       const int cnt = __popc(newb);
@@ -646,12 +648,29 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   H.ovf = A.ovf + slot * A.ovfcap;
   H.g0 = gl == 0;
 
+  // Work queue: the field list (sorted by period on the host) is cut into eight contiguous ranges, one per XCD (workgroup b
+  // runs on XCD b % 8), so that the fields an XCD marches share one or two velocity grids and these stay in that XCD's L2;
+  // a workgroup whose range is drained steals from the next ranges.
+  const unsigned nquad = ((unsigned)A.nfield + FPW - 1) / FPW;
+  int chunk = (int)(blockIdx.x & 7);
   for (;;) {
     __syncthreads();
-    if (lane == 0) s_base = atomicAdd(A.counter, (unsigned)FPW);
+    if (lane == 0) {
+      unsigned found = 0xffffffffu;
+      for (int tried = 0; tried < 8; tried++) {
+        const unsigned c0 = (nquad * (unsigned)chunk >> 3) * FPW, c1 = (nquad * (unsigned)(chunk + 1) >> 3) * FPW;
+        const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], (unsigned)FPW) : 0xffffffffu;
+        if (b < c1 - c0) {
+          found = c0 + b;
+          break;
+        }
+        chunk = (chunk + 1) & 7;
+      }
+      s_base = found;
+    }
     __syncthreads();
     const unsigned fbase = s_base;
-    if (fbase >= (unsigned)A.nfield) break;
+    if (fbase == 0xffffffffu) break;
     const int q = (int)fbase + grp;
     if (q < A.nfield) {
       const int f = A.flist ? A.flist[q] : q;   // the four groups run the same phases on their own field (SIMT across groups)
@@ -868,6 +887,21 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.counter = (unsigned *)p;
   A.status = d_status;
   A.flist = nullptr;
+  std::vector<int> order(nfield);
+  {   // stable counting sort of the fields by period (the list the XCD ranges are cut from)
+    std::vector<int> hper(nfield);
+    DZ_HIP(hipMemcpyAsync(hper.data(), A.period, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int> cnt(A.kmax + 2, 0);
+    auto key = [&](int i) { const int k = hper[i]; return k < 1 || k > A.kmax ? A.kmax + 1 : k; };
+    for (int i = 0; i < nfield; i++) cnt[key(i)]++;
+    int run = 0;
+    for (size_t k = 0; k < cnt.size(); k++) { const int c = cnt[k]; cnt[k] = run; run += c; }
+    for (int i = 0; i < nfield; i++) order[cnt[key(i)]++] = i;
+    if ((rc = dz_scratch(ctx, "fmm.order", (size_t)nfield * 4 + 16, &p))) return rc;
+    DZ_HIP(hipMemcpyAsync(p, order.data(), (size_t)nfield * 4, hipMemcpyHostToDevice, ctx->stream));
+    A.flist = (const int *)p;
+  }
   const bool force_spill = ctx->opts.count("fmm.force_spill") && ctx->opts["fmm.force_spill"];
   DzTimer t(ctx, "fmm");
   std::vector<int> redo;
