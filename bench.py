@@ -348,7 +348,7 @@ def main():
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],
         }
-        if not a.no_cpu:
+        if not a.no_cpu and world == 1:      # the CPU baseline is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
             out["speedup_vs_cpu_1core_forward"] = (nfield / (stats["disp_s"] + stats["fmm_s"] + stats["rays_s"])) / out["cpu_baseline"]["value"]
         # the JSON line must be the last thing on stdout: flush whatever native libraries (RCCL's version
