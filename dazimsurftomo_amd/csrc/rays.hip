@@ -585,6 +585,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.val = nullptr;
   A.col = nullptr;
   A.lcap = g.nvx * g.nvz < 1024 ? g.nvx * g.nvz : 1024;
+  if (ctx->opts.count("rays.lcap") && ctx->opts["rays.lcap"] >= 16 && ctx->opts["rays.lcap"] < A.lcap) {   // test knob: forces the
+    A.lcap = ctx->opts["rays.lcap"];                                                                         // full-grid sweep and the
+    if (A.LK > A.lcap) A.LK = A.lcap;                                                                        // retrace fallbacks
+  }
   const size_t lds = (size_t)A.lcap * 2 * 4 + 16;   // four cell lists (one per ray of the wavefront)
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -142,3 +142,30 @@ def test_joint_G_matches_oracle(ctx, orc):
         assert np.linalg.norm(blko) > 0
         assert np.linalg.norm(blk - blko) <= 1e-4 * np.linalg.norm(blko), b
     G.free()
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_cell_list_fallbacks_give_the_same_G(ctx, orc, joint):
+    """a 16-entry LDS cell list (option rays.lcap) forces every ray through the full-grid sweep of the row assembly and
+    through the retrace of the emit pass; G and the traveltimes must be identical to the default run, bit for bit"""
+    nx, ny = 17, 17
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    goxd, gozd, dv, minthk = 30.0, 100.0, 0.25, 2.0
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, 2, 8, 5, seed=31)
+    t = np.array([8.0, 20.0])
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    lsen = orc.depthkernel_ti(vel, depz, t, minthk)[1] if joint else None
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G0, t0, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+    a0 = G0.to_coo()
+    G0.free()
+    try:
+        ctx.set_option("rays.lcap", 16)
+        G1, t1, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+        a1 = G1.to_coo()
+        G1.free()
+    finally:
+        ctx.set_option("rays.lcap", 0)
+    assert np.array_equal(t0, t1)
+    assert len(a0[2]) > 1000 and all(np.array_equal(x, y) for x, y in zip(a0, a1))
