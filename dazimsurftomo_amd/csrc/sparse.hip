@@ -514,9 +514,12 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A) {
   A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
   A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
   const int64_t np = A->m * (A->ncb + 1);
-  DZ_HIP(hipMalloc((void **)&A->cbptr, (size_t)np * 8));
-  hipLaunchKernelGGL(k_colblock_ptr, dim3((unsigned)((np + VB - 1) / VB)), dim3(VB), 0, ctx->stream, A->m, A->ncb, A->cbw,
-                     A->rowptr, A->col, A->cbptr);
+  if (np > 0) {   // a matrix without rows (an empty ray batch) has no block pointers
+    DZ_HIP(hipMalloc((void **)&A->cbptr, (size_t)np * 8));
+    hipLaunchKernelGGL(k_colblock_ptr, dim3((unsigned)((np + VB - 1) / VB)), dim3(VB), 0, ctx->stream, A->m, A->ncb, A->cbw,
+                       A->rowptr, A->col, A->cbptr);
+    DZ_HIP(hipGetLastError());
+  }
   int rc;
   void *p;
   if ((rc = dz_scratch(ctx, "csr.absmax", (NPART + 4) * 4, &p))) return rc;

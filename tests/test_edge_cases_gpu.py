@@ -1,0 +1,53 @@
+"""-m gpu: empty and ragged inputs through the C ABI (the reference has no such tests; its loops simply do not execute:
+inv/CalSurfG.f90:1114-1328 for a period without sources, :1326 for a source without receivers)."""
+import numpy as np
+import pytest
+
+from tests.test_rays_gpu import build_case, flatten
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_field_and_ray_batches(ctx, orc):
+    nx = ny = 12
+    depz = np.array([0.0, 10.0, 30.0], np.float32)
+    vel, *_ = build_case(nx, ny, depz, 1, 4, 2, seed=1)
+    t = np.array([10.0])
+    pv, sen, nf = ctx.depthkernel(vel, depz, t, 2.0)
+    e_f, e_i = np.zeros(0, np.float32), np.zeros(0, np.int32)
+    out = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, e_f, e_f, e_i)
+    assert out["ttn"].shape[0] == 0
+    # one field, no rays at all: an empty matrix with the right column count
+    lat, lon = np.array([29.0], np.float32), np.array([101.0], np.float32)
+    from tests import synth
+    sx, sz = synth.radians(lat, lon)
+    fields = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, sx, sz, np.ones(1, np.int32))
+    G, tpred, nb = ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, sx, sz, np.ones(1, np.int32), e_i, e_f, e_f, sen)
+    assert (G.m, G.n, G.nnz) == (0, (nx - 2) * (ny - 2) * 2, 0) and len(tpred) == 0
+    G.free()
+
+
+def test_ragged_sources_some_without_receivers(ctx, orc):
+    """period 1 has three sources with 3 / 0 / 1 receivers, period 2 has none: same rows as the oracle's CalSurfG"""
+    nx = ny = 13
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    goxd, gozd, dv, minthk = 30.0, 100.0, 0.25, 2.0
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, 2, 6, 3, seed=9)
+    nsrc1[:] = [3, 0]
+    nrc1[0, :3] = [3, 0, 1]
+    t = np.array([8.0, 20.0])
+    rc, rw_o, ir_o, ic_o, ds_o, nb_o = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1,
+                                                    periods, 1_000_000)
+    assert rc == 0 and len(ds_o) == 4
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    assert len(scx) == 3 and len(rx) == 4
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
+    ir, ic, rw = G.to_coo()
+    n = (nx - 2) * (ny - 2) * (len(depz) - 1)
+    D = np.zeros((4, n)); D[ir - 1, ic - 1] = rw
+    Do = np.zeros((4, n)); Do[ir_o - 1, ic_o - 1] = rw_o
+    assert np.abs(D - Do).max() <= 2e-4 and np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
+    G.free()
