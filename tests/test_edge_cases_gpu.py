@@ -51,3 +51,23 @@ def test_ragged_sources_some_without_receivers(ctx, orc):
     Do = np.zeros((4, n)); Do[ir_o - 1, ic_o - 1] = rw_o
     assert np.abs(D - Do).max() <= 2e-4 and np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
     G.free()
+
+
+def test_lsmr_zero_right_hand_side_and_single_column(ctx, orc):
+    """b = 0 leaves x = 0 without iterating (inv/lsmrModule.f90:372-380); a one-column system converges in one step"""
+    from tests.test_sparse_gpu import random_system
+    irow, icol, rw, m = random_system(300, 40, 12, seed=2, tikh_rows=40)
+    A = ctx.csr_from_coo(m, 40, irow, icol, rw)
+    x, info = ctx.lsmr(A, np.zeros(m, np.float32), 0.0, 1e-6, 1e-6, 1e8, 100, 10)
+    xo, io = orc.lsmr(m, 40, irow, icol, rw, np.zeros(m, np.float32), 0.0, 1e-6, 1e-6, 1e8, 100, 10)
+    assert not x.any() and not xo.any() and info["itn"] == io["itn"] == 0 and info["istop"] == io["istop"]
+    A.free()
+    m1 = 50
+    ir = np.arange(1, m1 + 1, dtype=np.int32); ic = np.ones(m1, np.int32)
+    v = np.linspace(0.5, 1.5, m1).astype(np.float32)
+    b = (2.0 * v).astype(np.float32)
+    A = ctx.csr_from_coo(m1, 1, ir, ic, v)
+    x, info = ctx.lsmr(A, b, 0.0, 1e-6, 1e-6, 1e8, 100, 10)
+    xo, io = orc.lsmr(m1, 1, ir, ic, v, b, 0.0, 1e-6, 1e-6, 1e8, 100, 10)
+    assert abs(x[0] - 2.0) < 1e-5 and abs(xo[0] - 2.0) < 1e-5 and info["itn"] == io["itn"]
+    A.free()
