@@ -71,3 +71,27 @@ def test_lsmr_zero_right_hand_side_and_single_column(ctx, orc):
     xo, io = orc.lsmr(m1, 1, ir, ic, v, b, 0.0, 1e-6, 1e-6, 1e8, 100, 10)
     assert abs(x[0] - 2.0) < 1e-5 and abs(xo[0] - 2.0) < 1e-5 and info["itn"] == io["itn"]
     A.free()
+
+
+def test_maximum_layer_count(ctx, orc):
+    """34 knots x 5 sublayers -> 199 refined layers (the reference's NL = 200 arrays, inv/surfdisp96.f:57, inv/tregn96.f): dispersion,
+    finite-difference kernels and TI kernels against the oracle; one knot more is refused like the reference would overrun"""
+    nz = 34
+    depz = (np.arange(nz) * 3.0).astype(np.float32)
+    rng = np.random.default_rng(12)
+    vs1d = 3.0 + 0.015 * depz
+    vel = (vs1d[:, None, None] * (1 + 0.03 * rng.standard_normal((nz, 1, 3)))).astype(np.float32)
+    t = np.array([8.0, 20.0, 45.0])
+    pv, sen, nf = ctx.depthkernel(vel, depz, t, 5.0)
+    pvo, seno = orc.depthkernel(vel, depz, t, 5.0)
+    assert nf == 0 and np.abs(pv - pvo).max() <= 4e-6
+    for a, b in zip(sen, seno):
+        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 2e-4
+    lsen = ctx.ti_kernels(vel, depz, t, 5.0, pvo)
+    _, lo = orc.depthkernel_ti(vel, depz, t, 5.0)
+    assert np.abs(lsen - lo).max() <= 1e-6 * np.abs(lo).max()
+    import dazimsurftomo_amd as dz
+    depz2 = (np.arange(nz + 7) * 3.0).astype(np.float32)
+    vel2 = np.full((nz + 7, 1, 3), 3.5, np.float32)
+    with pytest.raises(dz.DazimError):
+        ctx.depthkernel(vel2, depz2, t, 5.0)
