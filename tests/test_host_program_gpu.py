@@ -121,3 +121,24 @@ def test_joint_inversion_matches_reference_loop(tmp_path):
     # period maps of the 2-psi terms exist for every period and inner cell, with finite phase velocities
     pm = np.loadtxt(tmp_path / "period_Azm_tomo.inv")
     assert pm.shape == (5 * (nx - 2) * (ny - 2), 9) and np.isfinite(pm).all() and (pm[:, 3] > 2.5).all()
+
+
+def test_program_error_behaviour(tmp_path):
+    """the reference STOPs with a message when the data file is missing (inv/Main_Jt.f90:230-235) or a source lies outside the
+    model (inv/CalSurfG.f90:1174-1180); so does the program"""
+    g = np.load(GOLD)
+    import dazimsurftomo_amd as dz
+    dz.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "all"])
+    (tmp_path / "para.in").write_text(str(g["para"]))
+    (tmp_path / "MOD").write_text(str(g["mod"]))
+    out = subprocess.run([EXE, "para.in"], cwd=tmp_path, timeout=120, capture_output=True, text=True)
+    # (a Fortran `STOP 'text'` ends with exit status 0, in the reference too: the message is the contract)
+    assert "unable to open the datafile" in (out.stdout + out.stderr) and "Program finishes successfully" not in out.stdout
+    lines = str(g["data"]).splitlines()
+    assert lines[0].startswith("#")
+    t = lines[0].split()
+    lines[0] = "# %9.4f %9.4f %s 2 0" % (40.0, float(t[2]), t[3])      # 40 N is far outside the 23-26.5 N model
+    (tmp_path / "surf_synth.dat").write_text("\n".join(lines) + "\n")
+    out = subprocess.run([EXE, "para.in"], cwd=tmp_path, timeout=300, capture_output=True, text=True)
+    assert "Source lies outside bounds of model" in out.stdout and "Program finishes successfully" not in out.stdout
