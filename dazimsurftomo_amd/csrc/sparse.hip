@@ -335,6 +335,8 @@ __global__ void k_absmax_finish(const float *part, int np, float *res) {
   if (threadIdx.x == 0) res[0] = v;
 }
 
+// GL = lanes that share one row (64, or 16 for short (row, column block) segments: four rows per wavefront at a time)
+template <int GL>
 __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
                                                           const int64_t *__restrict__ cbptr, const int *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
@@ -345,7 +347,8 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
   const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
   for (int i = threadIdx.x; i < width; i += 64 * SCW) acc[i] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int RPWV = 64 / GL;                        // rows per wavefront and step
+  const int lane = (threadIdx.x & 63) % GL, w = (threadIdx.x >> 6) * RPWV + (threadIdx.x & 63) / GL;
   const int64_t r0 = nrows * chunk / nchunk, r1 = nrows * (chunk + 1) / nchunk;
   // Software-pipelined over rows: the block pointers and y of the NEXT row are requested before the current row is
   // streamed, and two 256-entry groups are in flight per wavefront, so a row costs one memory latency instead of two
@@ -358,8 +361,8 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
     e = cbptr[r * (ncb + 1) + cb + 1];
     yr = y[r];
   }
-  for (; r < r1; r += SCW) {
-    const int64_t rn = r + SCW;
+  for (; r < r1; r += SCW * RPWV) {
+    const int64_t rn = r + SCW * RPWV;
     int64_t sn = 0, en = 0;
     float yn = 0.0f;
     if (rn < r1) {
@@ -370,22 +373,22 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
     if (s != e) {
       int64_t s4 = (s + 3) & ~(int64_t)3;
       if (s4 > e) s4 = e;
-      for (int64_t i = s + lane; i < s4; i += 64) SC_ADD(col[i], val[i]);
+      for (int64_t i = s + lane; i < s4; i += GL) SC_ADD(col[i], val[i]);
       const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
-      for (int64_t i = s4 + 4 * lane; i < e4; i += 512) {
+      for (int64_t i = s4 + 4 * lane; i < e4; i += 8 * GL) {
         const float4 v0 = *reinterpret_cast<const float4 *>(val + i);
         const int4 k0 = *reinterpret_cast<const int4 *>(col + i);
-        const bool two = i + 256 < e4;
+        const bool two = i + 4 * GL < e4;
         float4 v1 = v0;
         int4 k1 = k0;
         if (two) {
-          v1 = *reinterpret_cast<const float4 *>(val + i + 256);
-          k1 = *reinterpret_cast<const int4 *>(col + i + 256);
+          v1 = *reinterpret_cast<const float4 *>(val + i + 4 * GL);
+          k1 = *reinterpret_cast<const int4 *>(col + i + 4 * GL);
         }
         SC_ADD(k0.x, v0.x); SC_ADD(k0.y, v0.y); SC_ADD(k0.z, v0.z); SC_ADD(k0.w, v0.w);
         if (two) { SC_ADD(k1.x, v1.x); SC_ADD(k1.y, v1.y); SC_ADD(k1.z, v1.z); SC_ADD(k1.w, v1.w); }
       }
-      for (int64_t i = e4 + lane; i < e; i += 64) SC_ADD(col[i], val[i]);
+      for (int64_t i = e4 + lane; i < e; i += GL) SC_ADD(col[i], val[i]);
     }
     s = sn;
     e = en;
@@ -561,9 +564,17 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   if (pm > 0) (void)frexp(pm, &e);   // pm = f * 2^e, 0.5 <= f < 1  ->  pm < 2^e
   const double scale = ldexp(1.0, 40 - e);
   const size_t lds = (size_t)A->cbw * 8;
-  DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(spmvT_scatter, dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                     A->n, A->cbptr, A->col, A->val, y, scale, part);
+  // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
+  const bool shortseg = A->nnz < (int64_t)160 * A->m * A->ncb;
+  if (shortseg) {
+    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spmvT_scatter<16>, dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
+                       A->n, A->cbptr, A->col, A->val, y, scale, part);
+  } else {
+    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spmvT_scatter<64>, dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
+                       A->n, A->cbptr, A->col, A->val, y, scale, part);
+  }
   const int nb = nblk(A->n, NPART);
   hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
                      beta_sign, sumsq);

@@ -27,7 +27,7 @@ c1, rw1, ir1, ic1 = orc.tikhonov_iso(nx, ny, nz, dall, 20.0, e, ei, ei); c2, rw2
 G.append_coo(3 * c1, np.concatenate([ir1, ir2 + c1, ir2 + 2 * c1]).astype(np.int32), np.concatenate([ic1, ic2 + nvp, ic2 + 2 * nvp]).astype(np.int32), np.concatenate([rw1, rw2, rw2]))
 b = np.zeros(dall + 3 * c1, np.float32); b[:dall] = (d["obst"] - tpred) * j["w"]
 t0 = time.time(); x, info = ctx.lsmr(G, b, 0.0, 1e-5, 1e-4, 200.0, 500, 10); t1 = time.time()
-print("lsmr %.3fs (kernel %.3f)" % (t1 - t0, ctx.kernel_seconds("lsmr")), info, "ref", j["info"])
+print("lsmr %.3fs (kernel %.3f; per product: A*x %.1f us, A^T*y %.1f us)" % (t1 - t0, ctx.kernel_seconds("lsmr"), ctx.kernel_seconds("spmv") * 1e6, ctx.kernel_seconds("spmvt") * 1e6), info, "ref", j["info"])
 for blk, nm in enumerate(("dVs", "Gc", "Gs")):
     a, r = x[blk * nvp:(blk + 1) * nvp], j["x"][blk * nvp:(blk + 1) * nvp]
     print(nm, "rel-L2 %.2e  max|d| %.2e  max|ref| %.3f" % (np.linalg.norm(a - r) / np.linalg.norm(r), np.abs(a - r).max(), np.abs(r).max()))

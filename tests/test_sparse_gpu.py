@@ -160,12 +160,11 @@ def test_lsmr_native_rccl_single_rank(orc):
         c.close()
 
 
-@pytest.mark.parametrize("n", [3000, 45000])
-def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n):
+@pytest.mark.parametrize("n,m,per_row", [(3000, 8192, 640), (45000, 8192, 640), (45000, 32768, 144)])
+def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n, m, per_row):
     """>= 4 M entries: A*x runs with x staged in LDS (n <= 38 K) and A^T*y in the fixed-point scatter
-    form with 1 (n=3000) or 3 (n=45000) column blocks; both must still agree with the oracle, be
-    reproducible bit for bit, and agree with the gather kernels they replace"""
-    m, per_row = 8192, 640
+    form with 1 (n=3000) or 3 (n=45000) column blocks, a wavefront per row or -- third case, short rows -- 16 lanes per
+    row; both must still agree with the oracle, be reproducible bit for bit, and agree with the gather kernels they replace"""
     rng = np.random.default_rng(n)
     start = rng.integers(0, n, m)
     cols = (start[:, None] + np.cumsum(rng.integers(1, 6, (m, per_row)), axis=1)) % n
