@@ -268,25 +268,35 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
           if (AZIM) { gfdmc[fi] = accc; gfdms[fi] = accs; }
         }
       };
+      // The corner times of the cell the NEXT step starts in are requested as soon as that cell is known (on both grids: which
+      // one applies depends on node states that are still being loaded), so that they travel together with the velocity and
+      // node-state loads of the current step instead of costing a second dependent round trip per step.
+      float tc00, tc01, tc10, tc11, tr00, tr01, tr10, tr11;
+      auto load_corner_times = [&]() {
+        const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
+        tc00 = t[0]; tc01 = t[1]; tc10 = t[nnz]; tc11 = t[nnz + 1];
+        const int qx = ipxr < 1 ? 1 : (ipxr > RM - 1 ? RM - 1 : ipxr), qz = ipzr < 1 ? 1 : (ipzr > RM - 1 ? RM - 1 : ipzr);
+        const float *u = ttnr + (size_t)(qx - 1) * RM + (qz - 1);
+        tr00 = u[0]; tr01 = u[1]; tr10 = u[RM]; tr11 = u[RM + 1];
+      };
+      load_corner_times();
       const long maxrp = (long)nnx * nnz;
       for (long j = 1; j <= maxrp; j++) {
         if (sw == 1) break;
         float dtx, dtz;
         if (igref == 1) {
-          const float *t = ttnr + (size_t)(ipxr - 1) * RM + (ipzr - 1);
-          dtx = t[RM] - t[0];
-          dtx = dtx + t[RM + 1] - t[1];
+          dtx = tr10 - tr00;
+          dtx = dtx + tr11 - tr01;
           dtx = dtx / (2.0f * EARTH * dnxr);
-          dtz = t[1] - t[0];
-          dtz = dtz + t[RM + 1] - t[RM];
+          dtz = tr01 - tr00;
+          dtz = dtz + tr11 - tr10;
           dtz = dtz / (2.0f * EARTH * sinx0 * dnzr);
         } else {
-          const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
-          dtx = t[nnz] - t[0];
-          dtx = dtx + t[nnz + 1] - t[1];
+          dtx = tc10 - tc00;
+          dtx = dtx + tc11 - tc01;
           dtx = dtx / (2.0f * EARTH * dnx);
-          dtz = t[1] - t[0];
-          dtz = dtz + t[nnz + 1] - t[nnz];
+          dtz = tc01 - tc00;
+          dtz = dtz + tc11 - tc10;
           dtz = dtz / (2.0f * EARTH * sinx0 * dnz);
         }
         const float rd1 = sqrtf(dtx * dtx + dtz * dtz);
@@ -310,6 +320,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
         if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; rb = 1; clipx = true; }
         if (ipz < 1) { z1 = goz; ipz = 1; rb = 1; }
         if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; rb = 1; }
+        load_corner_times();
         if (clipx) sinx1 = dz_sinf(x1);   // the next step starts from the clipped point
         float c2psi = 0.0f, s2psi = 0.0f;
         if (AZIM) step_azimuth(x0, z0, x1, z1, c2psi, s2psi);

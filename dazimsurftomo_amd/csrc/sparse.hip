@@ -87,12 +87,9 @@ __global__ __launch_bounds__(64 * WPB) void spmv_rows(int64_t nrows, const int64
 
 // Same product with the dense vector staged in LDS: used when 4*len(x) fits (<= 152 KB), which
 // removes the per-entry cache-line gather that otherwise bounds the product (~1 line/clk/CU).
-// One workgroup of 16 wavefronts per CU.  GL lanes share a row (64, or 16 for matrices of short rows: four rows per
-// wavefront at a time) and the rows of a wavefront are software-pipelined three deep like the scatter kernel below:
-// while row i is gathered and reduced, the entries of row i+1 are in flight and the pointers of row i+2 are requested;
-// prefetch loads are unconditional (a lane with nothing to fetch reads entry 0) so that the waits stay partial.
+// One workgroup of 16 wavefronts per CU, each wavefront a row at a time, two 16-byte loads of
+// values and of indices in flight per lane.
 constexpr int LWPB = 16;
-template <int GL, int NG>
 __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64_t nx, const int64_t *__restrict__ ptr,
                                                            const int *__restrict__ idx, const float *__restrict__ val,
                                                            const float *__restrict__ x, float *__restrict__ out,
@@ -106,59 +103,32 @@ __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64
       for (int64_t j = i; j < nx; j++) xs[j] = x[j];
   }
   __syncthreads();
-  constexpr int RPWV = 64 / GL;
-  const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
-  struct Ptr { int64_t r, s, e; float o; };
-  struct Ent { int64_t r, s4, e4; float o; float4 v[NG]; int4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
-  auto load_ptr = [&](int64_t r) {
-    Ptr p;
-    const int64_t rr = r < nrows ? r : 0;
-    p.r = r;
-    p.s = ptr[rr];
-    p.e = ptr[rr + 1];
-    p.o = out[rr];
-    if (r >= nrows) p.e = p.s;
-    return p;
-  };
-  auto issue = [&](const Ptr &p) {
-    Ent t;
-    t.r = p.r;
-    t.o = p.o;
-    t.s4 = (p.s + 3) & ~(int64_t)3;
-    if (t.s4 > p.e) t.s4 = p.e;
-    t.e4 = t.s4 + ((p.e - t.s4) & ~(int64_t)3);
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      const int64_t i = t.s4 + 4 * lane + (int64_t)g * 4 * GL;
-      const int64_t j = i < t.e4 ? i : 0;
-      t.v[g] = *reinterpret_cast<const float4 *>(val + j);
-      t.k[g] = *reinterpret_cast<const int4 *>(idx + j);
-    }
-    const int64_t ih = p.s + lane, it = t.e4 + lane;   // <= 3 unaligned entries at either end
-    t.hh = ih < t.s4;
-    t.ht = it < p.e;
-    t.hv = val[t.hh ? ih : 0];
-    t.hk = idx[t.hh ? ih : 0];
-    t.tv = val[t.ht ? it : 0];
-    t.tk = idx[t.ht ? it : 0];
-    return t;
-  };
-  auto consume = [&](const Ent &t) {
+  for (int64_t r = (int64_t)blockIdx.x * LWPB + w; r < nrows; r += (int64_t)gridDim.x * LWPB) {
+    const int64_t s = ptr[r], e = ptr[r + 1];
     float acc = 0.0f;
-    if (t.hh) acc += t.hv * xs[t.hk];
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-      const int64_t i = t.s4 + 4 * lane + (int64_t)g * 4 * GL;
-      if (i < t.e4) {
-        acc += t.v[g].x * xs[t.k[g].x];
-        acc += t.v[g].y * xs[t.k[g].y];
-        acc += t.v[g].z * xs[t.k[g].z];
-        acc += t.v[g].w * xs[t.k[g].w];
-      }
+    int64_t s4 = (s + 3) & ~(int64_t)3;
+    if (s4 > e) s4 = e;
+    for (int64_t i = s + lane; i < s4; i += 64) acc += val[i] * xs[idx[i]];
+    const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
+    int64_t i = s4 + 4 * lane;
+    for (; i + 256 < e4; i += 512) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(val + i);
+      const int4 c0 = *reinterpret_cast<const int4 *>(idx + i);
+      const float4 v1 = *reinterpret_cast<const float4 *>(val + i + 256);
+      const int4 c1 = *reinterpret_cast<const int4 *>(idx + i + 256);
+      acc += v0.x * xs[c0.x];
+      acc += v0.y * xs[c0.y];
+      acc += v0.z * xs[c0.z];
+      acc += v0.w * xs[c0.w];
+      acc += v1.x * xs[c1.x];
+      acc += v1.y * xs[c1.y];
+      acc += v1.z * xs[c1.z];
+      acc += v1.w * xs[c1.w];
     }
-    for (int64_t i = t.s4 + 4 * lane + (int64_t)NG * 4 * GL; i < t.e4; i += 4 * GL) {   // long rows
+    for (; i < e4; i += 256) {
       const float4 v = *reinterpret_cast<const float4 *>(val + i);
       const int4 c = *reinterpret_cast<const int4 *>(idx + i);
       acc += v.x * xs[c.x];
@@ -166,30 +136,17 @@ __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64
       acc += v.z * xs[c.z];
       acc += v.w * xs[c.w];
     }
-    if (t.ht) acc += t.tv * xs[t.tk];
-#pragma unroll
-    for (int o = GL / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    if (lane == 0 && t.r < nrows) {
-      const float o = beta * t.o + acc;
-      out[t.r] = o;
+    for (int64_t k = e4 + lane; k < e; k += 64) acc += val[k] * xs[idx[k]];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float o = beta * out[r] + acc;
+      out[r] = o;
       sq += (double)o * (double)o;
     }
-  };
-  const int64_t stride = (int64_t)gridDim.x * LWPB * RPWV;
-  int64_t r = ((int64_t)blockIdx.x * LWPB + w) * RPWV + grp;
-  Ent eC = issue(load_ptr(r));
-  Ptr pB = load_ptr(r + stride);
-  for (; r < nrows; r += stride) {   // (rows differ per 16-lane group when GL = 16: the groups simply diverge at the end)
-    const Ptr pA = load_ptr(r + 2 * stride);
-    const Ent eB = issue(pB);
-    consume(eC);
-    eC = eB;
-    pB = pA;
   }
   if (sumsq) {
     __shared__ double s_sq[LWPB];
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0) s_sq[w] = sq;
+    if (lane == 0) s_sq[w] = sq;
     __syncthreads();
     if (threadIdx.x == 0) {
       double t = 0.0;
@@ -386,15 +343,13 @@ __global__ void k_absmax_finish(const float *part, int np, float *res) {
 // Row steps are dealt round-robin over all wavefronts of the launch (step k goes to workgroup k mod nchunk): G's ray rows hold
 // hundreds to thousands of entries and its Tikhonov rows seven, so contiguous chunks of equal rows or equal entries leave CUs
 // idle, while a counter that hands rows out dynamically costs more in same-address atomics than it saves (both measured).
-#ifndef DZ_SC_NG16
-#define DZ_SC_NG16 2
-#endif
+// (The same pipeline applied to the LDS-staged A*x kernel made it 2 % slower -- that kernel streams whole rows and is bandwidth
+// bound already -- and pipelining fixed-size segments instead of rows made this one 6 % slower; same-box A/B runs.)
 template <int GL, int NG>
 __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
                                                           const int64_t *__restrict__ cbptr, const int *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
-                                                          double scale, long long *__restrict__ part,
-                                                          int unused) {
+                                                          double scale, long long *__restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];
   const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
   const int c0 = cb * cbw;
@@ -408,14 +363,9 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
   // fixed point by the magic-number trick: for |t| < 2^51, the low mantissa bits of t + 1.5*2^52 hold round-to-nearest-even(t);
   // scale is a power of two, so the fused multiply-add rounds exactly like (v*y*scale) + magic would
   constexpr double MAGIC = 6755399441055744.0;
-#ifdef DZ_SC_NOATOM   // (experiment: the kernel without its LDS atomics)
-  float dummy = 0;
-#define SC_ADD(cc, vv, yy) dummy += (vv) * (yy) + (float)(cc)
-#else
 #define SC_ADD(cc, vv, yy)                                                                                        \
   atomicAdd((unsigned long long *)&acc[(cc) - c0],                                                                \
             (unsigned long long)(__double_as_longlong(fma((double)((vv) * (yy)), scale, MAGIC)) - __double_as_longlong(MAGIC)))
-#endif
   struct Ptr { int64_t s, e; float y; };
   struct Ent { int64_t s4, e4, e; float y; float4 v[NG]; int4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
   auto load_ptr = [&](int64_t r) {
@@ -478,9 +428,6 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
     eC = eB;
     pB = pA;
   }
-#ifdef DZ_SC_NOATOM
-  if (dummy == 1.2345f) acc[0] = 1;
-#endif
 #undef SC_ADD
   __syncthreads();
   long long *dst = part + (size_t)chunk * ncols + c0;
@@ -521,23 +468,15 @@ int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx = -1) {
   if (b < 1) b = 1;
   return (int)b;
 }
-// nx = length of the gathered vector; nblocks must come from spmv_blocks(ctx, nrows, nx); ptr_total = ptr[nrows] (entries)
+// nx = length of the gathered vector; nblocks must come from spmv_blocks(ctx, nrows, nx)
 int launch_spmv(dazim_ctx *ctx, int64_t nrows, int64_t nx, const int64_t *ptr, const int *idx, const float *val,
                 const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
-                int nblocks, int64_t ptr_total) {
+                int nblocks) {
   if (use_ldsx(ctx, nrows, nx)) {
     const size_t lds = (size_t)((nx + 3) & ~(int64_t)3) * 4;
-    // matrices of short rows (real data: most of G's rows are 7-entry Tikhonov rows): 16 lanes per row
-    const bool shortrow = nrows > 0 && ptr_total >= 0 && ptr_total < 160 * nrows;
-    if (shortrow) {
-      DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((spmv_rows_ldsx<16, 2>), dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x,
-                         out, beta_p, beta_sign, sumsq);
-    } else {
-      DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL((spmv_rows_ldsx<64, 4>), dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x,
-                         out, beta_p, beta_sign, sumsq);
-    }
+    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(spmv_rows_ldsx, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x, out,
+                       beta_p, beta_sign, sumsq);
   } else {
     hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
                        beta_p, beta_sign, sumsq);
@@ -646,7 +585,7 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
     }
     const int gn = spmv_blocks(ctx, A->n, A->m);
     if (npart) *npart = gn;
-    return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn, A->nnz);
+    return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn);
   }
   int nchunk = ctx->num_cu / A->ncb;
   if (nchunk < 1) nchunk = 1;
@@ -662,13 +601,13 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
   const bool shortseg = A->nnz < (int64_t)160 * A->m * A->ncb;
   if (shortseg) {
-    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16, DZ_SC_NG16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((spmvT_scatter<16, DZ_SC_NG16>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part, 0);
+    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((spmvT_scatter<16, 2>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
+                       A->n, A->cbptr, A->col, A->val, y, scale, part);
   } else {
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmvT_scatter<64, 4>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part, 0);
+                       A->n, A->cbptr, A->col, A->val, y, scale, part);
   }
   const int nb = nblk(A->n, NPART);
   hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
@@ -895,7 +834,7 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
   if ((rc = y.init(ctx, y_u, A->m, true, mode == 1))) return rc;
   if (mode == 1) {
     DzTimer t(ctx, "spmv");
-    if ((rc = launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m, A->n), A->nnz))) return rc;
+    if ((rc = launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m, A->n)))) return rc;
     t.stop();
   } else {
     float ymax = 1.0f;
@@ -1049,7 +988,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     DZ_HIP(hipEventRecord(a, ctx->stream));
     int r;
     if (!transpose) {
-      r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm, A->nnz);
+      r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
     } else if (!comm) {
       r = launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t);
     } else {   // w = A_p^T u_p ; all-reduce ; v = w + sign*beta*v
