@@ -335,52 +335,29 @@ __global__ void k_absmax_finish(const float *part, int np, float *res) {
   if (threadIdx.x == 0) res[0] = v;
 }
 
-// GL = lanes that share one row (64, or 16 for short (row, column block) segments: four rows per wavefront at a time).
-// The kernel is bound by the dependent loads of a row (block pointers and y -> entries -> LDS atomics), not by bandwidth, so it is
-// software-pipelined three deep: while the entries of row i are accumulated, those of row i+1 are in flight and the pointers of
-// row i+2 are requested.  All prefetch loads are unconditional (a lane with nothing to fetch reads entry 0), so that the compiler
-// can count them and wait only for the oldest ones; rows with more than 4*NG*GL aligned entries finish in a plain loop.
-// Row steps are dealt round-robin over all wavefronts of the launch (step k goes to workgroup k mod nchunk): G's ray rows hold
-// hundreds to thousands of entries and its Tikhonov rows seven, so contiguous chunks of equal rows or equal entries leave CUs
-// idle, while a counter that hands rows out dynamically costs more in same-address atomics than it saves (both measured).
-// (The same pipeline applied to the LDS-staged A*x kernel made it 2 % slower -- that kernel streams whole rows and is bandwidth
-// bound already -- and pipelining fixed-size segments instead of rows made this one 6 % slower; same-box A/B runs.)
-template <int GL, int NG>
-__global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
-                                                          const int64_t *__restrict__ cbptr, const int *__restrict__ col,
-                                                          const float *__restrict__ val, const float *__restrict__ y,
-                                                          double scale, long long *__restrict__ part) {
-  extern __shared__ __attribute__((aligned(16))) long long acc[];
-  const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
-  const int c0 = cb * cbw;
-  const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
-  for (int i = threadIdx.x; i < width; i += 64 * SCW) acc[i] = 0;
-  __syncthreads();
-  constexpr int RPWV = 64 / GL;                        // rows per wavefront and step
-  // NG = prefetched float4 groups per lane
-  const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
-  const int64_t r1 = nrows;
-  // fixed point by the magic-number trick: for |t| < 2^51, the low mantissa bits of t + 1.5*2^52 hold round-to-nearest-even(t);
-  // scale is a power of two, so the fused multiply-add rounds exactly like (v*y*scale) + magic would
-  constexpr double MAGIC = 6755399441055744.0;
-#define SC_ADD(cc, vv, yy)                                                                                        \
-  atomicAdd((unsigned long long *)&acc[(cc) - c0],                                                                \
-            (unsigned long long)(__double_as_longlong(fma((double)((vv) * (yy)), scale, MAGIC)) - __double_as_longlong(MAGIC)))
-  struct Ptr { int64_t s, e; float y; };
-  struct Ent { int64_t s4, e4, e; float y; float4 v[NG]; int4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
+// ---- software-pipelined walk over CSR row segments (A^T*y scatter and column-blocked A*x) ----
+// These kernels are bound by the dependent loads of a row (its pointers -> its entries -> the arithmetic), not by bandwidth, so
+// each lane group keeps three rows in flight: while the entries of row i are consumed, those of row i+1 are arriving and the
+// pointers of row i+2 are requested.  All prefetch loads are unconditional (a lane with nothing to fetch reads entry 0), so that
+// the compiler can count them and wait only for the oldest ones; rows with more than 4*NG*GL aligned entries finish in a plain
+// loop.  GL = lanes that share one row (64, or 16 for short segments: four rows per wavefront at a time); rows r_first,
+// r_first + stride, ... below nrows are visited; ptrf(r) -> {s, e, aux} gives the entry range and one per-row float,
+// elemf(column, value, aux) is called for every entry (head, aligned groups, tail: the order of a plain loop over this lane's
+// entries), endf(r, aux) once per row.
+struct RowPtr { int64_t s, e; float aux; };
+template <int GL, int NG, class PtrF, class ElemF, class EndF>
+__device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64_t nrows, int lane, const int *__restrict__ col,
+                                          const float *__restrict__ val, PtrF ptrf, ElemF elemf, EndF endf) {
+  struct Ent { int64_t r, s4, e4; float aux; float4 v[NG]; int4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
   auto load_ptr = [&](int64_t r) {
-    Ptr p;
-    const int64_t rr = r < r1 ? r : 0;                 // (a dummy read past the end)
-    p.s = cbptr[rr * (ncb + 1) + cb];
-    p.e = cbptr[rr * (ncb + 1) + cb + 1];
-    p.y = y[rr];
-    if (r >= r1) p.e = p.s;                            // nothing to do
+    RowPtr p = ptrf(r < nrows ? r : 0);                // (a dummy read past the end)
+    if (r >= nrows) p.e = p.s;                         // nothing to do
     return p;
   };
-  auto issue = [&](const Ptr &p) {
+  auto issue = [&](int64_t r, const RowPtr &p) {
     Ent t;
-    t.e = p.e;
-    t.y = p.y;
+    t.r = r;
+    t.aux = p.aux;
     t.s4 = (p.s + 3) & ~(int64_t)3;
     if (t.s4 > p.e) t.s4 = p.e;
     t.e4 = t.s4 + ((p.e - t.s4) & ~(int64_t)3);
@@ -401,34 +378,65 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
     return t;
   };
   auto consume = [&](const Ent &t) {
-    if (t.hh) SC_ADD(t.hk, t.hv, t.y);
+    if (t.hh) elemf(t.hk, t.hv, t.aux);
 #pragma unroll
     for (int g = 0; g < NG; g++) {
       const int64_t i = t.s4 + 4 * lane + (int64_t)g * 4 * GL;
       if (i < t.e4) {
-        SC_ADD(t.k[g].x, t.v[g].x, t.y); SC_ADD(t.k[g].y, t.v[g].y, t.y);
-        SC_ADD(t.k[g].z, t.v[g].z, t.y); SC_ADD(t.k[g].w, t.v[g].w, t.y);
+        elemf(t.k[g].x, t.v[g].x, t.aux); elemf(t.k[g].y, t.v[g].y, t.aux);
+        elemf(t.k[g].z, t.v[g].z, t.aux); elemf(t.k[g].w, t.v[g].w, t.aux);
       }
     }
     for (int64_t i = t.s4 + 4 * lane + (int64_t)NG * 4 * GL; i < t.e4; i += 4 * GL) {   // long rows
       const float4 v = *reinterpret_cast<const float4 *>(val + i);
       const int4 k = *reinterpret_cast<const int4 *>(col + i);
-      SC_ADD(k.x, v.x, t.y); SC_ADD(k.y, v.y, t.y); SC_ADD(k.z, v.z, t.y); SC_ADD(k.w, v.w, t.y);
+      elemf(k.x, v.x, t.aux); elemf(k.y, v.y, t.aux); elemf(k.z, v.z, t.aux); elemf(k.w, v.w, t.aux);
     }
-    if (t.ht) SC_ADD(t.tk, t.tv, t.y);
+    if (t.ht) elemf(t.tk, t.tv, t.aux);
+    endf(t.r, t.aux);
   };
-  const int64_t stride = (int64_t)nchunk * SCW * RPWV;
-  int64_t r = ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp;
-  Ent eC = issue(load_ptr(r));
-  Ptr pB = load_ptr(r + stride);
-  for (; r < r1; r += stride) {   // (rows differ per 16-lane group when GL = 16: the groups simply diverge at the end)
-    const Ptr pA = load_ptr(r + 2 * stride);
-    const Ent eB = issue(pB);
+  int64_t r = r_first;
+  Ent eC = issue(r, load_ptr(r));
+  RowPtr pB = load_ptr(r + stride);
+  for (; r < nrows; r += stride) {   // (rows differ per 16-lane group when GL = 16: the groups simply diverge at the end)
+    const RowPtr pA = load_ptr(r + 2 * stride);
+    const Ent eB = issue(r + stride, pB);
     consume(eC);
     eC = eB;
     pB = pA;
   }
-#undef SC_ADD
+}
+
+// A^T*y: GL lanes share one (row, column block) segment and walk it with walk_rows.
+// Row steps are dealt round-robin over all wavefronts of the launch (step k goes to workgroup k mod nchunk): G's ray rows hold
+// hundreds to thousands of entries and its Tikhonov rows seven, so contiguous chunks of equal rows or equal entries leave CUs
+// idle, while a counter that hands rows out dynamically costs more in same-address atomics than it saves (both measured).
+// (The same pipeline applied to the LDS-staged A*x kernel made it 2 % slower -- that kernel streams whole rows and is bandwidth
+// bound already -- and pipelining fixed-size segments instead of rows made this one 6 % slower; same-box A/B runs.)
+template <int GL, int NG>
+__global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
+                                                          const int64_t *__restrict__ cbptr, const int *__restrict__ col,
+                                                          const float *__restrict__ val, const float *__restrict__ y,
+                                                          double scale, long long *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) long long acc[];
+  const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
+  const int c0 = cb * cbw;
+  const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
+  for (int i = threadIdx.x; i < width; i += 64 * SCW) acc[i] = 0;
+  __syncthreads();
+  constexpr int RPWV = 64 / GL;                        // rows per wavefront and step
+  const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
+  // fixed point by the magic-number trick: for |t| < 2^51, the low mantissa bits of t + 1.5*2^52 hold round-to-nearest-even(t);
+  // scale is a power of two, so the fused multiply-add rounds exactly like (v*y*scale) + magic would
+  constexpr double MAGIC = 6755399441055744.0;
+  walk_rows<GL, NG>(
+      ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nchunk * SCW * RPWV, nrows, lane, col, val,
+      [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb], cbptr[r * (ncb + 1) + cb + 1], y[r]}; },
+      [&](int c, float v, float yr) {
+        atomicAdd((unsigned long long *)&acc[c - c0],
+                  (unsigned long long)(__double_as_longlong(fma((double)(v * yr), scale, MAGIC)) - __double_as_longlong(MAGIC)));
+      },
+      [](int64_t, float) {});
   __syncthreads();
   long long *dst = part + (size_t)chunk * ncols + c0;
   for (int i = threadIdx.x; i < width; i += 64 * SCW) dst[i] = acc[i];
@@ -444,6 +452,53 @@ __global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__
     for (int k = 0; k < nchunk; k++) t += part[(size_t)k * ncols + c];
     const float o = beta * out[c] + (float)((double)t * inv_scale);
     out[c] = o;
+    sq += (double)o * o;
+  }
+  if (sumsq) block_partial(sq, sumsq);
+}
+
+// A*x for matrices whose x does not fit the LDS (n > 38 K: joint inversions, S-512): the columns are cut at the same block
+// pointers as the scatter kernel, two scatter blocks (<= 38 K floats of x) per workgroup, which removes the per-entry
+// cache-line gather that bounds the plain kernel.  A workgroup owns (row set x column-block pair) and writes the partial
+// dot product of each of its rows to part[pair][row]; k_rows_combine adds the pairs in a fixed order.
+template <int GL, int NG>
+__global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int nset, int npair, int ncb, int cbw, int64_t ncols,
+                                                              const int64_t *__restrict__ cbptr, const int *__restrict__ col,
+                                                              const float *__restrict__ val, const float *__restrict__ x,
+                                                              float *__restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float xblk[];
+  const int set = blockIdx.x / npair, pr = blockIdx.x - set * npair;
+  const int cb0 = 2 * pr, cb1 = (cb0 + 2 < ncb) ? cb0 + 2 : ncb;
+  const int c0 = cb0 * cbw;
+  const int width = (int)((ncols - c0) < 2 * (int64_t)cbw ? (ncols - c0) : 2 * (int64_t)cbw);
+  for (int i = threadIdx.x; i < width; i += 64 * SCW) xblk[i] = x[c0 + i];
+  __syncthreads();
+  constexpr int RPWV = 64 / GL;
+  const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
+  float acc = 0.0f;
+  float *dst = part + (size_t)pr * nrows;
+  walk_rows<GL, NG>(
+      ((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nset * SCW * RPWV, nrows, lane, col, val,
+      [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb0], cbptr[r * (ncb + 1) + cb1], 0.0f}; },
+      [&](int c, float v, float) { acc += v * xblk[c - c0]; },
+      [&](int64_t r, float) {
+        float a = acc;
+#pragma unroll
+        for (int o = GL / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0 && r < nrows) dst[r] = a;
+        acc = 0.0f;
+      });
+}
+// out[r] = beta*out[r] + sum_pairs part[pair][r] ; partial ||out||^2
+__global__ void k_rows_combine(int64_t nrows, int npair, const float *__restrict__ part, float *__restrict__ out,
+                               const float *__restrict__ beta_p, float beta_sign, double *__restrict__ sumsq) {
+  const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
+  double sq = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
+    float t = part[r];
+    for (int k = 1; k < npair; k++) t += part[(size_t)k * nrows + r];
+    const float o = beta * out[r] + t;
+    out[r] = o;
     sq += (double)o * o;
   }
   if (sumsq) block_partial(sq, sumsq);
@@ -599,7 +654,8 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   const double scale = ldexp(1.0, 40 - e);
   const size_t lds = (size_t)A->cbw * 8;
   // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
-  const bool shortseg = A->nnz < (int64_t)160 * A->m * A->ncb;
+  bool shortseg = A->nnz < (int64_t)400 * A->m * A->ncb;   // measured: 16 lanes win at 141 and 296 entries per segment, 64 at 553
+  if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
   if (shortseg) {
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmvT_scatter<16, 2>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
@@ -612,6 +668,44 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   const int nb = nblk(A->n, NPART);
   hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
                      beta_sign, sumsq);
+  DZ_HIP(hipGetLastError());
+  if (npart) *npart = nb;
+  return 0;
+}
+
+bool use_blocked(dazim_ctx *ctx, const dazim_csr *A) {
+  if (ctx->opts.count("spmv.blocked") && !ctx->opts["spmv.blocked"]) return false;
+  return A->cbptr && A->n > LDSX_MAX && A->nnz >= (1 << 22) && A->m >= (int64_t)ctx->num_cu * SCW;
+}
+// y(out, m) = beta*y + A x ; the number of ||out||^2 partials written to sumsq goes to *npart
+int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out, const float *beta_p, float beta_sign,
+                 double *sumsq, int *npart) {
+  if (!use_blocked(ctx, A)) {
+    const int gm = spmv_blocks(ctx, A->m, A->n);
+    if (npart) *npart = gm;
+    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm);
+  }
+  const int npair = (A->ncb + 1) / 2;
+  int nset = ctx->num_cu / npair;
+  if (nset < 1) nset = 1;
+  int rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "spmv.part", (size_t)npair * A->m * 4, &p))) return rc;
+  float *part = (float *)p;
+  const size_t lds = (size_t)A->cbw * 2 * 4;
+  bool shortseg = A->nnz < (int64_t)600 * A->m * npair;    // measured: 16 lanes win at 282 and 519 entries per segment
+  if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
+  if (shortseg) {
+    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((spmv_rows_blocked<16, 2>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
+                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part);
+  } else {
+    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((spmv_rows_blocked<64, 4>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
+                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part);
+  }
+  const int nb = nblk(A->m, NPART);
+  hipLaunchKernelGGL(k_rows_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->m, npair, part, out, beta_p, beta_sign, sumsq);
   DZ_HIP(hipGetLastError());
   if (npart) *npart = nb;
   return 0;
@@ -834,7 +928,7 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
   if ((rc = y.init(ctx, y_u, A->m, true, mode == 1))) return rc;
   if (mode == 1) {
     DzTimer t(ctx, "spmv");
-    if ((rc = launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x.dev, y.dev, nullptr, 1.0f, nullptr, spmv_blocks(ctx, A->m, A->n)))) return rc;
+    if ((rc = launch_spmvA(ctx, A, x.dev, y.dev, nullptr, 1.0f, nullptr, nullptr))) return rc;
     t.stop();
   } else {
     float ymax = 1.0f;
@@ -943,7 +1037,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     localV = (float *)p;
   }
   const int gm = spmv_blocks(ctx, m, n), gn = spmv_blocks(ctx, n, m);
-  int gn_t = gn;   // partial count of the last transposed product
+  int gn_t = gn, gm_t = gm;   // partial counts of the last products
   const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
   if ((rc = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return rc;
   part = (double *)p;
@@ -988,7 +1082,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     DZ_HIP(hipEventRecord(a, ctx->stream));
     int r;
     if (!transpose) {
-      r = launch_spmv(ctx, m, n, A->rowptr, A->col, A->val, v, u, beta_p, sign, part, gm);
+      r = launch_spmvA(ctx, A, v, u, beta_p, sign, part, &gm_t);
     } else if (!comm) {
       r = launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t);
     } else {   // w = A_p^T u_p ; all-reduce ; v = w + sign*beta*v
@@ -1048,7 +1142,7 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
       itn++;
       // u = A v - alpha u ; beta = ||u||   (:484-487; d_scal[0] holds alpha)
       if ((rc = timed_spmv(false, d_scal, -1.0f))) return rc;
-      if ((rc = norm_to_host(part, gm, &beta, true))) return rc;
+      if ((rc = norm_to_host(part, gm_t, &beta, true))) return rc;
       if (beta > 0.0f) {
         hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
         if (localOrtho) {  // localVEnqueue :723-731

@@ -73,7 +73,9 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * the spill kernel.  "rays.keep_small": 1 = dazim_rays_build_G* keep every non-zero entry of the cells with
  * |fdm| >= ftol (what the forward program's dense GGc/GGs hold, fwd/FwdTraveltimeCPS.f90:694-712) instead of
  * applying the inversion's second threshold |row| > ftol (inv/CalSurfG.f90:1353).  "rays.lcap": capacity of the per-ray LDS
- * cell list (default min(cells, 1024)); small values exercise the full-grid-sweep and retrace fallbacks.            */
+ * cell list (default min(cells, 1024)); small values exercise the full-grid-sweep and retrace fallbacks.
+ * "spmv.ldsx", "spmv.blocked", "spmv.scatter": 0 = do not use the LDS-staged A*x (whole x / per column-block pair) or
+ * the fixed-point scatter A^T*y, i.e. fall back to the plain wavefront-per-row gather kernels (tests compare the two). */
 int dazim_set_option(dazim_ctx *ctx, const char *name, int value);
 
 /* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */

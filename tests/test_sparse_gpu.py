@@ -160,11 +160,11 @@ def test_lsmr_native_rccl_single_rank(orc):
         c.close()
 
 
-@pytest.mark.parametrize("n,m,per_row", [(3000, 8192, 640), (45000, 8192, 640), (45000, 32768, 144)])
+@pytest.mark.parametrize("n,m,per_row", [(3000, 8192, 640), (45000, 8192, 640), (45000, 32768, 144), (90000, 8192, 640)])
 def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n, m, per_row):
-    """>= 4 M entries: A*x runs with x staged in LDS (n <= 38 K) and A^T*y in the fixed-point scatter
-    form with 1 (n=3000) or 3 (n=45000) column blocks, a wavefront per row or -- third case, short rows -- 16 lanes per
-    row; both must still agree with the oracle, be reproducible bit for bit, and agree with the gather kernels they replace"""
+    """>= 4 M entries: A*x runs with x staged in LDS (n <= 38 K: whole; above: per pair of column blocks, 2 pairs at
+    n=45000 and 3, the last one half empty, at n=90000) and A^T*y in the fixed-point scatter form with 1, 3 or 5 column
+    blocks, a wavefront per row or -- third case, short rows -- 16 lanes per row; both must still agree with the oracle, be reproducible bit for bit, and agree with the gather kernels they replace"""
     rng = np.random.default_rng(n)
     start = rng.integers(0, n, m)
     cols = (start[:, None] + np.cumsum(rng.integers(1, 6, (m, per_row)), axis=1)) % n
@@ -177,13 +177,15 @@ def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n, m, per_row):
     y = rng.standard_normal(m).astype(np.float32); y /= np.linalg.norm(y)
     outs = {}
     for tag, (ldsx, scat) in {"fast": (1, 1), "gather": (0, 0)}.items():
-        ctx.set_option("spmv.ldsx", ldsx); ctx.set_option("spmv.scatter", scat)
+        ctx.set_option("spmv.ldsx", ldsx); ctx.set_option("spmv.blocked", ldsx); ctx.set_option("spmv.scatter", scat)
         y1 = np.zeros(m, np.float32); ctx.aprod(1, A, x, y1)
+        y1b = np.full(m, 7.0, np.float32); ctx.aprod(1, A, x, y1b)      # y = y + A x
+        assert np.allclose(y1b - 7.0, y1, rtol=0, atol=2e-5 * np.abs(y1).max() + 1e-5), tag
         x2 = np.zeros(n, np.float32); ctx.aprod(2, A, x2, y)
         x3 = np.zeros(n, np.float32); ctx.aprod(2, A, x3, y)
         assert np.array_equal(x2, x3), "A^T y must be reproducible"
         outs[tag] = (y1, x2)
-    ctx.set_option("spmv.ldsx", 1); ctx.set_option("spmv.scatter", 1)
+    ctx.set_option("spmv.ldsx", 1); ctx.set_option("spmv.blocked", 1); ctx.set_option("spmv.scatter", 1)
     y_o = np.zeros(m, np.float32); orc.aprod(1, m, n, x.copy(), y_o, irow, icol, rw)
     x_o = np.zeros(n, np.float32); orc.aprod(2, m, n, x_o, y.copy(), irow, icol, rw)
     for tag in outs:
