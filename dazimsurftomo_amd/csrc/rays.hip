@@ -2,11 +2,12 @@
 // back-tracing with B-spline Frechet weights (rpaths, :1735) and G-row assembly (:1339-1364) for a
 // batch of rays whose eikonal fields are already resident in HBM (output of dazim_fmm_batch).
 //
-// Four rays per wavefront, one per 16-lane group (the kernel is VALU-issue bound, so SIMT across groups
-// quarters the instruction count per ray).  The half-cell stepping is inherently serial and is executed
-// redundantly by the 16 lanes of a group, while the 4x4 B-spline scatter of every sub-segment is spread over
-// them: each lane keeps one cell of the current 4x4 block of the Frechet grid(s) in registers and the block is
-// written back to the ray's grid in HBM scratch only when the ray leaves it.  Touched cells are collected in an
+// Eight rays per wavefront, one per 8-lane group (the kernel is bound by instruction issue and by the dependent
+// loads of a step, so SIMT across groups divides the instruction count per ray and multiplies the loads in flight;
+// measured: 16 lanes per ray 0.094 s, 8 lanes 0.073 s, 4 lanes 0.084 s on the S-256 batch).  The half-cell stepping
+// is inherently serial and is executed redundantly by the lanes of a group, while the 4x4 B-spline scatter of every
+// sub-segment is spread over them: each lane keeps two cells of the current 4x4 block of the Frechet grid(s) in
+// registers and the block is written back to the ray's grid in HBM scratch only when the ray leaves it.  Touched cells are collected in an
 // LDS cell list.  Rows are emitted straight into CSR in the reference's column order (depth-major, then jj,
 // kk) by a count pass, an exclusive scan and an emit pass that reuses the saved cell lists -- no atomics, so G
 // is reproducible.  fp32 without FMA like the reference.
@@ -154,22 +155,24 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   return biv;
 }
 
-constexpr int GP = 16;  // lanes per ray
-constexpr int RPW = 4;  // rays per wavefront
+constexpr int GP = 8;             // lanes per ray
+constexpr int RPW = 64 / GP;      // rays per wavefront
+constexpr int LPR = 16 / GP;      // cells of the 4x4 B-spline block per lane
+constexpr int LSTEP = 4 / LPR;    // ... which are LSTEP rows apart
+constexpr unsigned GMASK = (1u << GP) - 1u;
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier (same-wave ops are in order)
 
-// One 16-lane group per ray, four rays per wavefront (the kernel is VALU-issue bound: ~330 k
-// instructions per ray when one wavefront traced one ray, and all of that work is per-ray scalar
-// work except the 4x4 B-spline scatter, which is exactly 16 lanes wide).  The Frechet grid(s) of a
-// ray live in an HBM scratch slot; the 4x4 block currently being updated is cached in registers,
-// one cell per lane, and written back when the ray moves to another B-spline cell (every ~10 steps),
-// so every cell still sees its contributions in the reference's order (fdm = r1 + fdm).
+// One GP-lane group per ray (~330 k instructions per ray when one wavefront traced one ray, all of it per-ray
+// scalar work except the 4x4 B-spline scatter).  The Frechet grid(s) of a ray live in an HBM scratch slot; the
+// 4x4 block currently being updated is cached in registers, LPR cells per lane, and written back when the ray
+// moves to another B-spline cell (every ~10 steps), so every cell still sees its contributions in the
+// reference's order (fdm = r1 + fdm).
 template <bool EMIT, bool AZIM>
 __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][lcap] cell lists
   const dazim_geom g = A.g;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
-  const int lm = gl & 3, ll = gl >> 2;  // this lane's (m,l) of the 4x4 scatter
+  const int lm = gl & 3, l0 = gl >> 2;  // this lane's cells of the 4x4 scatter: (m, l) = (lm, l0 + q*LSTEP), q < LPR
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
   constexpr int NG = AZIM ? 3 : 1;
   const int LC = A.lcap;   // list capacity (<= 1024 so that 12 wavefronts fit a CU); longer lists fall back to a full-grid sweep
@@ -260,12 +263,17 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
       if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
       // register-cached 4x4 block of the Frechet grid(s): this lane's cell is (bz+ll, bx+lm)
       int cbx = -100, cbz = -100;
-      float acc = 0.0f, accc = 0.0f, accs = 0.0f;
+      float acc[LPR], accc[LPR], accs[LPR];
+#pragma unroll
+      for (int q = 0; q < LPR; q++) acc[q] = accc[q] = accs[q] = 0.0f;
       auto flush = [&]() {
         if (cbx > -100) {
-          const int fi = (cbx + lm) * ldf + (cbz + ll);
-          gfdm[fi] = acc;
-          if (AZIM) { gfdmc[fi] = accc; gfdms[fi] = accs; }
+#pragma unroll
+          for (int q = 0; q < LPR; q++) {
+            const int fi = (cbx + lm) * ldf + (cbz + l0 + q * LSTEP);
+            gfdm[fi] = acc[q];
+            if (AZIM) { gfdmc[fi] = accc[q]; gfdms[fi] = accs[q]; }
+          }
         }
       };
       // The corner times of the cell the NEXT step starts in are requested as soon as that cell is known (on both grids: which
@@ -360,10 +368,15 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
         float vel = vel_at(g, veln, ipxo, ipzo, drx, drz);
         drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
         drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
-        float vi = basis1(drx / dvx, lm), wi = basis1(drz / dvz, ll);  // this lane's vi(m), wi(l)
+        float vi = basis1(drx / dvx, lm), wi[LPR];  // this lane's vi(m), wi(l)
+#pragma unroll
+        for (int q = 0; q < LPR; q++) wi[q] = basis1(drz / dvz, l0 + q * LSTEP);
         int ivxt = ivxo, ivzt = ivzo;
         for (int k = 1; k <= nhp; k++) {
-          const float velo = vel, vio = vi, wio = wi;
+          const float velo = vel, vio = vi;
+          float wio[LPR];
+#pragma unroll
+          for (int q = 0; q < LPR; q++) wio[q] = wi[q];
           if (k > 1) {
             const int cp = (k == 2) ? chp0 : chp1;
             if (cp == 1) ivxt = ivx;
@@ -380,7 +393,8 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
           drx = (rigx - gox) - (float)(ivxt - 1) * dvx;
           drz = (rigz - goz) - (float)(ivzt - 1) * dvz;
           vi = basis1(drx / dvx, lm);
-          wi = basis1(drz / dvz, ll);
+#pragma unroll
+          for (int q = 0; q < LPR; q++) wi[q] = basis1(drz / dvz, l0 + q * LSTEP);
           const float dinc = (k == 1) ? vrk * dpl : (vrk - vrp) * dpl;
           // block of this sub-segment: cells (ivzt-2+l, ivxt-2+m), l,m = 1..4
           const int nbx = ivxt - 1, nbz = ivzt - 1;
@@ -389,19 +403,25 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
             cbar();
             cbx = nbx;
             cbz = nbz;
-            const int fi = (cbx + lm) * ldf + (cbz + ll);
-            acc = gfdm[fi];
-            if (AZIM) { accc = gfdmc[fi]; accs = gfdms[fi]; }
+#pragma unroll
+            for (int q = 0; q < LPR; q++) {
+              const int fi = (cbx + lm) * ldf + (cbz + l0 + q * LSTEP);
+              acc[q] = gfdm[fi];
+              if (AZIM) { accc[q] = gfdmc[fi]; accs[q] = gfdms[fi]; }
+            }
           }
-          const float rdc1 = vi * wi / (vel * vel);
-          const float rdc2 = vio * wio / (velo * velo);
-          float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
-          acc = r1 + acc;
-          if (AZIM) {   // inv/rpathsAzim.f90:580-586
-            r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
-            accc = r1 + accc;
-            r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
-            accs = r1 + accs;
+#pragma unroll
+          for (int q = 0; q < LPR; q++) {
+            const float rdc1 = vi * wi[q] / (vel * vel);
+            const float rdc2 = vio * wio[q] / (velo * velo);
+            float r1 = -(rdc1 + rdc2) * dinc / 2.0f;
+            acc[q] = r1 + acc[q];
+            if (AZIM) {   // inv/rpathsAzim.f90:580-586
+              r1 = -(rdc1 * c2psi + rdc2 * c2psi) * dinc / 2.0f;
+              accc[q] = r1 + accc[q];
+              r1 = -(rdc1 * s2psi + rdc2 * s2psi) * dinc / 2.0f;
+              accs[q] = r1 + accs[q];
+            }
           }
         }
         x0 = x1;
@@ -439,7 +459,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
           const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
           keep = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
         }
-        const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
+        const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & GMASK);
         const int pos = nlist + __popc(m & ((1u << gl) - 1u));
         if (keep && pos < LC) s_list[pos] = (unsigned short)c;
         nlist += __popc(m);
@@ -497,7 +517,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
             keep = A.keep_small ? (rowv != 0.0f) : (fabsf(rowv) > FTOL);
             nn = blk * nparpi + (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
           }
-          const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & 0xffffull);
+          const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & GMASK);
           if (EMIT && keep) {
             const long pos = rstart + cnt + __popc(m & ((1u << gl) - 1u));
             A.val[pos] = rowv;
@@ -581,7 +601,13 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.rbflag = (int *)p;
   if ((rc = dz_scratch(ctx, "rays.count", (size_t)(m + 1) * 8, &p))) return rc;
   A.count = (long *)p;
-  A.LK = g.nvx * g.nvz < 512 ? g.nvx * g.nvz : 512;
+  // LDS cell lists: 512 entries keep 16 wavefronts (128 rays) on a CU, which is worth 25 % on the S-256 grid where longer lists
+  // are rare; large inversion grids (S-512: rays cross > 100 cells) get 1024.  Longer lists fall back to a full-grid sweep.
+  A.lcap = g.nvx * g.nvz <= 4096 ? 512 : 1024;
+  if (ctx->opts.count("rays.lcap") && ctx->opts["rays.lcap"] >= 16 && ctx->opts["rays.lcap"] <= 8192)   // tuning / test knob: small
+    A.lcap = ctx->opts["rays.lcap"];                                                                      // values force the fallbacks
+  if (A.lcap > g.nvx * g.nvz) A.lcap = g.nvx * g.nvz;
+  A.LK = A.lcap;   // cell lists handed from the count pass to the emit pass (longer ones are traced again)
   A.keep_small = ctx->opts.count("rays.keep_small") && ctx->opts["rays.keep_small"] ? 1 : 0;
   if ((rc = dz_scratch(ctx, "rays.nlist", nr1 * 4, &p))) return rc;
   A.nlist = (int *)p;
@@ -595,12 +621,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
   A.col = nullptr;
-  A.lcap = g.nvx * g.nvz < 1024 ? g.nvx * g.nvz : 1024;
-  if (ctx->opts.count("rays.lcap") && ctx->opts["rays.lcap"] >= 16 && ctx->opts["rays.lcap"] < A.lcap) {   // test knob: forces the
-    A.lcap = ctx->opts["rays.lcap"];                                                                         // full-grid sweep and the
-    if (A.LK > A.lcap) A.LK = A.lcap;                                                                        // retrace fallbacks
-  }
-  const size_t lds = (size_t)A.lcap * 2 * 4 + 16;   // four cell lists (one per ray of the wavefront)
+  const size_t lds = (size_t)A.lcap * 2 * RPW + 16;   // one cell list per ray of the wavefront
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -616,10 +637,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS cell lists");
   if (ctx->opts.count("rays.wg_per_cu") && ctx->opts["rays.wg_per_cu"] > 0 && ctx->opts["rays.wg_per_cu"] < per_cu) per_cu = ctx->opts["rays.wg_per_cu"];
   long nwg = (long)ctx->num_cu * per_cu;
-  if (nwg > (nray + 3) / 4) nwg = (nray + 3) / 4;
+  if (nwg > (nray + RPW - 1) / RPW) nwg = (nray + RPW - 1) / RPW;
   if (nwg >= 8) nwg -= nwg % 8;   // the XCD-aware ray order wants a multiple of 8
   if (nwg < 1) nwg = 1;
-  if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * 4 * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
+  if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * RPW * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
   A.fdm_scratch = (float *)p;
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
