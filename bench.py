@@ -43,7 +43,7 @@ BYTES_PER_FIELD = 256 * 256 * 8 + 129 * 129 * 8   # read veln + write ttn, coars
 # rocprofv3 --pmc on this same command); FETCH_SIZE of the 16-byte streaming kernels is doubled as
 # MI355X_MICROARCH.md prescribes for gfx950.
 PROFILED = {"source": "profiles/r1_pmc_hbm_traffic.md",
-            "fmm_traffic_bytes_per_field": 61.1e6,
+            "fmm_traffic_bytes_per_field": 61.0e6,
             "spmv_ax_traffic_per_nnz": 8.20, "spmv_aty_traffic_per_nnz": 8.84}
 
 
