@@ -313,9 +313,15 @@ __global__ void k_colblock_ptr(int64_t nrows, int ncb, int cbw, const int64_t *_
   }
   cbptr[t] = lo;
 }
+constexpr int APART = 2048;   // partial maxima (enough workgroups to stream at HBM rate)
 __global__ void k_absmax(int64_t n, const float *x, float *part) {
   float v = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) v = fmaxf(v, fabsf(x[i]));
+  const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;   // 16-byte loads when the array allows
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * VB) {
+    const float4 q = reinterpret_cast<const float4 *>(x)[i];
+    v = fmaxf(fmaxf(v, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) v = fmaxf(v, fabsf(x[i]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   __shared__ float s[VB / 64];
@@ -614,14 +620,14 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A) {
   }
   int rc;
   void *p;
-  if ((rc = dz_scratch(ctx, "csr.absmax", (NPART + 4) * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.absmax", (APART + 4) * 4, &p))) return rc;
   float *pm = (float *)p;
   A->vmax = 0.0f;
   if (A->nnz > 0) {
-    const int nb = nblk(A->nnz, NPART);
+    const int nb = nblk((A->nnz + 3) / 4, APART);
     hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, A->val, pm);
-    hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + NPART);
-    DZ_HIP(hipMemcpyAsync(&A->vmax, pm + NPART, 4, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + APART);
+    DZ_HIP(hipMemcpyAsync(&A->vmax, pm + APART, 4, hipMemcpyDeviceToHost, ctx->stream));
   }
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -934,12 +940,12 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
     float ymax = 1.0f;
     if (use_scatter(ctx, A)) {   // fixed-point scale needs max|y| (inside LSMR it is 1: u is normalised)
       void *p;
-      if ((rc = dz_scratch(ctx, "csr.absmax", (NPART + 4) * 4, &p))) return rc;
+      if ((rc = dz_scratch(ctx, "csr.absmax", (APART + 4) * 4, &p))) return rc;
       float *pm = (float *)p;
-      const int nb = nblk(A->m, NPART);
+      const int nb = nblk((A->m + 3) / 4, APART);
       hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(VB), 0, ctx->stream, A->m, y.dev, pm);
-      hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + NPART);
-      DZ_HIP(hipMemcpyAsync(&ymax, pm + NPART, 4, hipMemcpyDeviceToHost, ctx->stream));
+      hipLaunchKernelGGL(k_absmax_finish, dim3(1), dim3(64), 0, ctx->stream, pm, nb, pm + APART);
+      DZ_HIP(hipMemcpyAsync(&ymax, pm + APART, 4, hipMemcpyDeviceToHost, ctx->stream));
       DZ_HIP(hipStreamSynchronize(ctx->stream));
     }
     DzTimer t(ctx, "spmvt");
