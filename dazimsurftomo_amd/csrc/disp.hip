@@ -27,7 +27,7 @@ struct Layer {   // per refined layer, geometry only
   double tmp;    // (ar+ar)/(r0+r1), sphere() :528
   float d;       // flattened thickness, :524
   float rfac;    // btp**(-2.275), :541
-  float fm, den; // (2j-1), 2*nsublay of refineGrid2LayerMdl (inv/CalSurfG.f90:2352)
+  float fm, den; // (2j-1), 2*nsublay of refineGrid2LayerMdl (inv/CalSurfG.f90:2352); RDEN kernels: den holds 1/(2*nsublay)
   int iv;        // interval (1-based knot index i); 0 for the half-space
 };
 
@@ -69,6 +69,9 @@ struct Knots {           // one lane's view of its column
 
 // flattened layer m (1-based): Vp a, Vs b, density rho, thickness d as surfdisp96 holds them after
 // refineGrid2LayerMdl + sphere(0,0) + sphere(2,1)
+// RDEN: every 2*nsublay is a power of two (the usual sublayers = 3 gives 8), so x/den == x*(1/den) exactly and the three
+// fp32 divisions per layer become multiplications by the reciprocal the host stored in den.
+template <bool RDEN>
 __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, int m, int nz, float &a,
                                             float &b, float &rho, float &d) {
   const Layer L = lay[m - 1];
@@ -78,9 +81,15 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
     const float p0 = K.get(1, i), p1 = K.get(1, i + 1);
     const float s0 = K.get(0, i), s1 = K.get(0, i + 1);
     const float r0 = K.get(2, i), r1 = K.get(2, i + 1);
-    rvp = p0 + L.fm * (p1 - p0) / L.den;
-    rvs = s0 + L.fm * (s1 - s0) / L.den;
-    rrho = r0 + L.fm * (r1 - r0) / L.den;
+    if (RDEN) {
+      rvp = p0 + L.fm * (p1 - p0) * L.den;
+      rvs = s0 + L.fm * (s1 - s0) * L.den;
+      rrho = r0 + L.fm * (r1 - r0) * L.den;
+    } else {
+      rvp = p0 + L.fm * (p1 - p0) / L.den;
+      rvs = s0 + L.fm * (s1 - s0) / L.den;
+      rrho = r0 + L.fm * (r1 - r0) / L.den;
+    }
   } else {
     rvp = K.get(1, nz);
     rvs = K.get(0, nz);
@@ -99,6 +108,7 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
 // rounded to fp32): the normalisation of the compound vector multiplies by the reciprocal of its largest entry
 // instead of dividing five times, 1/rho and 1/rho^2 are formed once per layer, and fb/omega uses the reciprocal of
 // omega hoisted out of the layer loop; the remaining divisions of the layer loop use frcp/fdiv above.
+template <bool RDEN>
 __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, double wvno, double omga) {
   double e0, e1, e2, e3, e4;
   double omega = omga;
@@ -106,7 +116,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
   const double wvno2 = wvno * wvno;
   const double romega = 1.0 / omega;
   float fa, fb, frho, fd;
-  layer_model(K, lay, mmax, nz, fa, fb, frho, fd);
+  layer_model<RDEN>(K, lay, mmax, nz, fa, fb, frho, fd);
   {
     const double xka = omega / (double)fa, xkb = omega / (double)fb;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
@@ -126,7 +136,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     e4 = wvno2 - ra * rb;
   }
   for (int m = mmax - 1; m >= 1; m--) {
-    layer_model(K, lay, m, nz, fa, fb, frho, fd);
+    layer_model<RDEN>(K, lay, m, nz, fa, fb, frho, fd);
     const double xka = fdiv(omega, (double)fa), xkb = fdiv(omega, (double)fb);
     const double t = (double)fb * romega;
     const double gammk = 2.0 * t * t;
@@ -253,6 +263,7 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
 
 enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
 
+template <bool RDEN>
 __global__ __launch_bounds__(DT) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(DT) void disp_kernel(DispArgs A) {
   int jsol = 1;
   for (int m = 1; m <= mmax; m++) {
     float fa, fb, fr, fd;
-    layer_model(K, s_lay, m, nz, fa, fb, fr, fd);
+    layer_model<RDEN>(K, s_lay, m, nz, fa, fb, fr, fd);
     if (fb > 0.01f && fb < betmn) {
       betmn = fb;
       a_mn = fa;
@@ -332,7 +343,7 @@ __global__ __launch_bounds__(DT) void disp_kernel(DispArgs A) {
   double ceval = c1;
 
   while (__any(phase != P_DONE)) {
-    const double del = dltar4(K, s_lay, mmax, nz, omega / ceval, omega);
+    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, omega / ceval, omega);
     if (phase == P_DONE) continue;
     bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
     switch (phase) {
@@ -541,6 +552,14 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     L.den = 1;
     lay.push_back(L);
   }
+  bool rden = true;   // every 2*nsub a power of two: the kernel multiplies by the exact reciprocal instead of dividing
+  for (const Layer &L : lay) {
+    const int d = (int)L.den;
+    if ((d & (d - 1)) != 0 || d > (1 << 20)) rden = false;
+  }
+  if (ctx->opts.count("disp.rden") && !ctx->opts["disp.rden"]) rden = false;   // test knob: keep the divisions
+  if (rden)
+    for (Layer &L : lay) L.den = 1.0f / L.den;
   const int mmax = (int)lay.size();
   if (mmax > NL) return dz_fail(ctx, DAZIM_E_BAD_ARG, "refined model has %d layers > NL=%d", mmax, NL);
   {
@@ -592,11 +611,15 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   const int cpb = (DT + nvar - 1) / nvar + 1;
   const size_t dyn_lds = (size_t)cpb * 3 * nz * sizeof(float);
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   {
     DzTimer t(ctx, "disp");
     const long nwork = (long)ncol * nvar;
-    hipLaunchKernelGGL(disp_kernel, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+    if (rden)
+      hipLaunchKernelGGL(disp_kernel<true>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+    else
+      hipLaunchKernelGGL(disp_kernel<false>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     const long nf = (long)ncol * kmax;
     hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,

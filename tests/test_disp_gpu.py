@@ -87,3 +87,20 @@ def test_root_failure_is_reported(ctx, orc):
     assert np.array_equal(pv == 0, pvo == 0)
     assert nf == int((pvo == 0).sum())
     assert np.abs(pv - pvo).max() <= 4e-6
+
+
+def test_reciprocal_sublayer_interpolation_is_exact(ctx):
+    """sublayers=3 -> 2*nsublay = 8: the kernel multiplies by 1/8 instead of dividing (inv/CalSurfG.f90:2352); a power-of-two
+    divisor makes that exact, so the results must be bit-identical to the dividing kernel (option disp.rden=0)"""
+    depz = np.arange(12, dtype=np.float32) * 5.0
+    vel = model(5, 4, depz, 7)
+    t = np.arange(5, 37, 2, dtype=np.float64)
+    pv1, sen1, nf1 = ctx.depthkernel(vel, depz, t, 3.0)
+    ctx.set_option("disp.rden", 0)
+    try:
+        pv0, sen0, nf0 = ctx.depthkernel(vel, depz, t, 3.0)
+    finally:
+        ctx.set_option("disp.rden", 1)
+    assert nf0 == nf1 and np.array_equal(pv0, pv1)
+    for a, b in zip(sen0, sen1):
+        assert np.array_equal(a, b)
