@@ -42,6 +42,7 @@ struct FmmArgs {
   int nfield, kmax;
   const double *pv;
   const float *veln;  // [kmax][nnx][nnz]
+  const float *slown; // [kmax][nnx][nnz]  1/veln (the slown = 1.0/vel of fouds2 :583, one IEEE division per node instead of one per update)
   const float *scx, *scz;
   const int *period;
   const float *risti_c;  // [nnx]       EARTH*sin(gox+(ix-1)*dnx)
@@ -53,6 +54,7 @@ struct FmmArgs {
   Node *rec_c;   // [nwg][nnx*nnz]
   Node *rec_r;   // [nwg][RM*RM]
   float *velnr;  // [nwg][RM*RM]
+  float *slownr; // [nwg][RM*RM]  1/velnr
   HEnt *ovf;     // [nwg][ovfcap]
   int ovfcap;
   unsigned *counter;
@@ -70,7 +72,7 @@ __device__ __forceinline__ void bspl4(float u, float w[4]) {
 
 // ---- gridder: inv/CalSurfG.f90:1423-1516, one thread per propagation node -------------------
 __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict__ pv,
-                               float *__restrict__ veln) {
+                               float *__restrict__ veln, float *__restrict__ slown) {
   const int nn = g.nnx * g.nnz;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nn * kmax) return;
@@ -96,6 +98,7 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
     sumi = sumi + vi[i1 - 1] * sumj;
   }
   veln[tid] = sumi;
+  slown[tid] = 1.0f / sumi;
 }
 
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
@@ -360,10 +363,9 @@ struct Heap {
 
 // fouds2 for one quadrant: inv/CalSurfG.f90:586-723.  (tj,sj) = neighbour along x, (tj2,sj2) the
 // node behind it, (tk,..) along z; vj2/vk2 = second node inside the grid.
-__device__ __forceinline__ float quadrant_time(float vel, float risti, float dnx, float dnz, Node nj, Node nj2,
+__device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, Node nj, Node nj2,
                                                Node nk, Node nk2, bool vj2, bool vk2) {
   const float ri = EARTH;
-  const float slown = 1.0f / vel;
   const bool aj = nj.s == 0, ak = nk.s == 0;
   const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
   const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
@@ -450,7 +452,7 @@ __device__ unsigned long long g_fmm_prof[8];
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
 template <int CAP, bool SPILL, class NT, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ veln,
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane, int *nbq) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
@@ -497,7 +499,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     Node nj2 = rec[vj2 ? iself + 2 * sj : iroot];
     Node nk = rec[vk ? iself + kd : iroot];
     Node nk2 = rec[vk2 ? iself + 2 * kd : iroot];
-    const float vel = veln[nvalid ? iself : iroot];
+    const float vel = slow[nvalid ? iself : iroot];   // slowness of the neighbour (1/velocity, precomputed)
     const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
@@ -642,6 +644,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   Node *rec_c = A.rec_c + slot * nn;
   Node *rec_r = A.rec_r + slot * RM * RM;
   float *velnr = A.velnr + slot * RM * RM;
+  float *slownr = A.slownr + slot * RM * RM;
   Heap<CAP, SPILL, NT> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
@@ -730,7 +733,9 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
                 s = s + ui[j1 - 1] * (float)pv[(ic - 2 + i1) * (g.nvx + 2) + (jc - 2 + j1)];
               sum[i1 - 1] = vi[i1 - 1] * s;
             }
-            velnr[idx] = sum[0] + sum[1] + sum[2] + sum[3];
+            const float vr = sum[0] + sum[1] + sum[2] + sum[3];
+            velnr[idx] = vr;
+            slownr[idx] = 1.0f / vr;
             rec_r[idx] = Node{0.0f, -1};
           }
         }
@@ -777,7 +782,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, true>(H, velnr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, s_nbq[grp]);
+        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, s_nbq[grp]);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -849,7 +854,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, veln, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, s_nbq[grp]);
+        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nn, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, s_nbq[grp]);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -881,6 +886,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.rec_r = (Node *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;
+  if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * nr * 4, &p))) return rc;
+  A.slownr = (float *)p;
   if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * ovfcap * sizeof(HEnt), &p))) return rc;
   A.ovf = (HEnt *)p;
   if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
@@ -997,10 +1004,12 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if ((rc = dz_scratch(ctx, "fmm.veln", nn * kmax * 4, &p))) return rc;
     d_veln = (float *)p;
   }
+  if ((rc = dz_scratch(ctx, "fmm.slown", nn * kmax * 4, &p))) return rc;
+  float *d_slown = (float *)p;
   {
     DzTimer t(ctx, "gridder");
     const int total = (int)(nn * kmax);
-    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln);
+    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln, d_slown);
     DZ_HIP(hipGetLastError());
     t.stop();
   }
@@ -1011,6 +1020,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     A0.kmax = kmax;
     A0.pv = pv.dev;
     A0.veln = d_veln;
+    A0.slown = d_slown;
     A0.scx = scx.dev;
     A0.scz = scz.dev;
     A0.period = period.dev;
