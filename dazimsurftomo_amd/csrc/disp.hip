@@ -59,7 +59,9 @@ __device__ __forceinline__ double fdiv(double a, double b) {
 // sqrt for the normal-range, non-negative operands of the secular function: reciprocal-square-root estimate + two coupled
 // Newton steps (9 instructions instead of the ~25 of the correctly rounded sequence with its range scaling); accurate to an
 // ulp like frcp/fdiv above.
-__device__ __forceinline__ double fsqrt(double x) {
+// rs receives 1/sqrt(x) (the coupled iteration carries it along; one more step brings it to an ulp), which replaces the
+// divisions by the square root that follow.  x == 0 gives 0 and an unusable rs: the callers never divide in that case.
+__device__ __forceinline__ double fsqrt(double x, double &rs) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
@@ -67,6 +69,9 @@ __device__ __forceinline__ double fsqrt(double x) {
   h = __builtin_fma(h, r, h);
   r = __builtin_fma(-g, g, x);
   g = __builtin_fma(r, h, g);
+  r = __builtin_fma(-h, g, 0.5);
+  h = __builtin_fma(h, r, h);
+  rs = h + h;
   return x > 0.0 ? g : 0.0;
 }
 
@@ -156,17 +161,19 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     const double gammk = 2.0 * t * t;
     const double gam = gammk * wvno2;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
-    const double ra = fsqrt(wvnop * wvnom);
+    double rra;
+    const double ra = fsqrt(wvnop * wvnom, rra);
     wvnop = wvno + xkb;
     wvnom = fabs(wvno - xkb);
-    const double rb = fsqrt(wvnop * wvnom);
+    double rrb;
+    const double rb = fsqrt(wvnop * wvnom, rrb);
     const double dpth = (double)fd, rho1 = (double)frho;
     const double rrho1 = frcp(rho1), rrho2 = rrho1 * rrho1;
     const double p = ra * dpth, q = rb * dpth;
     double w, x, y, z, cosp, cosq, sinp, sinq, fac, pex = 0.0, sex = 0.0;
     if (wvno < xka) {
       sincos(p, &sinp, &cosp);   // one argument reduction for both
-      w = fdiv(sinp, ra);
+      w = sinp * rra;
       x = -ra * sinp;
     } else if (wvno == xka) {
       cosp = 1.0;
@@ -178,12 +185,12 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
       if (p < 16) fac = exp(-2.0 * p);
       cosp = (1.0 + fac) * 0.5;
       sinp = (1.0 - fac) * 0.5;
-      w = fdiv(sinp, ra);
+      w = sinp * rra;
       x = ra * sinp;
     }
     if (wvno < xkb) {
       sincos(q, &sinq, &cosq);
-      y = fdiv(sinq, rb);
+      y = sinq * rrb;
       z = -rb * sinq;
     } else if (wvno == xkb) {
       cosq = 1.0;
@@ -195,7 +202,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
       if (q < 16) fac = exp(-2.0 * q);
       cosq = (1.0 + fac) * 0.5;
       sinq = (1.0 - fac) * 0.5;
-      y = fdiv(sinq, rb);
+      y = sinq * rrb;
       z = rb * sinq;
     }
     const double exa = pex + sex;
