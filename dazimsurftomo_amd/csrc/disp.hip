@@ -129,6 +129,7 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
 // omega hoisted out of the layer loop; the remaining divisions of the layer loop use frcp/fdiv above.
 template <bool RDEN>
 __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, double wvno, double omga) {
+#pragma clang fp contract(fast)   // FMA contraction inside the secular function only (the file is built with -ffp-contract=off)
   double e0, e1, e2, e3, e4;
   double omega = omga;
   if (omega < 1.0e-4) omega = 1.0e-4;
