@@ -286,7 +286,7 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
 enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
 
 template <bool RDEN>
-__global__ __launch_bounds__(DT) void disp_kernel(DispArgs A) {
+__global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
   extern __shared__ __attribute__((aligned(16))) float s_knot[];  // [cpb][3][nz]
