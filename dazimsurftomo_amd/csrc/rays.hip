@@ -155,11 +155,10 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   return biv;
 }
 
-constexpr int GP = 8;             // lanes per ray
-constexpr int RPW = 64 / GP;      // rays per wavefront
-constexpr int LPR = 16 / GP;      // cells of the 4x4 B-spline block per lane
-constexpr int LSTEP = 4 / LPR;    // ... which are LSTEP rows apart
-constexpr unsigned GMASK = (1u << GP) - 1u;
+// lanes per ray: 8 in the count pass, which traces every ray (measured: 16 lanes 94 ms, 8 lanes 73 ms, 4 lanes 84 ms on the S-256
+// batch); 16 in the emit pass, which only walks the saved cell lists (lane-parallel work: 8.2 ms with 16 lanes, 12.5 with 8)
+constexpr int GP_COUNT = 8, GP_EMIT = 16;
+constexpr int RPW_MAX = 64 / GP_COUNT;   // rays per wavefront (most of the two passes: sizes the scratch slots)
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier (same-wave ops are in order)
 
 // One GP-lane group per ray (~330 k instructions per ray when one wavefront traced one ray, all of it per-ray
@@ -169,6 +168,11 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // reference's order (fdm = r1 + fdm).
 template <bool EMIT, bool AZIM>
 __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
+  constexpr int GP = EMIT ? GP_EMIT : GP_COUNT;   // lanes per ray
+  constexpr int RPW = 64 / GP;                    // rays per wavefront
+  constexpr int LPR = 16 / GP;                    // cells of the 4x4 B-spline block per lane
+  constexpr int LSTEP = 4 / LPR;                  // ... which are LSTEP rows apart
+  constexpr unsigned GMASK = (1u << GP) - 1u;
   extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][lcap] cell lists
   const dazim_geom g = A.g;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
@@ -621,7 +625,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
   A.col = nullptr;
-  const size_t lds = (size_t)A.lcap * 2 * RPW + 16;   // one cell list per ray of the wavefront
+  const size_t lds = (size_t)A.lcap * 2 * RPW_MAX + 16;   // one cell list per ray of the wavefront
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -637,10 +641,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (per_cu < 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "inversion grid too large for the LDS cell lists");
   if (ctx->opts.count("rays.wg_per_cu") && ctx->opts["rays.wg_per_cu"] > 0 && ctx->opts["rays.wg_per_cu"] < per_cu) per_cu = ctx->opts["rays.wg_per_cu"];
   long nwg = (long)ctx->num_cu * per_cu;
-  if (nwg > (nray + RPW - 1) / RPW) nwg = (nray + RPW - 1) / RPW;
+  if (nwg > (nray + RPW_MAX - 1) / RPW_MAX) nwg = (nray + RPW_MAX - 1) / RPW_MAX;
   if (nwg >= 8) nwg -= nwg % 8;   // the XCD-aware ray order wants a multiple of 8
   if (nwg < 1) nwg = 1;
-  if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * RPW * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
+  if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * RPW_MAX * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
   A.fdm_scratch = (float *)p;
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
