@@ -25,6 +25,7 @@ program DAzimSurfTomo_amd
   character(len=40) :: dummy
   character :: str1
   logical :: ex, iso_mod
+  logical, external :: ti_kernels_on_device
   integer :: nx, ny, nz, nsrc, nrc, maxiter, kmaxRc, kmax, err
   real :: goxd, gozd, dvxd, dvzd, minthk, Minvel, Maxvel, spfra, weightVs, weightGcs, damp
   real*8, allocatable :: tRc(:), tRcV(:, :), pv(:, :)
@@ -222,9 +223,11 @@ program DAzimSurfTomo_amd
 
     ! ---- forward problem + sensitivity matrix on the device (CalSurfG / CalSurfGAnisoJoint) ---------------
     dsyn = 0; tRcV = 0
-    if (.not. iso_mod) call ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+    if (.not. iso_mod .and. .not. ti_kernels_on_device()) &
+      call ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
     call dazim_assemble_G(.not. iso_mod, nx, ny, nz, vsf, dsyn, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
-                          minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv)
+                          minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv, &
+                          ti_here=(.not. iso_mod .and. ti_kernels_on_device()))
     if (.not. iso_mod) then                       ! inv/CalSurfGAniso_Joint.f90:801-811 (the iso branch leaves tRcV = 0)
       do tt = 1, kmaxRc
         do jj = 1, ny - 2

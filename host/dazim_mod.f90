@@ -287,9 +287,12 @@ contains
 
   ! The whole of CalSurfG (inv/CalSurfG.f90:909) / the GPU part of CalSurfGAnisoJoint on the device; G stays in HBM
   ! (handle returned), dsurf(dall) and pv(nx*ny,kmaxRc) come back to the host.
+  ! ti_here = .true. (joint only): lsen is an OUTPUT, computed here by dazim_ti_kernels from the dispersion curves this routine
+  ! needs anyway (the reference's depthkernelTI runs surfdisp96 a second time for them, inv/depthkernelTI.f90:66).
   subroutine dazim_assemble_G(joint, nx, ny, nz, vels, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, &
-                              minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nar, pv)
+                              minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nar, pv, ti_here)
     logical :: joint
+    logical, optional :: ti_here
     integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
     real :: vels(nx, ny, nz), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
     real*8 :: tRc(*)
@@ -310,6 +313,10 @@ contains
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, svs, svp, srho, nfail), &
                'CalSurfG/depthkernel')
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
+    if (joint .and. present(ti_here)) then
+      if (ti_here) call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
+                              'depthkernelTI/tregn96')
+    end if
     ! flatten the (period, source, receiver) loops in the reference's order (:1114-1326)
     nfield = sum(nsrcsurf1(1:kmax)); nray = 0
     do k = 1, kmax

@@ -13,3 +13,7 @@ subroutine ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc
   Lsen_Gsc = 0.0
   call depthkernelTI(nx, ny, nz, vsf, pv2, 2, 0, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
 end subroutine
+
+logical function ti_kernels_on_device()
+  ti_kernels_on_device = .false.
+end function
