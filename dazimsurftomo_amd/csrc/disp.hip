@@ -27,8 +27,9 @@ struct Layer {   // per refined layer, geometry only
   double tmp;    // (ar+ar)/(r0+r1), sphere() :528
   float d;       // flattened thickness, :524
   float rfac;    // btp**(-2.275), :541
-  float fm, den; // (2j-1), 2*nsublay of refineGrid2LayerMdl (inv/CalSurfG.f90:2352); RDEN kernels: den holds 1/(2*nsublay)
+  float fm, den; // (2j-1), 2*nsublay of refineGrid2LayerMdl (inv/CalSurfG.f90:2352)
   int iv;        // interval (1-based knot index i); 0 for the half-space
+  float rden;    // 1/den rounded to nearest (RDEN kernels)
 };
 
 struct DispArgs {
@@ -88,10 +89,15 @@ struct Knots {           // one lane's view of its column
 
 // flattened layer m (1-based): Vp a, Vs b, density rho, thickness d as surfdisp96 holds them after
 // refineGrid2LayerMdl + sphere(0,0) + sphere(2,1)
-// RDEN: every 2*nsublay is a power of two (the usual sublayers = 3 gives 8), so x/den == x*(1/den) exactly and the three
-// fp32 divisions per layer become multiplications by the reciprocal the host stored in den.
-template <bool RDEN>
-__device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, int m, int nz, float &a,
+// The three fp32 divisions x/den per layer (den = 2*nsublay, a small even integer) without dividing, bit-identical:
+// RDEN = 1: every den is a power of two (the usual sublayers = 3 gives 8), so x/den == x*(1/den) exactly;
+// RDEN = 2: q = x*r, q' = fma(fma(-den, q, x), r, q) with r = RN(1/den) equals RN(x/den) for every float x with
+//           1e-30 <= |x| <= 1e30 or x = 0 -- checked exhaustively over all 1.7e9 such x for each den in {6, 10, 12, 14, 18, 20,
+//           22, 24, 26, 28, 30, 36} (host: fastdiv_ok) -- and `fast` (wavefront-uniform) says that this lane's and its
+//           neighbours' knot differences are in that range; otherwise the division is done.
+// RDEN = 0: divide.
+template <int RDEN>
+__device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, int m, int nz, bool fast, float &a,
                                             float &b, float &rho, float &d) {
   const Layer L = lay[m - 1];
   float rvp, rvs, rrho;
@@ -100,10 +106,19 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
     const float p0 = K.get(1, i), p1 = K.get(1, i + 1);
     const float s0 = K.get(0, i), s1 = K.get(0, i + 1);
     const float r0 = K.get(2, i), r1 = K.get(2, i + 1);
-    if (RDEN) {
-      rvp = p0 + L.fm * (p1 - p0) * L.den;
-      rvs = s0 + L.fm * (s1 - s0) * L.den;
-      rrho = r0 + L.fm * (r1 - r0) * L.den;
+    if (RDEN == 1) {
+      rvp = p0 + L.fm * (p1 - p0) * L.rden;
+      rvs = s0 + L.fm * (s1 - s0) * L.rden;
+      rrho = r0 + L.fm * (r1 - r0) * L.rden;
+    } else if (RDEN == 2 && fast) {
+      const float tp = L.fm * (p1 - p0), ts = L.fm * (s1 - s0), tr = L.fm * (r1 - r0);
+      float qp = tp * L.rden, qs = ts * L.rden, qr = tr * L.rden;
+      qp = __builtin_fmaf(__builtin_fmaf(-L.den, qp, tp), L.rden, qp);
+      qs = __builtin_fmaf(__builtin_fmaf(-L.den, qs, ts), L.rden, qs);
+      qr = __builtin_fmaf(__builtin_fmaf(-L.den, qr, tr), L.rden, qr);
+      rvp = p0 + qp;
+      rvs = s0 + qs;
+      rrho = r0 + qr;
     } else {
       rvp = p0 + L.fm * (p1 - p0) / L.den;
       rvs = s0 + L.fm * (s1 - s0) / L.den;
@@ -127,8 +142,8 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
 // rounded to fp32): the normalisation of the compound vector multiplies by the reciprocal of its largest entry
 // instead of dividing five times, 1/rho and 1/rho^2 are formed once per layer, and fb/omega uses the reciprocal of
 // omega hoisted out of the layer loop; the remaining divisions of the layer loop use frcp/fdiv above.
-template <bool RDEN>
-__device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, double wvno, double omga) {
+template <int RDEN>
+__device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, bool fast, double wvno, double omga) {
 #pragma clang fp contract(fast)   // FMA contraction inside the secular function only (the file is built with -ffp-contract=off)
   double e0, e1, e2, e3, e4;
   double omega = omga;
@@ -136,7 +151,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
   const double wvno2 = wvno * wvno;
   const double romega = 1.0 / omega;
   float fa, fb, frho, fd;
-  layer_model<RDEN>(K, lay, mmax, nz, fa, fb, frho, fd);
+  layer_model<RDEN>(K, lay, mmax, nz, fast, fa, fb, frho, fd);
   {
     const double xka = omega / (double)fa, xkb = omega / (double)fb;
     double wvnop = wvno + xka, wvnom = fabs(wvno - xka);
@@ -156,7 +171,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, dou
     e4 = wvno2 - ra * rb;
   }
   for (int m = mmax - 1; m >= 1; m--) {
-    layer_model<RDEN>(K, lay, m, nz, fa, fb, frho, fd);
+    layer_model<RDEN>(K, lay, m, nz, fast, fa, fb, frho, fd);
     const double xka = fdiv(omega, (double)fa), xkb = fdiv(omega, (double)fb);
     const double t = (double)fb * romega;
     const double gammk = 2.0 * t * t;
@@ -285,7 +300,7 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
 
 enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
 
-template <bool RDEN>
+template <int RDEN>
 __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
@@ -331,12 +346,23 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     const float dln = 0.01f;
     K.pv = (r & 1) ? b0 + 0.5f * dln * b0 : b0 - 0.5f * dln * b0;
   }
+  bool fast = false;
+  if (RDEN == 2) {   // every knot difference the interpolation will see is 0 or inside the range the shortcut was verified on
+    bool ok = true;
+    for (int i = 1; i < nz; i++)
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float ad = fabsf(K.get(q, i + 1) - K.get(q, i));
+        ok = ok && (ad == 0.0f || (ad >= 1.0e-30f && ad <= 1.0e28f));
+      }
+    fast = __all(ok);
+  }
   // ---- start-up of surfdisp96 (:134-216): extremal velocities, half-space start value ----
   float betmx = -1.e20f, betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
   int jsol = 1;
   for (int m = 1; m <= mmax; m++) {
     float fa, fb, fr, fd;
-    layer_model<RDEN>(K, s_lay, m, nz, fa, fb, fr, fd);
+    layer_model<RDEN>(K, s_lay, m, nz, fast, fa, fb, fr, fd);
     if (fb > 0.01f && fb < betmn) {
       betmn = fb;
       a_mn = fa;
@@ -365,7 +391,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   double ceval = c1;
 
   while (__any(phase != P_DONE)) {
-    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, omega / ceval, omega);
+    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega);
     if (phase == P_DONE) continue;
     bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
     switch (phase) {
@@ -574,14 +600,18 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     L.den = 1;
     lay.push_back(L);
   }
-  bool rden = true;   // every 2*nsub a power of two: the kernel multiplies by the exact reciprocal instead of dividing
-  for (const Layer &L : lay) {
+  // division-free layer interpolation (see layer_model): 1 = every 2*nsub a power of two, 2 = every 2*nsub a power of two or one
+  // of the divisors the reciprocal + correction form was verified on exhaustively, 0 = divide
+  int rden = 1;
+  for (Layer &L : lay) {
     const int d = (int)L.den;
-    if ((d & (d - 1)) != 0 || d > (1 << 20)) rden = false;
+    L.rden = 1.0f / L.den;
+    const bool pow2 = (d & (d - 1)) == 0 && d <= (1 << 20);
+    bool fastdiv_ok = false;
+    for (int v : {6, 10, 12, 14, 18, 20, 22, 24, 26, 28, 30, 36}) fastdiv_ok = fastdiv_ok || d == v;
+    if (!pow2) rden = (fastdiv_ok && rden != 0) ? 2 : 0;
   }
-  if (ctx->opts.count("disp.rden") && !ctx->opts["disp.rden"]) rden = false;   // test knob: keep the divisions
-  if (rden)
-    for (Layer &L : lay) L.den = 1.0f / L.den;
+  if (ctx->opts.count("disp.rden") && !ctx->opts["disp.rden"]) rden = 0;   // test knob: keep the divisions
   const int mmax = (int)lay.size();
   if (mmax > NL) return dz_fail(ctx, DAZIM_E_BAD_ARG, "refined model has %d layers > NL=%d", mmax, NL);
   {
@@ -633,15 +663,18 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   const int cpb = (DT + nvar - 1) / nvar + 1;
   const size_t dyn_lds = (size_t)cpb * 3 * nz * sizeof(float);
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   {
     DzTimer t(ctx, "disp");
     const long nwork = (long)ncol * nvar;
-    if (rden)
-      hipLaunchKernelGGL(disp_kernel<true>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+    if (rden == 1)
+      hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+    else if (rden == 2)
+      hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
     else
-      hipLaunchKernelGGL(disp_kernel<false>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+      hipLaunchKernelGGL(disp_kernel<0>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     const long nf = (long)ncol * kmax;
     hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,

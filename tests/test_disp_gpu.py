@@ -89,16 +89,19 @@ def test_root_failure_is_reported(ctx, orc):
     assert np.abs(pv - pvo).max() <= 4e-6
 
 
-def test_reciprocal_sublayer_interpolation_is_exact(ctx):
-    """sublayers=3 -> 2*nsublay = 8: the kernel multiplies by 1/8 instead of dividing (inv/CalSurfG.f90:2352); a power-of-two
-    divisor makes that exact, so the results must be bit-identical to the dividing kernel (option disp.rden=0)"""
+@pytest.mark.parametrize("sublayers", [2.0, 3.0, 4.0])
+def test_division_free_sublayer_interpolation_is_exact(ctx, sublayers):
+    """The sub-layer interpolation divides by 2*nsublay (inv/CalSurfG.f90:2352).  sublayers=3 -> 8: the kernel multiplies by
+    1/8 (exact for a power of two); sublayers=2, 4 -> 6, 10: reciprocal + one fused correction step, which equals the
+    correctly rounded quotient for those divisors (verified exhaustively over all floats in 1e-30..1e30).  Either way the
+    results must be bit-identical to the dividing kernel (option disp.rden=0)."""
     depz = np.arange(12, dtype=np.float32) * 5.0
     vel = model(5, 4, depz, 7)
     t = np.arange(5, 37, 2, dtype=np.float64)
-    pv1, sen1, nf1 = ctx.depthkernel(vel, depz, t, 3.0)
+    pv1, sen1, nf1 = ctx.depthkernel(vel, depz, t, sublayers)
     ctx.set_option("disp.rden", 0)
     try:
-        pv0, sen0, nf0 = ctx.depthkernel(vel, depz, t, 3.0)
+        pv0, sen0, nf0 = ctx.depthkernel(vel, depz, t, sublayers)
     finally:
         ctx.set_option("disp.rden", 1)
     assert nf0 == nf1 and np.array_equal(pv0, pv1)
