@@ -283,13 +283,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
       // The corner times of the cell the NEXT step starts in are requested as soon as that cell is known (on both grids: which
       // one applies depends on node states that are still being loaded), so that they travel together with the velocity and
       // node-state loads of the current step instead of costing a second dependent round trip per step.
-      float tc00, tc01, tc10, tc11, tr00, tr01, tr10, tr11;
+      float tc00, tc01, tc10, tc11, tr00 = 0.0f, tr01 = 0.0f, tr10 = 0.0f, tr11 = 0.0f;
       auto load_corner_times = [&]() {
         const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
         tc00 = t[0]; tc01 = t[1]; tc10 = t[nnz]; tc11 = t[nnz + 1];
-        const int qx = ipxr < 1 ? 1 : (ipxr > RM - 1 ? RM - 1 : ipxr), qz = ipzr < 1 ? 1 : (ipzr > RM - 1 ? RM - 1 : ipzr);
-        const float *u = ttnr + (size_t)(qx - 1) * RM + (qz - 1);
-        tr00 = u[0]; tr01 = u[1]; tr10 = u[RM]; tr11 = u[RM + 1];
+        if (ipxr >= 1 && ipxr < nnxr && ipzr >= 1 && ipzr < nnzr) {   // (outside the refined box igref is 0 and these are not used)
+          const float *u = ttnr + (size_t)(ipxr - 1) * RM + (ipzr - 1);
+          tr00 = u[0]; tr01 = u[1]; tr10 = u[RM]; tr11 = u[RM + 1];
+        }
       };
       load_corner_times();
       const long maxrp = (long)nnx * nnz;
