@@ -454,8 +454,14 @@ __global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
   for (int64_t c = (int64_t)blockIdx.x * VB + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * VB) {
-    long long t = 0;
-    for (int k = 0; k < nchunk; k++) t += part[(size_t)k * ncols + c];
+    // eight independent partial sums: the loads of a column are in flight together (integer sums: any order gives the same bits)
+    long long t8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (; k + 8 <= nchunk; k += 8)
+#pragma unroll
+      for (int j = 0; j < 8; j++) t8[j] += part[(size_t)(k + j) * ncols + c];
+    for (; k < nchunk; k++) t8[0] += part[(size_t)k * ncols + c];
+    const long long t = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
     const float o = beta * out[c] + (float)((double)t * inv_scale);
     out[c] = o;
     sq += (double)o * o;
