@@ -17,11 +17,18 @@ its HBM fraction is reported for transparency, not as a target), `spmv` (the HBM
 40 % target applies to) and `cpu_baseline` (the oracle = plain-C port of the reference, 1 thread, on
 a bounded sample of the same workload on this box's host cores).
 
-Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_LSMR_NATIVE=1 makes the N > 1
-solve use the RCCL path inside the library instead of the torch.distributed driver; DAZIM_BENCH_FORCE_DIST=1 takes the
-multi-rank code path with a single rank.
+Multi-GPU (`--gpus N` under torch.distributed.run): the default workload stays S-256 per rank (weak scaling, so that the N = 1
+point of a scaling curve equals the single-GPU bench); BASELINE's 8-GPU configuration is `--gpus 8 --workload s512 --sources 1000`
+(511 x 511 nodes, 32 periods, 8 x 1000 sources).  The row-sharded LSMR runs inside the library over its own RCCL communicator
+(dazim_comm_init; one n-float all-reduce + one scalar per iteration); if that communicator cannot be set up on every rank the
+run falls back to the torch.distributed driver (dazimsurftomo_amd/distributed.py) and says so in the JSON line (`lsmr.driver`).
+
+Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_LSMR_NATIVE=0 forces the
+torch.distributed driver at N > 1, =1 the in-library RCCL path (no fallback); DAZIM_BENCH_FORCE_DIST=1 takes the multi-rank code
+path with a single rank.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,12 +46,45 @@ MINTHK = 3.0                    # sublayers -> rmax = 45
 PERIODS = np.arange(5, 37, 2, dtype=np.float64)   # 16 periods 5..35 s
 HBM_PEAK_GBS = 8000.0
 BYTES_PER_FIELD = 256 * 256 * 8 + 129 * 129 * 8   # read veln + write ttn, coarse + refined
-# HBM traffic per unit from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected separately with
-# rocprofv3 --pmc on this same command); FETCH_SIZE of the 16-byte streaming kernels is doubled as
-# MI355X_MICROARCH.md prescribes for gfx950.
-PROFILED = {"source": "profiles/r1_pmc_hbm_traffic.md",
-            "fmm_traffic_bytes_per_field": 61.0e6,
-            "spmv_ax_traffic_per_nnz": 8.20, "spmv_aty_traffic_per_nnz": 8.84}
+# HBM traffic comes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected separately with rocprofv3 --pmc on this
+# same command by tools/profile_round.sh, which writes profiles/pmc_traffic.json: KiB per dispatch and kernel, the workload, and
+# the hash of the kernel sources it was measured on).  A profile of other sources, or of another workload, is NOT quoted:
+# `traffic` is null then.  FETCH_SIZE of the 16-byte streaming kernels is doubled as MI355X_MICROARCH.md prescribes for gfx950.
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "dazimsurftomo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def profiled_traffic(workload, nfield, nnz):
+    """bytes per launch of the eikonal kernel and of the two products from profiles/pmc_traffic.json, or Nones with the reason"""
+    none = {"fmm": None, "ax": None, "aty": None}
+    try:
+        prof = json.load(open(PMC_FILE))
+    except Exception as e:
+        return none, f"no usable {os.path.relpath(PMC_FILE, ROOT)} ({type(e).__name__})"
+    if prof.get("source_sha") != kernel_source_hash():
+        return none, f"{os.path.relpath(PMC_FILE, ROOT)} was measured on other kernel sources ({prof.get('source_sha')}): stale, not quoted"
+    if prof.get("workload") != workload or prof.get("fields") != nfield:
+        return none, f"{os.path.relpath(PMC_FILE, ROOT)} was measured on workload {prof.get('workload')} / {prof.get('fields')} fields"
+    K = 1024.0
+
+    def tot(prefixes, fetch_x):
+        t = 0.0
+        for name, v in prof["kernels"].items():
+            if any(pfx in name for pfx in prefixes):
+                t += (fetch_x * v["fetch_kib"] + v["write_kib"]) * K
+        return t or None
+    out = {"fmm": tot(["fmm_kernel"], 1.0),                                   # 8-byte record accesses: raw counter values
+           "ax": tot(["spmv_rows", "k_rows_combine"], 2.0),                   # 16-byte streams: FETCH_SIZE x 2 on gfx950
+           "aty": tot(["spmvT_scatter", "k_scatter_combine"], 2.0)}
+    return out, os.path.relpath(PMC_FILE, ROOT) + " (" + prof.get("tag", "?") + ")"
 
 
 WORKLOADS = {   # SURVEY.md 8d: name -> (nx = ny, periods); the metric is quoted on S-256, the others are the parity-test sizes
@@ -112,6 +152,33 @@ def tikhonov_rows(nx, ny, nz, dall, w):
     return cnt, np.array(ir, np.int32), np.array(ic, np.int32), np.array(rw, np.float32)
 
 
+def cpu_multicore(orc, g, pv_maps, scx, scz, per, nfield_total, sub, budget_s=8.0):
+    """the same oracle calls from one thread per host core (the C code holds no global state and ctypes releases the GIL): eikonal
+    fields/s and depthkernel columns/s with all cores busy -- the honest multi-core figure next to the 1-thread one.  (The
+    reference itself only threads depthkernel, inv/CalSurfG.f90:39-43.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    ncore = os.cpu_count() or 1
+    fields = list(range(0, nfield_total, max(1, nfield_total // (12 * ncore))))[:12 * ncore]
+    velns = {k: orc.gridder(g, pv_maps[k]) for k in sorted({int(per[f]) - 1 for f in fields})}
+
+    def one_field(f):
+        k = int(per[f]) - 1
+        orc.gridder(g, pv_maps[k])
+        orc.fmm_field(g, pv_maps[k], velns[k], scx[f], scz[f])
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(ncore) as ex:
+        list(ex.map(one_field, fields))
+    t_f = time.perf_counter() - t0
+    cols = [np.ascontiguousarray(sub[:, :, i:i + 1]) for i in range(sub.shape[2])] * max(1, (2 * ncore) // sub.shape[2])
+    cols = cols[:2 * ncore]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(ncore) as ex:
+        list(ex.map(lambda c: orc.depthkernel(c, DEPZ, PERIODS, MINTHK), cols))
+    t_c = time.perf_counter() - t0
+    return {"cores": ncore, "fmm_fields_per_s": len(fields) / t_f, "depthkernel_columns_per_s": len(cols) / t_c,
+            "sample": f"{len(fields)} eikonal fields and {len(cols)} depthkernel columns over {ncore} threads"}
+
+
 def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_per_field, budget_s=20.0):
     """the oracle (plain-C port of the reference, 1 thread) on a bounded sample of the same workload"""
     from oracle.pyoracle import Oracle, build
@@ -173,8 +240,18 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
             ref_extra["reference_fmm_fields_per_s"] = nrf / (time.perf_counter() - t0)
     except Exception as e:   # the reference build is optional equipment
         ref_extra["reference_note"] = f"oracle/_ref not usable here: {e}"
+    try:
+        mc = cpu_multicore(orc, g, pv_maps, scx, scz, per, nfield_total, sub)
+        # forward time per field with every core busy: rays scale like the fields (independent items)
+        scale = mc["fmm_fields_per_s"] * t_field
+        mc["value"] = 1.0 / (1.0 / mc["fmm_fields_per_s"] + rays_per_field * t_ray / max(scale, 1e-9)
+                             + ncolumns / nfield_total / mc["depthkernel_columns_per_s"])
+        mc["unit"] = "fields/s"
+    except Exception as e:
+        mc = {"note": f"multi-core leg failed: {e}"}
     return {
         **ref_extra,
+        "multicore": mc,
         "value": 1.0 / per_field, "unit": "fields/s", "cores": 1, "kind": "port",
         "sample": f"{ncol_s} columns of depthkernel (73 curves x {kmax} periods each), {nf} eikonal fields {g.nnx}x{g.nnz}, "
                   f"{nr} rays traced (row assembly excluded); forward time per field = fmm + {rays_per_field} rays + "
@@ -188,14 +265,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--sources", type=int, default=1000)
-    ap.add_argument("--receivers", type=int, default=32)
+    ap.add_argument("--sources", type=int, default=None, help="sources per GPU (default: 1000; 200 for s128, SURVEY 8d)")
+    ap.add_argument("--receivers", type=int, default=None, help="receivers per source (default: 32; 16 for s128)")
     ap.add_argument("--lsmr-iters", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s256")
     a = ap.parse_args()
+    if a.sources is None:
+        a.sources = 200 if a.workload == "s128" else 1000
+    if a.receivers is None:
+        a.receivers = 16 if a.workload == "s128" else 32
     nnodes = set_workload(a.workload)
-    calibrated = a.workload == "s256"      # the PMC traffic figures in profiles/ were collected on S-256
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -225,13 +305,29 @@ def main():
     for kv in os.environ.get("DAZIM_OPTS", "").split(","):   # tuning experiments: DAZIM_OPTS=rays.wg_per_cu=4,fmm.wg_per_cu=6
         if "=" in kv:
             ctx.set_option(*kv.split("="))
-    # N > 1: the row-sharded LSMR.  Default: the Python driver over torch.distributed (backend nccl = RCCL).
-    # DAZIM_LSMR_NATIVE=1: the same algorithm inside the C library with its own RCCL communicator (dazim_comm_init).
-    native = use_dist and os.environ.get("DAZIM_LSMR_NATIVE") == "1"
+    # N > 1: the row-sharded LSMR.  Default: inside the C library with its own RCCL communicator (dazim_comm_init), set up
+    # here and confirmed by every rank; if any rank cannot join, all ranks fall back together to the Python driver over
+    # torch.distributed (backend nccl = RCCL).  DAZIM_LSMR_NATIVE=0 / 1 forces one or the other.
+    want = os.environ.get("DAZIM_LSMR_NATIVE", "auto")
+    native = use_dist and want != "0"
+    lsmr_note = ""
     if native:
-        box = [dz.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        ctx.comm_init(world, rank, box[0])
+        ok = 1
+        try:
+            box = [dz.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            ctx.comm_init(world, rank, box[0])
+        except Exception as e:      # (a rank that cannot even create the id still reaches the vote below)
+            ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
+            if want == "1":
+                raise
+        vote = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 0:
+            if ok:
+                ctx.comm_free()
+            native = False
+            lsmr_note = lsmr_note or "in-library RCCL set-up failed on another rank"
 
     kmax = len(PERIODS)
     vel = s256_model()
@@ -283,12 +379,14 @@ def main():
             x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
             stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+            stats["nranks"] = ctx.kernel_seconds("lsmr.nranks")
         else:           # row-partitioned G, one RCCL all-reduce of G^T u (n floats) + one scalar per iteration
             t_l = time.perf_counter()
             x, info = lsmr_distributed(GpuLocalOps(ctx, G), d_b, n_model, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10)
             torch.cuda.synchronize()
             stats["lsmr_s"] = time.perf_counter() - t_l
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        stats["spmv_kind"], stats["spmvt_kind"] = ctx.kernel_seconds("spmv.kind"), ctx.kernel_seconds("spmvt.kind")
         stats["lsmr_itn"] = info["itn"]
         stats["nfail"] = nfail
         G.free()
@@ -316,6 +414,10 @@ def main():
         total_fields = nfield * world
         fmm_gbs = BYTES_PER_FIELD * nfield / stats["fmm_s"] / 1e9
         m, n, nnz = stats["m"], stats["n"], stats["nnz"]
+        traffic, traffic_src = profiled_traffic(a.workload, nfield, nnz)
+        pops = nfield * (nnodes * nnodes + 129 * 129)          # node acceptances per launch (upper bound: the refined grid
+        kind_ax = {0: "spmv_rows", 1: "spmv_rows_ldsx", 2: "spmv_rows_blocked + k_rows_combine"}  # stops at its edge)
+        kind_aty = {0: "spmv_rows (CSC gather)", 1: "spmvT_scatter + k_scatter_combine"}
         b_ax = nnz * 8 + (m + 1) * 8 + n * 4 + 2 * m * 4      # A*x : CSR stream + rowptr + x + u read/write
         b_aty = nnz * 8 + (n + 1) * 8 + m * 4 + 2 * n * 4
         out = {
@@ -327,23 +429,29 @@ def main():
                                    f"{len(PERIODS)} periods {PERIODS[0]:g}..{PERIODS[-1]:g} s, {a.sources} sources x "
                                    f"{rays_per_field} receivers per GPU ({nfield} fields, {nray} rays), "
                                    f"{a.lsmr_iters} LSMR iterations", "fields_per_gpu": nfield, "rays_per_gpu": nray},
-            "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fmm_gbs / HBM_PEAK_GBS,
-                         "traffic": PROFILED["fmm_traffic_bytes_per_field"] * nfield if calibrated else None,
-                         "note": "issue/latency-bound by the serial heap order of fast marching, not by HBM; "
-                                 f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
-                                 "FETCH_SIZE+WRITE_SIZE of " + PROFILED["source"] + " scaled to this launch (8-byte "
-                                 "accesses: raw counter values, the gfx950 x2 read correction is only calibrated for "
-                                 "16-byte streams)"},
-            "spmv": {"kernels": {"Ax": "spmv_rows_ldsx" if n <= 38 * 1024 else "spmv_rows", "ATy": "spmvT_scatter + k_scatter_combine"}, "bound": "hbm",
+            # the dominant kernel.  It is bound by the serial heap order of fast marching (instruction issue + small random record
+            # accesses), not by HBM bandwidth: `bound` says so; the HBM fraction of its algorithmic bytes is still reported
+            # (achieved / peak / frac) because the metric asks for it, next to what the kernel is really limited by (pops/s).
+            "roofline": {"kernel": "fmm_kernel", "bound": "latency", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fmm_gbs / HBM_PEAK_GBS, "traffic": traffic["fmm"],
+                         "node_acceptances_per_s": pops / stats["fmm_s"],
+                         "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
+                         "traffic_source": traffic_src,
+                         "note": "serial dependence chain per field (one heap pop after the other), all parallelism across "
+                                 f"fields; algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
+                                 "FETCH_SIZE + WRITE_SIZE per launch (8-byte accesses: raw counter values, the gfx950 x2 read "
+                                 "correction is only calibrated for 16-byte streams)"},
+            "spmv": {"kernels": {"Ax": kind_ax.get(int(stats.get("spmv_kind", -1)), "?"),
+                                 "ATy": kind_aty.get(int(stats.get("spmvt_kind", -1)), "?")}, "bound": "hbm",
                      "unit": "GB/s", "peak": HBM_PEAK_GBS,
                      "Ax": {"us": stats["spmv_s"] * 1e6, "achieved": b_ax / stats["spmv_s"] / 1e9,
-                            "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS,
-                            "traffic": PROFILED["spmv_ax_traffic_per_nnz"] * nnz if calibrated else None},
+                            "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["ax"]},
                      "ATy": {"us": stats["spmvt_s"] * 1e6, "achieved": b_aty / stats["spmvt_s"] / 1e9,
-                             "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS,
-                             "traffic": PROFILED["spmv_aty_traffic_per_nnz"] * nnz if calibrated else None},
+                             "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["aty"]},
                      "m": m, "n": n, "nnz": nnz},
+            "lsmr": {"driver": ("in-library RCCL (dazim_comm_init)" if native else "torch.distributed (backend nccl = RCCL)") if use_dist
+                               else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
+                     "host_syncs_per_iteration": 0.125 if (not use_dist or native) else 3},
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],

@@ -39,6 +39,34 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
   return 0;
 }
 
+namespace {
+__global__ void k_range_flag(int64_t n, const int *a, int lo, int hi, int *bad) {
+  bool b = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) b |= a[i] < lo || a[i] > hi;
+  if (b) atomicOr(bad, 1);
+}
+}  // namespace
+
+// Integer index arrays that cross the ABI (periods, kernel slots, field-of-ray, COO rows / columns) are validated on the device
+// before any kernel dereferences them: an index outside its range would otherwise read another period's grid or fault.
+int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what) {
+  if (n <= 0) return 0;
+  if (!a_dev) return dz_fail(ctx, DAZIM_E_BAD_ARG, "%s is NULL", what);
+  void *p;
+  int rc;
+  if ((rc = dz_scratch(ctx, "ctx.rangeflag", 16, &p))) return rc;
+  int *bad = (int *)p, hbad = 0;
+  DZ_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
+  int64_t nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_range_flag, dim3((unsigned)nb), dim3(256), 0, ctx->stream, n, a_dev, lo, hi, bad);
+  DZ_HIP(hipGetLastError());
+  DZ_HIP(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (hbad) return dz_fail(ctx, DAZIM_E_BAD_ARG, "%s outside %d..%d", what, lo, hi);
+  return 0;
+}
+
 extern "C" {
 
 int dazim_create(dazim_ctx **out, int device) {
@@ -65,6 +93,7 @@ void dazim_destroy(dazim_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && ctx->comm_release) ctx->comm_release(ctx);
   for (auto &kv : ctx->scratch)
     if (kv.second.first) (void)hipFree(kv.second.first);
   (void)hipEventDestroy(ctx->ev0);

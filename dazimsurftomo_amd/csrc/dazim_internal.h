@@ -23,6 +23,7 @@ struct dazim_ctx {
   std::map<std::string, std::pair<void *, size_t>> scratch;
   // RCCL communicator of a row-sharded solve (dazim_comm_init); nullptr = single GPU, RCCL never touched
   void *comm = nullptr;
+  void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
 };
 
@@ -40,6 +41,9 @@ int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
 
 bool dz_is_device_ptr(const void *p);
+
+// every a[i] of a DEVICE array inside lo..hi?  Returns 0, or DAZIM_E_BAD_ARG with "<what> outside lo..hi" as the message.
+int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what);
 
 // Staging helper: wraps a user pointer that may live on the host or on the device.
 template <class T>

@@ -899,6 +899,9 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     std::vector<int> hper(nfield);
     DZ_HIP(hipMemcpyAsync(hper.data(), A.period, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nfield; i++)
+      if (hper[i] < 1 || hper[i] > A.kmax)
+        return dz_fail(ctx, DAZIM_E_BAD_ARG, "period_idx[%d] = %d outside 1..%d (1-based, like periods(srcnum,knumi))", i, hper[i], A.kmax);
     std::vector<int> cnt(A.kmax + 2, 0);
     auto key = [&](int i) { const int k = hper[i]; return k < 1 || k > A.kmax ? A.kmax + 1 : k; };
     for (int i = 0; i < nfield; i++) cnt[key(i)]++;
@@ -961,7 +964,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
   if (!ctx) return DAZIM_E_BAD_ARG;
   dazim_geom g;
   if (dazim_geometry(nx, ny, goxd, gozd, dvxd, dvzd, &g)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad grid %dx%d", nx, ny);
-  if (kmax < 1 || nfield < 0 || !pv_u || !ttn_u || g.nnx > 32767 || g.nnz > 32767)
+  if (kmax < 1 || nfield < 0 || !pv_u || !ttn_u || (nfield > 0 && (!scx_u || !scz_u || !period_u)) || g.nnx > 32767 || g.nnz > 32767)
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_fmm_batch");
   DZ_HIP(hipSetDevice(ctx->device));
   const size_t nn = (size_t)g.nnx * g.nnz, npv = (size_t)(g.nvz + 2) * (g.nvx + 2), nr = (size_t)RM * RM;

@@ -552,7 +552,12 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   const bool joint = lsen_u != nullptr;
   dazim_geom g;
   if (dazim_geometry(nx, ny, goxd, gozd, dvxd, dvzd, &g)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad grid");
-  if (nray < 0 || nfield < 1 || nz < 2 || (size_t)g.nvx * g.nvz > 65535u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_rays_build_G");
+  if (nray < 0 || nfield < 1 || nz < 2 || kmax < 1 || (size_t)g.nvx * g.nvz > 65535u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_rays_build_G");
+  // every array the kernels dereference must be there: dazim_fmm_batch can be called without the refined outputs (ttnr, nstsr,
+  // boxes nullable there), but the ray tracer reads them next to the source (inv/CalSurfG.f90:1941-1952)
+  if (!vels_u || !scx_u || !scz_u || !period_u || !veln_u || !ttn_u || !ttnr_u || !nstsr_u || !boxes_u || !svs_u || !svp_u ||
+      !srho_u || !dsurf_u || (nray > 0 && (!field_u || !rcx_u || !rcz_u)))
+    return dz_fail(ctx, DAZIM_E_BAD_ARG, "dazim_rays_build_G: NULL array (the refined fields ttnr, nstsr and boxes of dazim_fmm_batch are required)");
   DZ_HIP(hipSetDevice(ctx->device));
   const size_t nn = (size_t)g.nnx * g.nnz, nr = (size_t)RM * RM, ncol = (size_t)nx * ny;
   DzBuf<float> vels, scx, scz, veln, ttn, ttnr, rcx, rcz, dsurf;
@@ -580,6 +585,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = dsurf.init(ctx, dsurf_u, nray, false, true))) return rc;
   DzBuf<float> lsen;
   if (joint && (rc = lsen.init(ctx, lsen_u, (size_t)(nz - 1) * kmax * ncol, true, false))) return rc;
+  // index conventions follow the reference: periods and kernel slots 1-based (periods(srcnum,knumi), knumi), field_of_ray 0-based
+  if ((rc = dz_check_range(ctx, period.dev, nfield, 1, kmax, "period_idx"))) return rc;
+  if ((rc = dz_check_range(ctx, kidx.dev, nfield, 1, kmax, "kernel_idx"))) return rc;
+  if ((rc = dz_check_range(ctx, field.dev, nray, 0, nfield - 1, "field_of_ray"))) return rc;
 
   RayArgs A;
   A.g = g;

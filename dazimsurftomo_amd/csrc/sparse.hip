@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64 * WPB) void spmv_rows(int64_t nrows, const int64
                                                         const float *__restrict__ val,
                                                         const float *__restrict__ x, float *__restrict__ out,
                                                         const float *__restrict__ beta_p, float beta_sign,
-                                                        double *__restrict__ sumsq) {
+                                                        double *__restrict__ sumsq, const int *__restrict__ guard) {
+  if (guard && *guard) return;   // LSMR has stopped (or skips this half-step): see LsmrState
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64
                                                            const int *__restrict__ idx, const float *__restrict__ val,
                                                            const float *__restrict__ x, float *__restrict__ out,
                                                            const float *__restrict__ beta_p, float beta_sign,
-                                                           double *__restrict__ sumsq) {
+                                                           double *__restrict__ sumsq, const int *__restrict__ guard) {
   extern __shared__ __attribute__((aligned(16))) float xs[];
+  if (guard && *guard) return;
   for (int64_t i = threadIdx.x * 4; i < nx; i += 64 * LWPB * 4) {
     if (i + 3 < nx)
       *reinterpret_cast<float4 *>(xs + i) = *reinterpret_cast<const float4 *>(x + i);
@@ -184,7 +186,9 @@ __global__ void finish_norm(const double *part, int np, float *res, double *res_
 // res[0] = sqrt(*sum) (after the all-reduce of a distributed norm)
 __global__ void k_sqrt_sum(const double *sum, float *res) { res[0] = (float)sqrt(sum[0]); }
 // v = w + sign*beta*v with the partial of ||v||^2 (distributed A^T u: w is the all-reduced product)
-__global__ void k_axpby_norm(int64_t n, const float *w, float *v, const float *beta_p, float beta_sign, double *part) {
+__global__ void k_axpby_norm(int64_t n, const float *w, float *v, const float *beta_p, float beta_sign, double *part,
+                             const int *guard) {
+  if (guard && *guard) return;
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
@@ -221,11 +225,118 @@ __global__ void k_update(int64_t n, float f1, float f2, float f3, float *h, floa
   }
   block_partial(sq, part);
 }
+// ---- LSMR with the scalar recurrences on the device (inv/lsmrModule.f90:484-616) ----------------------------------------
+// The host only enqueues kernels: alpha, beta, the plane rotations, the norm estimates and the stopping tests live in one
+// LsmrState in HBM, so an iteration needs no host round trip.  The stop flag is looked at every few iterations; the
+// iterations enqueued behind the one that stopped return at once (every kernel of the loop starts with `if (*guard) return`),
+// so x, itn and the norm estimates are exactly those of the stopping iteration.
+struct LsmrState {
+  float alpha, beta, alphabar, zetabar, rho, rhobar, cbar, sbar;
+  float betadd, betad, rhodold, tautildeold, thetatilde, zeta, d;
+  float normA2, maxrbar, minrbar, normb, ctol;
+  float normA, condA, normr, normAr, normx;
+  float damp, atol, btol;
+  float alpha_new;   // alpha of the running iteration: k_alpha_update -> k_tests
+  int itn, istop, itnlim;
+  int stop;          // != 0: LSMR has stopped; guard of the first half-step (u = A v - alpha u)
+  int stop2;         // stop, or beta == 0 in the running iteration: guard of the second half-step (skipped as a block, :490-503)
+};
+__device__ __forceinline__ float dz_d2norm(float a, float bb) {   // d2norm, :708-721
+  const float scale = fabsf(a) + fabsf(bb);
+  if (scale == 0.0f) return 0.0f;
+  return scale * sqrtf((a / scale) * (a / scale) + (bb / scale) * (bb / scale));
+}
+// one pass of the scalar recurrences, statement for statement :506-588 (fp32, no contraction); s -> state after the
+// iteration that produced (alpha, beta); f1..f3 are the coefficients of the hbar / x / h updates (:539-541)
+__device__ __forceinline__ void lsmr_recur(LsmrState &s, float alpha, float beta, float &f1, float &f2, float &f3) {
+  const float damp = s.damp;
+  float alphabar = s.alphabar, zetabar = s.zetabar, rho = s.rho, rhobar = s.rhobar, cbar = s.cbar, sbar = s.sbar;
+  float betadd = s.betadd, betad = s.betad, rhodold = s.rhodold, tautildeold = s.tautildeold, thetatilde = s.thetatilde;
+  float zeta = s.zeta, d = s.d, normA2 = s.normA2, maxrbar = s.maxrbar, minrbar = s.minrbar;
+  const int itn = s.itn + 1;
+  const float alphahat = dz_d2norm(alphabar, damp);
+  const float chat = alphabar / alphahat, shat = damp / alphahat;
+  const float rhoold = rho;
+  rho = dz_d2norm(alphahat, beta);
+  const float c = alphahat / rho, sn = beta / rho;
+  const float thetanew = sn * alpha;
+  alphabar = c * alpha;
+  const float rhobarold = rhobar, zetaold = zeta;
+  const float thetabar = sbar * rho, rhotemp = cbar * rho;
+  rhobar = dz_d2norm(cbar * rho, thetanew);
+  cbar = cbar * rho / rhobar;
+  sbar = thetanew / rhobar;
+  zeta = cbar * zetabar;
+  zetabar = -sbar * zetabar;
+  f1 = thetabar * rho / (rhoold * rhobarold);
+  f2 = zeta / (rho * rhobar);
+  f3 = thetanew / rho;
+  const float betaacute = chat * betadd, betacheck = -shat * betadd;
+  const float betahat = c * betaacute;
+  betadd = -sn * betaacute;
+  const float thetatildeold = thetatilde;
+  const float rhotildeold = dz_d2norm(rhodold, thetabar);
+  const float ctildeold = rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
+  thetatilde = stildeold * rhobar;
+  rhodold = ctildeold * rhobar;
+  betad = -stildeold * betad + ctildeold * betahat;
+  tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+  const float taud = (zeta - thetatilde * tautildeold) / rhodold;
+  d = d + betacheck * betacheck;
+  s.normr = sqrtf(d + (betad - taud) * (betad - taud) + betadd * betadd);
+  normA2 = normA2 + beta * beta;
+  s.normA = sqrtf(normA2);
+  normA2 = normA2 + alpha * alpha;
+  maxrbar = fmaxf(maxrbar, rhobarold);
+  if (itn > 1) minrbar = fminf(minrbar, rhobarold);
+  s.condA = fmaxf(maxrbar, rhotemp) / fminf(minrbar, rhotemp);
+  s.normAr = fabsf(zetabar);
+  s.alpha = alpha; s.beta = beta; s.alphabar = alphabar; s.zetabar = zetabar; s.rho = rho; s.rhobar = rhobar; s.cbar = cbar;
+  s.sbar = sbar; s.betadd = betadd; s.betad = betad; s.rhodold = rhodold; s.tautildeold = tautildeold;
+  s.thetatilde = thetatilde; s.zeta = zeta; s.d = d; s.normA2 = normA2; s.maxrbar = maxrbar; s.minrbar = minrbar;
+  s.itn = itn;
+}
+// sum of np partials by the first wavefront of the block in a fixed order: every block, every launch gets the same bits
+__device__ __forceinline__ double block_total(const double *part, int np) {
+  __shared__ double s_t;
+  if (threadIdx.x < 64) {
+    double t = 0.0;
+    for (int i = threadIdx.x; i < np; i += 64) t += part[i];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) s_t = t;
+  }
+  __syncthreads();
+  return s_t;
+}
+// sum of the partials -> sum[0] (row-sharded solve: the squared norm of u before its all-reduce)
+__global__ void k_total(const double *part, int np, double *sum, const int *guard) {
+  if (guard && *guard) return;
+  const double t = block_total(part, np);
+  if (threadIdx.x == 0) sum[0] = t;
+}
+// beta = ||u|| from the partials of the product that wrote u (or from the all-reduced sum); u /= beta; localVEnqueue(v)
+// (:487-492).  beta == 0 skips the second half-step of this iteration (stop2).
+__global__ void k_beta_scal_u(int64_t m, float *u, const double *part, int np, const double *sum_in, int64_t n, const float *v,
+                              float *lv_slot, LsmrState *S) {
+  if (S->stop) return;
+  const double t = sum_in ? sum_in[0] : block_total(part, np);
+  const float beta = (float)sqrt(t);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S->beta = beta;
+    S->stop2 = !(beta > 0.0f);
+  }
+  if (!(beta > 0.0f)) return;
+  const float a = 1.0f / beta;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < m; i += (int64_t)gridDim.x * VB) u[i] = a * u[i];
+  if (lv_slot)
+    for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) lv_slot[i] = v[i];
+}
 // local reorthogonalisation step q (localVOrtho, inv/lsmrModule.f90:733-748), modified Gram-Schmidt:
 // d = sum(part_in) (the dot of v with lv_prev computed by the previous launch); v -= d*lv_prev;
-// part_out = partial dots of the updated v with lv_next.  lv_prev / lv_next may be null.
+// part_out = partial dots of the updated v with lv_next, or -- last step, lv_next null -- partials of ||v||^2.
 __global__ void k_reorth(int64_t n, float *v, const float *lv_prev, const double *part_in, int np,
-                         const float *lv_next, double *part_out) {
+                         const float *lv_next, double *part_out, const int *guard) {
+  if (guard && *guard) return;
   __shared__ float s_d;
   if (lv_prev) {
     if (threadIdx.x < 64) {
@@ -244,9 +355,78 @@ __global__ void k_reorth(int64_t n, float *v, const float *lv_prev, const double
       vi = vi - d * lv_prev[i];
       v[i] = vi;
     }
-    if (lv_next) acc += (double)vi * lv_next[i];
+    acc += lv_next ? (double)vi * lv_next[i] : (double)vi * vi;
   }
-  if (lv_next) block_partial(acc, part_out);
+  if (part_out) block_partial(acc, part_out);
+}
+// alpha = ||v|| (:499); v /= alpha; rotations; hbar = h - f1*hbar ; x += f2*hbar ; h = v - f3*h (:539-541); partials of ||x||^2.
+// Every block evaluates the recurrences from the (read-only here) state; k_tests commits them.
+__global__ void k_alpha_update(int64_t n, float *v, float *h, float *hbar, float *x, const double *part, int np,
+                               double *partx, LsmrState *S) {
+  if (S->stop) return;
+  __shared__ float s_f[4];
+  const bool half2 = !S->stop2;                  // beta > 0: v was renewed and alpha with it (else both keep their values)
+  const double t = half2 ? block_total(part, np) : 0.0;
+  if (threadIdx.x == 0) {
+    LsmrState st = *S;
+    const float alpha = half2 ? (float)sqrt(t) : st.alpha;
+    float f1, f2, f3;
+    lsmr_recur(st, alpha, st.beta, f1, f2, f3);
+    s_f[0] = f1; s_f[1] = f2; s_f[2] = f3; s_f[3] = alpha;
+    if (blockIdx.x == 0) S->alpha_new = alpha;
+  }
+  __syncthreads();
+  const float f1 = s_f[0], f2 = s_f[1], f3 = s_f[2], alpha = s_f[3];
+  const bool scal = half2 && alpha > 0.0f;
+  const float a = scal ? 1.0f / alpha : 1.0f;
+  double sq = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    float vi = v[i];
+    if (scal) {
+      vi = a * vi;
+      v[i] = vi;
+    }
+    const float hb = h[i] - f1 * hbar[i];
+    const float xn = x[i] + f2 * hb;
+    hbar[i] = hb;
+    x[i] = xn;
+    h[i] = vi - f3 * h[i];
+    sq += (double)xn * xn;
+  }
+  block_partial(sq, partx);
+}
+// normx (:590), stopping tests (:595-616), commit of the state, one trace record per iteration (the columns of the
+// reference's iteration log, format 1500 at :679, plus test3 and rtol which decide whether the line is printed)
+__global__ void k_tests(const double *partx, int npx, const float *x, LsmrState *S, dazim_lsmr_rec *trace, int trace_cap) {
+  if (S->stop) return;
+  const double t = block_total(partx, npx);
+  if (threadIdx.x != 0) return;
+  LsmrState st = *S;
+  float f1, f2, f3;
+  lsmr_recur(st, st.alpha_new, st.beta, f1, f2, f3);
+  const float normx = (float)sqrt(t);
+  st.normx = normx;
+  const float test1 = st.normr / st.normb, test2 = st.normAr / (st.normA * st.normr), test3 = 1.0f / st.condA;
+  const float t1 = test1 / (1.0f + st.normA * normx / st.normb);
+  const float rtol = st.btol + st.atol * st.normA * normx / st.normb;
+  int istop = 0;
+  if (st.itn >= st.itnlim) istop = 7;
+  if (1.0f + test3 <= 1.0f) istop = 6;
+  if (1.0f + test2 <= 1.0f) istop = 5;
+  if (1.0f + t1 <= 1.0f) istop = 4;
+  if (test3 <= st.ctol) istop = 3;
+  if (test2 <= st.atol) istop = 2;
+  if (test1 <= rtol) istop = 1;
+  st.istop = istop;
+  st.stop = istop != 0;
+  st.stop2 = st.stop;
+  if (trace && st.itn < trace_cap) {
+    dazim_lsmr_rec r;
+    r.itn = st.itn; r.x1 = x[0]; r.normr = st.normr; r.normAr = st.normAr; r.test1 = test1; r.test2 = test2;
+    r.test3 = test3; r.rtol = rtol; r.normA = st.normA; r.condA = st.condA;
+    trace[st.itn] = r;
+  }
+  *S = st;
 }
 __global__ void k_scale_rows(int64_t nrows, const int64_t *ptr, float *val, const float *w) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -256,8 +436,14 @@ __global__ void k_scale_rows(int64_t nrows, const int64_t *ptr, float *val, cons
   }
 }
 // out[col[i]] += |val[i]|: the reference's DWS, norm(col(i))=norm(col(i))+abs(rw(i)), inv/Main_Jt.f90:477-481
-__global__ void k_col_abs_sums(int64_t n, const int *col, const float *val, float *out) {
-  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) atomicAdd(&out[col[i]], fabsf(val[i]));
+// Accumulated in 64-bit fixed point (integer addition is associative: the result does not depend on the order in which the
+// atomics land, so DWS is reproducible run to run), then converted.
+__global__ void k_col_abs_sums(int64_t n, const int *col, const float *val, double scale, unsigned long long *acc) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB)
+    atomicAdd(&acc[col[i]], (unsigned long long)__double2ll_rn((double)fabsf(val[i]) * scale));
+}
+__global__ void k_fixed_to_float(int64_t n, const unsigned long long *acc, double inv_scale, float *out) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) out[i] = (float)((double)acc[i] * inv_scale);
 }
 __global__ void k_gather_f(int64_t n, const unsigned *perm, const float *src, float *dst) {
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) dst[i] = src[perm[i]];
@@ -423,8 +609,9 @@ template <int GL, int NG>
 __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
                                                           const int64_t *__restrict__ cbptr, const int *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
-                                                          double scale, long long *__restrict__ part) {
+                                                          double scale, long long *__restrict__ part, const int *__restrict__ guard) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];
+  if (guard && *guard) return;
   const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
   const int c0 = cb * cbw;
   const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
@@ -450,7 +637,8 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
 // out[c] = beta*out[c] + sum_chunks part[chunk][c] / scale ; partial ||out||^2
 __global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__restrict__ part, double inv_scale,
                                   float *__restrict__ out, const float *__restrict__ beta_p, float beta_sign,
-                                  double *__restrict__ sumsq) {
+                                  double *__restrict__ sumsq, const int *__restrict__ guard) {
+  if (guard && *guard) return;
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
   for (int64_t c = (int64_t)blockIdx.x * VB + threadIdx.x; c < ncols; c += (int64_t)gridDim.x * VB) {
@@ -477,8 +665,9 @@ template <int GL, int NG>
 __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int nset, int npair, int ncb, int cbw, int64_t ncols,
                                                               const int64_t *__restrict__ cbptr, const int *__restrict__ col,
                                                               const float *__restrict__ val, const float *__restrict__ x,
-                                                              float *__restrict__ part) {
+                                                              float *__restrict__ part, const int *__restrict__ guard) {
   extern __shared__ __attribute__((aligned(16))) float xblk[];
+  if (guard && *guard) return;
   const int set = blockIdx.x / npair, pr = blockIdx.x - set * npair;
   const int cb0 = 2 * pr, cb1 = (cb0 + 2 < ncb) ? cb0 + 2 : ncb;
   const int c0 = cb0 * cbw;
@@ -503,7 +692,9 @@ __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int
 }
 // out[r] = beta*out[r] + sum_pairs part[pair][r] ; partial ||out||^2
 __global__ void k_rows_combine(int64_t nrows, int npair, const float *__restrict__ part, float *__restrict__ out,
-                               const float *__restrict__ beta_p, float beta_sign, double *__restrict__ sumsq) {
+                               const float *__restrict__ beta_p, float beta_sign, double *__restrict__ sumsq,
+                               const int *__restrict__ guard) {
+  if (guard && *guard) return;
   const float beta = beta_p ? beta_sign * beta_p[0] : beta_sign;
   double sq = 0.0;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * blockDim.x) {
@@ -538,15 +729,15 @@ int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx = -1) {
 // nx = length of the gathered vector; nblocks must come from spmv_blocks(ctx, nrows, nx)
 int launch_spmv(dazim_ctx *ctx, int64_t nrows, int64_t nx, const int64_t *ptr, const int *idx, const float *val,
                 const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
-                int nblocks) {
+                int nblocks, const int *guard = nullptr) {
   if (use_ldsx(ctx, nrows, nx)) {
     const size_t lds = (size_t)((nx + 3) & ~(int64_t)3) * 4;
     DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(spmv_rows_ldsx, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x, out,
-                       beta_p, beta_sign, sumsq);
+                       beta_p, beta_sign, sumsq, guard);
   } else {
     hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
-                       beta_p, beta_sign, sumsq);
+                       beta_p, beta_sign, sumsq, guard);
   }
   DZ_HIP(hipGetLastError());
   return 0;
@@ -644,15 +835,19 @@ bool use_scatter(dazim_ctx *ctx, const dazim_csr *A) {
 }
 // x(out, n) = beta*x + A^T y ; returns the number of ||out||^2 partials written to sumsq in *npart
 int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax, float *out, const float *beta_p,
-                 float beta_sign, double *sumsq, int *npart) {
-  if (!use_scatter(ctx, A)) {
+                 float beta_sign, double *sumsq, int *npart, const int *guard = nullptr) {
+  const double pm = (double)A->vmax * (double)ymax;
+  ctx->ksec["spmvt.kind"] = (use_scatter(ctx, A) && std::isfinite(pm)) ? 1 : 0;
+  // non-finite values (NaN / Inf in G or y) cannot be put on the fixed-point grid: the gather form propagates them like
+  // the reference's plain loop would
+  if (!use_scatter(ctx, A) || !std::isfinite(pm)) {
     if (!A->colptr) {
       int rc0 = build_transpose(ctx, const_cast<dazim_csr *>(A));
       if (rc0) return rc0;
     }
     const int gn = spmv_blocks(ctx, A->n, A->m);
     if (npart) *npart = gn;
-    return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn);
+    return launch_spmv(ctx, A->n, A->m, A->colptr, A->row, A->tval, y, out, beta_p, beta_sign, sumsq, gn, guard);
   }
   int nchunk = ctx->num_cu / A->ncb;
   if (nchunk < 1) nchunk = 1;
@@ -660,10 +855,14 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   void *p;
   if ((rc = dz_scratch(ctx, "spmvt.part", (size_t)nchunk * A->n * 8, &p))) return rc;
   long long *part = (long long *)p;
-  const double pm = (double)A->vmax * (double)ymax;
   int e = 0;
   if (pm > 0) (void)frexp(pm, &e);   // pm = f * 2^e, 0.5 <= f < 1  ->  pm < 2^e
-  const double scale = ldexp(1.0, 40 - e);
+  // fractional bits: every term is below 2^fb in fixed point and a column holds at most m of them, so the int64 sum needs
+  // fb + ceil(log2 m) <= 62.  40 bits up to 4 M rows (quantum 2^-40 of the largest term), fewer beyond (still < fp32 round-off)
+  int lgm = 0;
+  while (((int64_t)1 << lgm) < A->m) lgm++;
+  const int fb = 62 - lgm < 40 ? 62 - lgm : 40;
+  const double scale = ldexp(1.0, fb - e);
   const size_t lds = (size_t)A->cbw * 8;
   // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
   bool shortseg = A->nnz < (int64_t)400 * A->m * A->ncb;   // measured: 16 lanes win at 141 and 296 entries per segment, 64 at 553
@@ -671,15 +870,15 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   if (shortseg) {
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmvT_scatter<16, 2>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part);
+                       A->n, A->cbptr, A->col, A->val, y, scale, part, guard);
   } else {
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmvT_scatter<64, 4>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part);
+                       A->n, A->cbptr, A->col, A->val, y, scale, part, guard);
   }
   const int nb = nblk(A->n, NPART);
   hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
-                     beta_sign, sumsq);
+                     beta_sign, sumsq, guard);
   DZ_HIP(hipGetLastError());
   if (npart) *npart = nb;
   return 0;
@@ -691,11 +890,12 @@ bool use_blocked(dazim_ctx *ctx, const dazim_csr *A) {
 }
 // y(out, m) = beta*y + A x ; the number of ||out||^2 partials written to sumsq goes to *npart
 int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out, const float *beta_p, float beta_sign,
-                 double *sumsq, int *npart) {
+                 double *sumsq, int *npart, const int *guard = nullptr) {
+  ctx->ksec["spmv.kind"] = use_blocked(ctx, A) ? 2 : (use_ldsx(ctx, A->m, A->n) ? 1 : 0);
   if (!use_blocked(ctx, A)) {
     const int gm = spmv_blocks(ctx, A->m, A->n);
     if (npart) *npart = gm;
-    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm);
+    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm, guard);
   }
   const int npair = (A->ncb + 1) / 2;
   int nset = ctx->num_cu / npair;
@@ -710,14 +910,14 @@ int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out,
   if (shortseg) {
     DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmv_rows_blocked<16, 2>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
-                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part);
+                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part, guard);
   } else {
     DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((spmv_rows_blocked<64, 4>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
-                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part);
+                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part, guard);
   }
   const int nb = nblk(A->m, NPART);
-  hipLaunchKernelGGL(k_rows_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->m, npair, part, out, beta_p, beta_sign, sumsq);
+  hipLaunchKernelGGL(k_rows_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->m, npair, part, out, beta_p, beta_sign, sumsq, guard);
   DZ_HIP(hipGetLastError());
   if (npart) *npart = nb;
   return 0;
@@ -729,7 +929,8 @@ extern "C" {
 
 int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
   if (!A) return 0;
-  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx) DZ_HIP(hipStreamSynchronize(ctx->stream));   // (a matrix may outlive its context: the arrays are still freed)
+  else (void)hipDeviceSynchronize();
   void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr};
   for (void *p : ps)
     if (p) (void)hipFree(p);
@@ -757,6 +958,7 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   if ((rc = icol.init(ctx, icol_u, nnz, true, false))) return rc;
   if ((rc = rw.init(ctx, rw_u, nnz, true, false))) return rc;
   dazim_csr *A = new dazim_csr;
+  auto fail = [&](int r) { dazim_csr_free(ctx, A); return r; };   // no leak on the error paths below
   A->m = m;
   A->n = n;
   A->nnz = nnz;
@@ -767,15 +969,15 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   unsigned *k0, *k1, *v0, *perm;
   int *bad;
   void *p;
-  if ((rc = dz_scratch(ctx, "csr.k0", nz * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.k0", nz * 4, &p))) return fail(rc);
   k0 = (unsigned *)p;
-  if ((rc = dz_scratch(ctx, "csr.k1", nz * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.k1", nz * 4, &p))) return fail(rc);
   k1 = (unsigned *)p;
-  if ((rc = dz_scratch(ctx, "csr.v0", nz * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.v0", nz * 4, &p))) return fail(rc);
   v0 = (unsigned *)p;
-  if ((rc = dz_scratch(ctx, "csr.perm", nz * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.perm", nz * 4, &p))) return fail(rc);
   perm = (unsigned *)p;
-  if ((rc = dz_scratch(ctx, "csr.bad", 16, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "csr.bad", 16, &p))) return fail(rc);
   bad = (int *)p;
   DZ_HIP(hipMemsetAsync(bad, 0, 4, ctx->stream));
   const int nb = nblk(nnz);
@@ -795,7 +997,7 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
     // ---- canonical CSR: stable sort by column, then stable sort by row -> rows ascending, columns
     // ascending inside a row (entries of equal (row,col) keep the caller's order) ----
     unsigned *permc;
-    if ((rc = dz_scratch(ctx, "csr.permc", nz * 4, &p))) return rc;
+    if ((rc = dz_scratch(ctx, "csr.permc", nz * 4, &p))) return fail(rc);
     permc = (unsigned *)p;
     hipLaunchKernelGGL(k_iota_keys, dim3(nb), dim3(VB), 0, ctx->stream, nnz, icol.dev, k0, v0);
     size_t tb = 0, tb1 = 0;
@@ -803,7 +1005,7 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
     DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb1, k0, k1, permc, perm, (size_t)nnz, 0, rbits, ctx->stream));
     if (tb1 > tb) tb = tb1;
     void *tmp;
-    if ((rc = dz_scratch(ctx, "csr.tmp", tb + 256, &tmp))) return rc;
+    if ((rc = dz_scratch(ctx, "csr.tmp", tb + 256, &tmp))) return fail(rc);
     DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, permc, (size_t)nnz, 0, cbits, ctx->stream));
     hipLaunchKernelGGL(k_gather_i, dim3(nb), dim3(VB), 0, ctx->stream, nnz, permc, irow.dev, (int *)k0, -1);
     DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, permc, perm, (size_t)nnz, 0, rbits, ctx->stream));
@@ -814,8 +1016,8 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   } else {
     DZ_HIP(hipMemsetAsync(A->rowptr, 0, (m + 1) * 8, ctx->stream));
   }
-  if ((rc = build_colblocks(ctx, A))) return rc;
-  if ((rc = invalidate_transpose(A))) return rc;
+  if ((rc = build_colblocks(ctx, A))) return fail(rc);
+  if ((rc = invalidate_transpose(A))) return fail(rc);
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -829,8 +1031,10 @@ int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *
   A->m = m; A->n = n; A->nnz = nnz;
   A->rowptr = rowptr; A->col = col; A->val = val;
   int rc;
-  if ((rc = build_colblocks(ctx, A))) return rc;
-  if ((rc = invalidate_transpose(A))) return rc;
+  if ((rc = build_colblocks(ctx, A)) || (rc = invalidate_transpose(A))) {
+    dazim_csr_free(ctx, A);   // ownership was taken: the arrays go with it
+    return rc;
+  }
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
@@ -922,8 +1126,16 @@ int dazim_csr_col_abs_sums(dazim_ctx *ctx, const dazim_csr *A, float *out_u) {
   DzBuf<float> out;
   int rc;
   if ((rc = out.init(ctx, out_u, A->n, false, true))) return rc;
-  DZ_HIP(hipMemsetAsync(out.dev, 0, (size_t)A->n * 4, ctx->stream));
-  if (A->nnz) hipLaunchKernelGGL(k_col_abs_sums, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->col, A->val, out.dev);
+  void *p;
+  if ((rc = dz_scratch(ctx, "csr.colacc", (size_t)A->n * 8, &p))) return rc;
+  unsigned long long *acc = (unsigned long long *)p;
+  DZ_HIP(hipMemsetAsync(acc, 0, (size_t)A->n * 8, ctx->stream));
+  int e = 0, lgm = 0;
+  if (A->vmax > 0) (void)frexp((double)A->vmax, &e);
+  while (((int64_t)1 << lgm) < A->m) lgm++;
+  const double scale = ldexp(1.0, (62 - lgm < 40 ? 62 - lgm : 40) - e);
+  if (A->nnz) hipLaunchKernelGGL(k_col_abs_sums, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->col, A->val, scale, acc);
+  hipLaunchKernelGGL(k_fixed_to_float, dim3(nblk(A->n)), dim3(VB), 0, ctx->stream, A->n, acc, 1.0 / scale, out.dev);
   DZ_HIP(hipGetLastError());
   if ((rc = out.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -986,6 +1198,7 @@ int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128) {
   ncclComm_t comm;
   DZ_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
   ctx->comm = (void *)comm;
+  ctx->comm_release = [](dazim_ctx *c) { (void)dazim_comm_free(c); };
   ctx->nranks = nranks;
   ctx->rank = rank;
   return 0;
@@ -1002,72 +1215,122 @@ int dazim_comm_free(dazim_ctx *ctx) {
   return 0;
 }
 
-// LSMR, inv/lsmrModule.f90:36-750.  Vectors live on the device; the scalar recurrences (plane
-// rotations, norm estimates, stopping rules) run on the host in fp32 exactly as written there.
-int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,
-               float conlim, int itnlim, int localSize, float *x_u, int *istop_o, int *itn_o,
-               float *normA_o, float *condA_o, float *normr_o, float *normAr_o, float *normx_o) {
-  if (!ctx || !A || !b_u || !x_u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_lsmr");
+// LSMR, inv/lsmrModule.f90:36-750.  Vectors AND scalars live on the device (LsmrState above); the host enqueues
+// iterations and looks at the stop flag every CHECK iterations, one batch behind the one being enqueued, so the GPU never waits
+// for the host.  With a communicator attached (dazim_comm_init) A and b are this rank's rows of one global system: one scalar
+// all-reduce for ||u||^2 and one all-reduce of the n floats of A_p^T u_p per iteration, the state is replicated.
+int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,
+                      float conlim, int itnlim, int localSize, float *x_u, int *istop_o, int *itn_o,
+                      float *normA_o, float *condA_o, float *normr_o, float *normAr_o, float *normx_o,
+                      dazim_lsmr_rec *trace, int trace_cap, int *trace_n) {
+  if (!ctx || !A || !b_u || !x_u || (trace && trace_cap < 1)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_lsmr");
   DZ_HIP(hipSetDevice(ctx->device));
   const int64_t m = A->m, n = A->n;
   DzBuf<float> b, x;
   int rc;
-  if ((rc = b.init(ctx, b_u, m, true, false))) return rc;
-  if ((rc = x.init(ctx, x_u, n, false, true))) return rc;
   ncclComm_t comm = (ncclComm_t)ctx->comm;   // non-null: A, b are this rank's rows of one global system
   void *p;
   double *d_sum = nullptr;
   float *wbuf = nullptr;
   int64_t m_glob = m;
-  if (comm) {
-    if ((rc = dz_scratch(ctx, "lsmr.sum", 64, &p))) return rc;
-    d_sum = (double *)p;
-    if ((rc = dz_scratch(ctx, "lsmr.w", n * 4, &p))) return rc;
-    wbuf = (float *)p;
+  int localVecs = 0;
+  float *u = nullptr, *v = nullptr, *h = nullptr, *hbar = nullptr, *localV = nullptr, *d_scal = nullptr;
+  double *part = nullptr, *part2 = nullptr, *partx = nullptr;
+  LsmrState *S = nullptr;
+  dazim_lsmr_rec *d_trace = nullptr;
+  const int gm = spmv_blocks(ctx, m, n), gn = spmv_blocks(ctx, n, m);
+  // ---- everything that can fail locally comes first, so that a row-sharded solve can agree on it before any rank waits in
+  // a collective for a rank that has already returned ----
+  auto setup = [&]() -> int {
+    int r;
+    if ((r = b.init(ctx, b_u, m, true, false))) return r;
+    if ((r = x.init(ctx, x_u, n, false, true))) return r;
+    if (comm) {
+      if ((r = dz_scratch(ctx, "lsmr.sum", 64, &p))) return r;
+      d_sum = (double *)p;
+      if ((r = dz_scratch(ctx, "lsmr.w", n * 4, &p))) return r;
+      wbuf = (float *)p;
+    }
+    if ((r = dz_scratch(ctx, "lsmr.u", m * 4, &p))) return r;
+    u = (float *)p;
+    if ((r = dz_scratch(ctx, "lsmr.v", n * 4, &p))) return r;
+    v = (float *)p;
+    if ((r = dz_scratch(ctx, "lsmr.h", n * 4, &p))) return r;
+    h = (float *)p;
+    if ((r = dz_scratch(ctx, "lsmr.hbar", n * 4, &p))) return r;
+    hbar = (float *)p;
+    const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
+    if ((r = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return r;
+    part = (double *)p;
+    if ((r = dz_scratch(ctx, "lsmr.part2", (size_t)NPART * 8 * 2, &p))) return r;
+    part2 = (double *)p;
+    if ((r = dz_scratch(ctx, "lsmr.partx", (size_t)NPART * 8, &p))) return r;
+    partx = (double *)p;
+    if ((r = dz_scratch(ctx, "lsmr.scal", 64, &p))) return r;
+    d_scal = (float *)p;
+    if ((r = dz_scratch(ctx, "lsmr.state", sizeof(LsmrState), &p))) return r;
+    S = (LsmrState *)p;
+    if (trace) {
+      if ((r = dz_scratch(ctx, "lsmr.trace", (size_t)trace_cap * sizeof(dazim_lsmr_rec), &p))) return r;
+      d_trace = (dazim_lsmr_rec *)p;
+    }
+    if (!use_scatter(ctx, A) && !A->colptr && (r = build_transpose(ctx, const_cast<dazim_csr *>(A)))) return r;
+    return 0;
+  };
+  rc = setup();
+  if (comm) {   // agree on (failure, n, m_total): every rank leaves together or none does
+    long long hv[4] = {rc != 0 ? 1 : 0, (long long)n, -(long long)n, 0}, *dv = nullptr;
     double hm = (double)m;
-    DZ_HIP(hipMemcpyAsync(d_sum, &hm, 8, hipMemcpyHostToDevice, ctx->stream));
-    DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
-    DZ_HIP(hipMemcpyAsync(&hm, d_sum, 8, hipMemcpyDeviceToHost, ctx->stream));
-    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    bool ok = rc == 0 || d_sum != nullptr;
+    if (hipMalloc((void **)&dv, sizeof hv + 8) != hipSuccess) return dz_fail(ctx, -3, "row-sharded LSMR: no memory for the consensus buffer");
+    (void)hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, ctx->stream);
+    (void)hipMemcpyAsync(dv + 4, &hm, 8, hipMemcpyHostToDevice, ctx->stream);
+    ncclResult_t r1 = ncclAllReduce(dv, dv, 3, ncclInt64, ncclMax, comm, ctx->stream);
+    ncclResult_t r2 = ncclAllReduce(dv + 4, dv + 4, 1, ncclDouble, ncclSum, comm, ctx->stream);
+    (void)hipMemcpyAsync(hv, dv, sizeof hv, hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipMemcpyAsync(&hm, dv + 4, 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dv);
+    (void)ok;
+    if (rc) return rc;
+    if (r1 != ncclSuccess || r2 != ncclSuccess || e != hipSuccess) return dz_fail(ctx, -2000, "row-sharded LSMR: consensus all-reduce failed");
+    if (hv[0]) return dz_fail(ctx, -2001, "row-sharded LSMR: another rank failed during set-up");
+    if (hv[1] != -hv[2]) return dz_fail(ctx, DAZIM_E_BAD_ARG, "row-sharded LSMR: the ranks disagree on the number of columns (%lld here, %lld elsewhere)", (long long)n, hv[1]);
     m_glob = (int64_t)hm;
+  } else if (rc) {
+    return rc;
   }
-  int localVecs = localSize < 0 ? 0 : localSize;
+  localVecs = localSize < 0 ? 0 : localSize;
   if (m_glob < localVecs) localVecs = (int)m_glob;
   if (n < localVecs) localVecs = (int)n;
-  float *u, *v, *h, *hbar, *localV = nullptr, *d_scal;
-  double *part, *part2;
-  if ((rc = dz_scratch(ctx, "lsmr.u", m * 4, &p))) return rc;
-  u = (float *)p;
-  if ((rc = dz_scratch(ctx, "lsmr.v", n * 4, &p))) return rc;
-  v = (float *)p;
-  if ((rc = dz_scratch(ctx, "lsmr.h", n * 4, &p))) return rc;
-  h = (float *)p;
-  if ((rc = dz_scratch(ctx, "lsmr.hbar", n * 4, &p))) return rc;
-  hbar = (float *)p;
-  if (localVecs > 0) {
+  if (localVecs > 0) {   // (after the consensus: sized by the global row count)
     if ((rc = dz_scratch(ctx, "lsmr.localV", (size_t)n * localVecs * 4, &p))) return rc;
     localV = (float *)p;
   }
-  const int gm = spmv_blocks(ctx, m, n), gn = spmv_blocks(ctx, n, m);
-  int gn_t = gn, gm_t = gm;   // partial counts of the last products
-  const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
-  if ((rc = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return rc;
-  part = (double *)p;
-  if ((rc = dz_scratch(ctx, "lsmr.part2", (size_t)NPART * 8 * 2, &p))) return rc;
-  part2 = (double *)p;
-  if ((rc = dz_scratch(ctx, "lsmr.scal", 64, &p))) return rc;
-  d_scal = (float *)p;  // [0] = last norm (beta or alpha), kept on the device for the next kernel
-  struct Guard {   // pinned scalars + the two timing events, released on every exit path
-    float *h = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+  constexpr int CHECK = 8, NSLOT = 2;
+  struct Guard {   // pinned state copies + events, released on every exit path
+    LsmrState *h = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, done[NSLOT] = {}, ta[NSLOT][4] = {};
     ~Guard() {
       if (e0) (void)hipEventDestroy(e0);
       if (e1) (void)hipEventDestroy(e1);
+      for (int i = 0; i < NSLOT; i++) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        for (int j = 0; j < 4; j++)
+          if (ta[i][j]) (void)hipEventDestroy(ta[i][j]);
+      }
       if (h) (void)hipHostFree(h);
     }
   } guard;
-  DZ_HIP(hipHostMalloc((void **)&guard.h, 64));
-  float *h_scal = guard.h;
+  DZ_HIP(hipHostMalloc((void **)&guard.h, sizeof(LsmrState) * (NSLOT + 1) + 64));
+  LsmrState *h_state = guard.h;
+  float *h_scal = (float *)(guard.h + NSLOT + 1);
+  DZ_HIP(hipEventCreate(&guard.e0));
+  DZ_HIP(hipEventCreate(&guard.e1));
+  for (int i = 0; i < NSLOT; i++) {
+    DZ_HIP(hipEventCreate(&guard.done[i]));
+    for (int j = 0; j < 4; j++) DZ_HIP(hipEventCreate(&guard.ta[i][j]));
+  }
   // rowwise = the vector is sharded by rows (u): its squared norm is summed over the ranks first
   auto norm_to_host = [&](const double *pp, int np, float *res, bool rowwise = false) -> int {
     if (comm && rowwise) {
@@ -1083,39 +1346,25 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
     return 0;
   };
   const int bn = nblk(n, NPART), bm = nblk(m, NPART);
-  DZ_HIP(hipEventCreate(&guard.e0));
-  DZ_HIP(hipEventCreate(&guard.e1));
-  hipEvent_t e0 = guard.e0, e1 = guard.e1;
-  DZ_HIP(hipEventRecord(e0, ctx->stream));
-  double t_spmv = 0, t_spmvt = 0;
-  int n_spmv = 0, n_spmvt = 0;
-  auto timed_spmv = [&](bool transpose, const float *beta_p, float sign) -> int {
-    hipEvent_t a = ctx->ev0, bq = ctx->ev1;
-    DZ_HIP(hipEventRecord(a, ctx->stream));
-    int r;
-    if (!transpose) {
-      r = launch_spmvA(ctx, A, v, u, beta_p, sign, part, &gm_t);
-    } else if (!comm) {
-      r = launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t);
-    } else {   // w = A_p^T u_p ; all-reduce ; v = w + sign*beta*v
-      DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
-      r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr);
-      if (r) return r;
-      DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
-      hipLaunchKernelGGL(k_axpby_norm, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, v, beta_p, sign, part);
-      gn_t = bn;
-    }
+  DZ_HIP(hipEventRecord(guard.e0, ctx->stream));
+  int gm_t = gm, gn_t = gn;   // partial counts of the last products
+  // v(out) = A^T u + sign*beta*v with partials of ||v||^2 in `part` (row-sharded: local product, all-reduce, then the axpby)
+  auto spmvT = [&](const float *beta_p, float sign, const int *g) -> int {
+    if (!comm) return launch_spmvT(ctx, A, u, 1.0f, v, beta_p, sign, part, &gn_t, g);
+    DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
+    int r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr, g);
     if (r) return r;
-    DZ_HIP(hipEventRecord(bq, ctx->stream));
-    DZ_HIP(hipEventSynchronize(bq));
-    float ms = 0;
-    DZ_HIP(hipEventElapsedTime(&ms, a, bq));
-    if (transpose) { t_spmvt += ms * 1e-3; n_spmvt++; } else { t_spmv += ms * 1e-3; n_spmv++; }
+    DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
+    hipLaunchKernelGGL(k_axpby_norm, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, v, beta_p, sign, part, g);
+    gn_t = bn;
     return 0;
   };
 
   int istop = 0, itn = 0;
-  float normA = 0, condA = 0, normr = 0, normAr = 0, normx = 0;
+  float normA = 0, condA = 0, normr = 0, normAr = 0, normx = 0, normb = 0;
+  int ntrace = 0;
+  double t_spmv = 0, t_spmvt = 0;
+  int n_spmv = 0, n_spmvt = 0;
   // u = b ; beta = ||u|| ; u /= beta ; v = A^T u ; alpha = ||v|| ; v /= alpha   (:355-372)
   hipLaunchKernelGGL(k_copy, dim3(bm), dim3(VB), 0, ctx->stream, m, b.dev, u);
   DZ_HIP(hipMemsetAsync(v, 0, n * 4, ctx->stream));
@@ -1126,130 +1375,122 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   if ((rc = norm_to_host(part, bm, &beta, true))) return rc;
   if (beta > 0.0f) {
     hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
-    if ((rc = timed_spmv(true, nullptr, 1.0f))) return rc;  // v = 1*v(=0) + A^T u
+    if ((rc = spmvT(nullptr, 1.0f, nullptr))) return rc;  // v = 1*v(=0) + A^T u
     if ((rc = norm_to_host(part, gn_t, &alpha))) return rc;
   }
   if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
   normAr = alpha * beta;
+  normb = beta;
+  if (trace) {   // the line the reference prints before the loop (:468-471): itn 0, x(1) = 0, test1 = 1, test2 = alpha/beta
+    memset(&trace[0], 0, sizeof trace[0]);
+    trace[0].normr = beta; trace[0].normAr = normAr; trace[0].test1 = 1.0f; trace[0].test2 = beta > 0.0f ? alpha / beta : 0.0f;
+    ntrace = 1;
+  }
   if (normAr != 0.0f) {
-    bool localOrtho = false, localVQueueFull = false;
-    int localPointer = 0;
-    if (localVecs > 0) {
-      localPointer = 1;
-      localOrtho = true;
-      hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, localV);
-    }
-    float zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    if (localVecs > 0) hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, localV);   // localV(:,1) = v
     hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, h);
-    float betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
-    float normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e+30f, normb = beta, ctol = 0;
-    if (conlim > 0.0f) ctol = 1.0f / conlim;
-    normr = beta;
-    auto d2norm = [](float a, float bb) -> float {  // :708-721
-      const float scale = fabsf(a) + fabsf(bb);
-      if (scale == 0.0f) return 0.0f;
-      return scale * sqrtf((a / scale) * (a / scale) + (bb / scale) * (bb / scale));
+    LsmrState &s0 = h_state[NSLOT];
+    memset(&s0, 0, sizeof s0);
+    s0.alpha = alpha; s0.beta = beta; s0.alphabar = alpha; s0.zetabar = alpha * beta; s0.rho = 1; s0.rhobar = 1; s0.cbar = 1;
+    s0.betadd = beta; s0.rhodold = 1; s0.normA2 = alpha * alpha; s0.minrbar = 1e+30f; s0.normb = beta;
+    s0.ctol = conlim > 0.0f ? 1.0f / conlim : 0.0f;
+    s0.normr = beta; s0.normAr = normAr; s0.damp = damp; s0.atol = atol; s0.btol = btol; s0.itnlim = itnlim;
+    DZ_HIP(hipMemcpyAsync(S, &s0, sizeof s0, hipMemcpyHostToDevice, ctx->stream));
+    if (d_trace) DZ_HIP(hipMemsetAsync(d_trace, 0, (size_t)trace_cap * sizeof(dazim_lsmr_rec), ctx->stream));
+    const int *g1 = &S->stop, *g2 = &S->stop2;
+    // one iteration, enqueued without any host synchronisation; k = its number (the reorthogonalisation window is a function
+    // of k alone: localVEnqueue advances once per iteration, :723-731)
+    auto enqueue_iteration = [&](int k, hipEvent_t *tev) -> int {
+      int r;
+      if (tev) DZ_HIP(hipEventRecord(tev[0], ctx->stream));
+      if ((r = launch_spmvA(ctx, A, v, u, &S->alpha, -1.0f, part, &gm_t, g1))) return r;   // u = A v - alpha u (:484-486)
+      if (tev) DZ_HIP(hipEventRecord(tev[1], ctx->stream));
+      float *slot = nullptr;
+      int lim = 0;
+      if (localVecs > 0) {
+        const int ptr = k % localVecs + 1;             // localPointer after this iteration's enqueue
+        slot = localV + (size_t)(ptr - 1) * n;
+        lim = k >= localVecs ? localVecs : k + 1;     // localVQueueFull ? localVecs : localPointer (:738-742)
+      }
+      if (comm) {
+        hipLaunchKernelGGL(k_total, dim3(1), dim3(64), 0, ctx->stream, part, gm_t, d_sum, g1);
+        DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
+      }
+      hipLaunchKernelGGL(k_beta_scal_u, dim3(bm > bn ? bm : bn), dim3(VB), 0, ctx->stream, m, u, part, gm_t,
+                         comm ? d_sum : (const double *)nullptr, n, v, slot, S);
+      if (tev) DZ_HIP(hipEventRecord(tev[2], ctx->stream));
+      if ((r = spmvT(&S->beta, -1.0f, g2))) return r;                                       // v = A^T u - beta v (:496-497)
+      if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
+      const double *pa = part;
+      int npa = gn_t;
+      if (localVecs > 0) {   // localVOrtho :733-748 (modified Gram-Schmidt, one launch per vector; the last one leaves ||v||^2)
+        for (int q = 0; q <= lim; q++) {
+          const float *prev = q > 0 ? localV + (size_t)(q - 1) * n : nullptr;
+          const float *next = q < lim ? localV + (size_t)q * n : nullptr;
+          hipLaunchKernelGGL(k_reorth, dim3(bn), dim3(VB), 0, ctx->stream, n, v, prev, part2 + ((q + 1) & 1) * NPART, bn, next,
+                             q < lim ? part2 + (q & 1) * NPART : part, g2);
+        }
+        npa = bn;
+      }
+      hipLaunchKernelGGL(k_alpha_update, dim3(bn), dim3(VB), 0, ctx->stream, n, v, h, hbar, x.dev, pa, npa, partx, S);
+      hipLaunchKernelGGL(k_tests, dim3(1), dim3(64), 0, ctx->stream, partx, bn, x.dev, S, d_trace, trace_cap);
+      DZ_HIP(hipGetLastError());
+      return 0;
     };
-    for (;;) {
-      itn++;
-      // u = A v - alpha u ; beta = ||u||   (:484-487; d_scal[0] holds alpha)
-      if ((rc = timed_spmv(false, d_scal, -1.0f))) return rc;
-      if ((rc = norm_to_host(part, gm_t, &beta, true))) return rc;
-      if (beta > 0.0f) {
-        hipLaunchKernelGGL(k_scal_inv, dim3(bm), dim3(VB), 0, ctx->stream, m, u, d_scal, 1.0f);
-        if (localOrtho) {  // localVEnqueue :723-731
-          if (localPointer < localVecs)
-            localPointer++;
-          else {
-            localPointer = 1;
-            localVQueueFull = true;
-          }
-          hipLaunchKernelGGL(k_copy, dim3(bn), dim3(VB), 0, ctx->stream, n, v, localV + (size_t)(localPointer - 1) * n);
+    // batches of CHECK iterations; the state after batch j is copied to pinned slot j % NSLOT and examined while batch j+1
+    // is already running
+    const int limit = itnlim > 1 ? itnlim : 1;   // (the reference tests itn >= itnlim after its first iteration)
+    int launched = 0, nbatch = 0, examined = 0;
+    bool stopped = false;
+    while (!stopped) {
+      if (launched < limit) {
+        const int sl = nbatch % NSLOT;
+        for (int i = 0; i < CHECK && launched < limit; i++) {
+          launched++;
+          if ((rc = enqueue_iteration(launched, i == 0 ? guard.ta[sl] : nullptr))) return rc;
         }
-        // v = A^T u - beta v   (:496-497; d_scal[0] holds beta)
-        if ((rc = timed_spmv(true, d_scal, -1.0f))) return rc;
-        if (localOrtho) {  // localVOrtho :733-748 (modified Gram-Schmidt, one launch per vector)
-          const int lim = localVQueueFull ? localVecs : localPointer;
-          for (int q = 0; q <= lim; q++) {
-            const float *prev = q > 0 ? localV + (size_t)(q - 1) * n : nullptr;
-            const float *next = q < lim ? localV + (size_t)q * n : nullptr;
-            hipLaunchKernelGGL(k_reorth, dim3(bn), dim3(VB), 0, ctx->stream, n, v, prev, part2 + ((q + 1) & 1) * NPART, bn,
-                               next, part2 + (q & 1) * NPART);
-          }
-          hipLaunchKernelGGL(k_sumsq, dim3(bn), dim3(VB), 0, ctx->stream, n, v, part);
-          if ((rc = norm_to_host(part, bn, &alpha))) return rc;
-        } else {
-          if ((rc = norm_to_host(part, gn_t, &alpha))) return rc;
-        }
-        if (alpha > 0.0f) hipLaunchKernelGGL(k_scal_inv, dim3(bn), dim3(VB), 0, ctx->stream, n, v, d_scal, 1.0f);
+        DZ_HIP(hipMemcpyAsync(&h_state[sl], S, sizeof(LsmrState), hipMemcpyDeviceToHost, ctx->stream));
+        DZ_HIP(hipEventRecord(guard.done[sl], ctx->stream));
+        nbatch++;
       }
-      if (!(beta > 0.0f) || !(alpha > 0.0f)) {  // keep the device copy of alpha valid for the next product
-        h_scal[8] = alpha;
-        DZ_HIP(hipMemcpyAsync(d_scal, h_scal + 8, 4, hipMemcpyHostToDevice, ctx->stream));
+      const int keep = launched < limit ? 1 : 0;   // one batch stays unexamined while more can be enqueued behind it
+      while (examined < nbatch - keep && !stopped) {
+        const int ls = examined % NSLOT;
+        DZ_HIP(hipEventSynchronize(guard.done[ls]));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, guard.ta[ls][0], guard.ta[ls][1]) == hipSuccess) { t_spmv += ms * 1e-3; n_spmv++; }
+        if (hipEventElapsedTime(&ms, guard.ta[ls][2], guard.ta[ls][3]) == hipSuccess) { t_spmvt += ms * 1e-3; n_spmvt++; }
+        s0 = h_state[ls];
+        stopped = s0.stop != 0;
+        examined++;
       }
-      // ---- scalar recurrences, verbatim order of :506-588 ----
-      const float alphahat = d2norm(alphabar, damp);
-      const float chat = alphabar / alphahat, shat = damp / alphahat;
-      const float rhoold = rho;
-      rho = d2norm(alphahat, beta);
-      const float c = alphahat / rho, s = beta / rho;
-      const float thetanew = s * alpha;
-      alphabar = c * alpha;
-      const float rhobarold = rhobar, zetaold = zeta;
-      const float thetabar = sbar * rho, rhotemp = cbar * rho;
-      rhobar = d2norm(cbar * rho, thetanew);
-      cbar = cbar * rho / rhobar;
-      sbar = thetanew / rhobar;
-      zeta = cbar * zetabar;
-      zetabar = -sbar * zetabar;
-      const float f1 = thetabar * rho / (rhoold * rhobarold), f2 = zeta / (rho * rhobar), f3 = thetanew / rho;
-      hipLaunchKernelGGL(k_update, dim3(bn), dim3(VB), 0, ctx->stream, n, f1, f2, f3, h, hbar, x.dev, v, part);
-      // k_update must not clobber d_scal (alpha) before the next product reads it: keep normx separately
-      hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, part, bn, d_scal + 4, (double *)nullptr);
-      DZ_HIP(hipMemcpyAsync(h_scal + 4, d_scal + 4, 4, hipMemcpyDeviceToHost, ctx->stream));
-      const float betaacute = chat * betadd, betacheck = -shat * betadd;
-      const float betahat = c * betaacute;
-      betadd = -s * betaacute;
-      const float thetatildeold = thetatilde;
-      const float rhotildeold = d2norm(rhodold, thetabar);
-      const float ctildeold = rhodold / rhotildeold, stildeold = thetabar / rhotildeold;
-      thetatilde = stildeold * rhobar;
-      rhodold = ctildeold * rhobar;
-      betad = -stildeold * betad + ctildeold * betahat;
-      tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
-      const float taud = (zeta - thetatilde * tautildeold) / rhodold;
-      d = d + betacheck * betacheck;
-      normr = sqrtf(d + (betad - taud) * (betad - taud) + betadd * betadd);
-      normA2 = normA2 + beta * beta;
-      normA = sqrtf(normA2);
-      normA2 = normA2 + alpha * alpha;
-      maxrbar = fmaxf(maxrbar, rhobarold);
-      if (itn > 1) minrbar = fminf(minrbar, rhobarold);
-      condA = fmaxf(maxrbar, rhotemp) / fminf(minrbar, rhotemp);
-      normAr = fabsf(zetabar);
-      DZ_HIP(hipStreamSynchronize(ctx->stream));
-      normx = h_scal[4];
-      const float test1 = normr / normb, test2 = normAr / (normA * normr), test3 = 1.0f / condA;
-      const float t1 = test1 / (1.0f + normA * normx / normb);
-      const float rtol = btol + atol * normA * normx / normb;
-      if (itn >= itnlim) istop = 7;
-      if (1.0f + test3 <= 1.0f) istop = 6;
-      if (1.0f + test2 <= 1.0f) istop = 5;
-      if (1.0f + t1 <= 1.0f) istop = 4;
-      if (test3 <= ctol) istop = 3;
-      if (test2 <= atol) istop = 2;
-      if (test1 <= rtol) istop = 1;
-      if (istop != 0) break;
+      if (!stopped && launched >= limit && examined == nbatch) stopped = true;   // (istop = 7 sets the flag at itn >= itnlim)
+    }
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    istop = s0.istop; itn = s0.itn; normA = s0.normA; condA = s0.condA; normr = s0.normr; normAr = s0.normAr; normx = s0.normx;
+    if (trace) {
+      const int cnt = itn + 1 < trace_cap ? itn + 1 : trace_cap;
+      if (cnt > 1) {
+        DZ_HIP(hipMemcpyAsync(trace + 1, d_trace + 1, (size_t)(cnt - 1) * sizeof(dazim_lsmr_rec), hipMemcpyDeviceToHost, ctx->stream));
+        DZ_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      ntrace = cnt;
     }
   }
   if (damp > 0.0f && istop == 2) istop = 3;  // :686
-  DZ_HIP(hipEventRecord(e1, ctx->stream));
-  DZ_HIP(hipEventSynchronize(e1));
+  DZ_HIP(hipEventRecord(guard.e1, ctx->stream));
+  DZ_HIP(hipEventSynchronize(guard.e1));
   float ms = 0;
-  DZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+  DZ_HIP(hipEventElapsedTime(&ms, guard.e0, guard.e1));
   ctx->ksec["lsmr"] = ms * 1e-3;
   ctx->ksec["spmv"] = n_spmv ? t_spmv / n_spmv : -1.0;
   ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
+  ctx->ksec["lsmr.normb"] = normb;
+  {
+    int nr = 1;
+    if (comm) (void)ncclCommCount(comm, &nr);
+    ctx->ksec["lsmr.nranks"] = nr;     // ranks the RCCL communicator of this solve really has
+  }
   if (istop_o) *istop_o = istop;
   if (itn_o) *itn_o = itn;
   if (normA_o) *normA_o = normA;
@@ -1257,9 +1498,17 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
   if (normr_o) *normr_o = normr;
   if (normAr_o) *normAr_o = normAr;
   if (normx_o) *normx_o = normx;
+  if (trace_n) *trace_n = ntrace;
   if ((rc = x.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,
+               float conlim, int itnlim, int localSize, float *x_u, int *istop_o, int *itn_o,
+               float *normA_o, float *condA_o, float *normr_o, float *normAr_o, float *normx_o) {
+  return dazim_lsmr_traced(ctx, A, b_u, damp, atol, btol, conlim, itnlim, localSize, x_u, istop_o, itn_o, normA_o, condA_o,
+                           normr_o, normAr_o, normx_o, nullptr, 0, nullptr);
 }
 
 }  // extern "C"

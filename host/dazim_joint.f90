@@ -1,7 +1,7 @@
 ! dazim_joint.f90 -- drop-in for the reference's CalSurfGAnisoJoint (inv/CalSurfGAniso_Joint.f90:209), all on the GPU:
 ! TI depth kernels Lsen_Gsc (depthkernelTI/tregn96 -> dazim_ti_kernels), dispersion + depth kernels, eikonal fields,
-! rpathsAzim and the three column blocks dVs | Gc | Gs (dazim_rays_build_G_joint).  The dense copies GVs/GGc/GGs are
-! not filled (see INTEGRATION.md).  host/Makefile compiles it (object only) to keep it honest.
+! rpathsAzim and the three column blocks dVs | Gc | Gs (dazim_rays_build_G_joint), plus the dense copies GVs/GGc/GGs
+! (dall x nparpi each, inv/CalSurfGAniso_Joint.f90:754-775) unless the caller set dazim_fill_dense = .false.
 subroutine CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, col, dsurf, GVs, GGc, GGs, Lsen_Gsc, dall, rmax, tRcV, &
                               goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, minthk, &
                               scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, writepath)
@@ -20,7 +20,8 @@ subroutine CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, col, dsurf, GVs,
   allocate (pv2(nx*ny, kmaxRc))
   call dazim_lsen_gsc(nx, ny, nz, vels, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
   call dazim_calsurfg_joint(nx, ny, nz, vels, iw, rw, col, dsurf, Lsen_Gsc, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
-                            periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pv2)
+                            periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pv2, &
+                            dall, nparpi, GVs, GGc, GGs)
   do tt = 1, kmaxRc                           ! tRcV = inner-cell phase velocities, inv/CalSurfGAniso_Joint.f90:803-811
     do jj = 1, ny - 2
       do ii = 1, nx - 2

@@ -295,10 +295,15 @@ program DAzimSurfTomo_amd
     else
       atol = 1e-5; btol = 1e-4; conlim = 200; itnlim = 500; localSize = 10
     end if
-    call dazim_check(dazim_lsmr(dazim_handle, G, cbst, damp, atol, btol, conlim, itnlim, localSize, dv, istop, itn, &
-                                anorm, acond, rnorm, arnorm, xnorm), 'LSMR')
-    write (36, '(a,i3,a,i8,a,es12.5,a,es12.5)') ' Exit  LSMR.  istop =', istop, '  itn =', itn, '  normA =', anorm, &
-      '  normr =', rnorm
+    block                                     ! lsmr.txt carries the reference's iteration log (nout = 36, inv/Main_Jt.f90:136,562)
+      type(dazim_lsmr_rec), allocatable :: tr(:)
+      integer(c_int) :: ntr
+      allocate (tr(itnlim + 2))
+      call dazim_check(dazim_lsmr_traced(dazim_handle, G, cbst, damp, atol, btol, conlim, itnlim, localSize, dv, istop, itn, &
+                                         anorm, acond, rnorm, arnorm, xnorm, tr, int(itnlim + 2, c_int), ntr), 'LSMR')
+      call dazim_lsmr_log(36, m, n, damp, atol, btol, conlim, itnlim, localSize, tr, int(ntr), istop, itn, anorm, acond, rnorm, &
+                          arnorm, xnorm)
+    end block
     if (istop == 3) then
       write (*, '(a)') '  istop = 3, large condition number, LSMR failed'
       write (66, '(a)') '  istop = 3, large condition number, LSMR failed'

@@ -8,7 +8,9 @@
 !        = inv/CalSurfG.f90:1
 !   CalSurfG(nx,ny,nz,nparpi,vels,iw,rw,col,dsurf,GVs,dall,goxdf,gozdf,dvxdf,dvzdf,kmaxRc,tRc,
 !            periods,depz,minthk,scxf,sczf,rcxf,rczf,nrc1,nsrcsurf1,kmax,nsrcsurf,nrcf,nar)
-!        = inv/CalSurfG.f90:909 (the dense GVs copy is not filled: see DESIGN.md, N2)
+!        = inv/CalSurfG.f90:909, including the dense copy GVs(dall,nparpi) the reference's main program multiplies with
+!          (inv/CalSurfG.f90:1369-1378, inv/CalSigamNorm.f90:73); a caller that passes a dummy GVs sets
+!          dazim_fill_dense = .false. first
 !   aprod(mode,m,n,x,y,leniw,lenrw,iw,rw)                      = inv/aprod.f90:7
 !   LSMR(m,n,leniw,lenrw,iw,rw,b,damp,atol,btol,conlim,itnlim,localSize,nout,x,istop,itn,
 !        normA,condA,normr,normAr,normx)                      = inv/lsmrModule.f90:36
@@ -19,16 +21,22 @@ module dazim_mod
   use iso_c_binding
   implicit none
   private
-  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle
+  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
-            dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo
+            dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
+  ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
+  logical, save :: dazim_fill_dense = .true.
 
   type, bind(C) :: dazim_refbox
     integer(c_int) :: vnl, vnr, vnt, vnb, nnxr, nnzr, isx, isz
     real(c_float) :: goxr, gozr, dnxr, dnzr
+  end type
+  type, bind(C) :: dazim_lsmr_rec      ! include/dazim.h: one line of the reference's iteration log
+    integer(c_int) :: itn
+    real(c_float) :: x1, normr, normAr, test1, test2, test3, rtol, normA, condA
   end type
 
   interface
@@ -44,11 +52,11 @@ module dazim_mod
     integer(c_int) function dazim_dispersion_kernels(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, &
         pv, svs, svp, srho, nfail) bind(C, name="dazim_dispersion_kernels")
       import
-      type(c_ptr), value :: ctx
+      type(c_ptr), value :: ctx, svs, svp, srho     ! all three c_loc(array), or all three c_null_ptr (phase velocities only)
       integer(c_int), value :: nx, ny, nz, kmax
       real(c_float), value :: sublayers
       real(c_float) :: vel(*), depz(*)
-      real(c_double) :: periods(*), pv(*), svs(*), svp(*), srho(*)
+      real(c_double) :: periods(*), pv(*)
       integer(c_int) :: nfail
     end function
     integer(c_int) function dazim_set_option(ctx, name, value) bind(C, name="dazim_set_option")
@@ -62,16 +70,6 @@ module dazim_mod
       real(c_float), value :: sublayers
       real(c_float) :: vel(*), depz(*), lsen(*)
       real(c_double) :: periods(*), pv(*)
-    end function
-    integer(c_int) function dazim_dispersion_only(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, &
-        pv, svs, svp, srho, nfail) bind(C, name="dazim_dispersion_kernels")
-      import
-      type(c_ptr), value :: ctx, svs, svp, srho
-      integer(c_int), value :: nx, ny, nz, kmax
-      real(c_float), value :: sublayers
-      real(c_float) :: vel(*), depz(*)
-      real(c_double) :: periods(*), pv(*)
-      integer(c_int) :: nfail
     end function
     integer(c_int) function dazim_fmm_batch(ctx, nx, ny, goxd, gozd, dvxd, dvzd, kmax, pv, nfield, scx, scz, &
         period_idx, veln, ttn, ttnr, nstsr, boxes, status) bind(C, name="dazim_fmm_batch")
@@ -153,6 +151,17 @@ module dazim_mod
       integer(c_int), value :: mode
       real(c_float) :: x(*), y(*)
     end function
+    integer(c_int) function dazim_lsmr_traced(ctx, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
+        normA, condA, normr, normAr, normx, trace, trace_cap, trace_n) bind(C, name="dazim_lsmr_traced")
+      import
+      type(c_ptr), value :: ctx, A
+      real(c_float) :: b(*), x(*)
+      real(c_float), value :: damp, atol, btol, conlim
+      integer(c_int), value :: itnlim, localSize, trace_cap
+      integer(c_int) :: istop, itn, trace_n
+      real(c_float) :: normA, condA, normr, normAr, normx
+      type(dazim_lsmr_rec) :: trace(*)
+    end function
     integer(c_int) function dazim_lsmr(ctx, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
         normA, condA, normr, normAr, normx) bind(C, name="dazim_lsmr")
       import
@@ -209,13 +218,14 @@ contains
   subroutine depthkernel(nx, ny, nz, vel, pvRc, sen_vsRc, sen_vpRc, sen_rhoRc, iwave, igr, kmaxRc, tRc, depz, minthk)
     integer :: nx, ny, nz, iwave, igr, kmaxRc
     real :: vel(nx, ny, nz), depz(nz), minthk
-    real*8 :: pvRc(nx*ny, kmaxRc), sen_vsRc(nx*ny, kmaxRc, nz), sen_vpRc(nx*ny, kmaxRc, nz), sen_rhoRc(nx*ny, kmaxRc, nz)
+    real*8 :: pvRc(nx*ny, kmaxRc)
+    real*8, target :: sen_vsRc(nx*ny, kmaxRc, nz), sen_vpRc(nx*ny, kmaxRc, nz), sen_rhoRc(nx*ny, kmaxRc, nz)
     real*8 :: tRc(kmaxRc)
     integer(c_int) :: nfail
     if (iwave /= 2 .or. igr /= 0) stop 'Can only deal with Rayleigh wave phase velocity data!'  ! inv/Main_Jt.f90:213
     call dazim_init(0)
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pvRc, &
-                                        sen_vsRc, sen_vpRc, sen_rhoRc, nfail), 'depthkernel')
+                                        c_loc(sen_vsRc), c_loc(sen_vpRc), c_loc(sen_rhoRc), nfail), 'depthkernel')
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
   end subroutine
 
@@ -229,8 +239,8 @@ contains
     integer(c_int) :: nfail
     call dazim_init(0)
     allocate (pv(nx*ny, kmaxRc))
-    call check(dazim_dispersion_only(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
-                                     c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
+    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
+                                        c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
     call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, Lsen_Gsc), 'depthkernelTI/tregn96')
   end subroutine
 
@@ -245,12 +255,15 @@ contains
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     real :: nolsen(1)
     call build_G(.false., nx, ny, nz, vels, iw, rw, col, dsurf, nolsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
-                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar)
+                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, &
+                 dall=dall, nparpi=nparpi, GVs=GVs)
   end subroutine
 
-  ! joint rows dVs | Gc | Gs (receiver loop of inv/CalSurfGAniso_Joint.f90:209) given Lsen_Gsc; pv2 optional out
+  ! joint rows dVs | Gc | Gs (receiver loop of inv/CalSurfGAniso_Joint.f90:209) given Lsen_Gsc; pv2 optional out;
+  ! dall, nparpi, GVs, GGc, GGs: the dense copies of the three column blocks (inv/CalSurfGAniso_Joint.f90:754-775)
   subroutine dazim_calsurfg_joint(nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
-                                  periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+                                  periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout, &
+                                  dall, nparpi, GVs, GGc, GGs)
     integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
     real :: vels(nx, ny, nz), rw(*), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
     integer :: iw(*), col(*)
@@ -258,12 +271,20 @@ contains
     integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     real*8, optional :: pvout(nx*ny, kmaxRc)
+    integer, optional :: dall, nparpi
+    real, optional :: GVs(*), GGc(*), GGs(*)
     call build_G(.true., nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
-                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+                 periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout, &
+                 dall, nparpi, GVs, GGc, GGs)
   end subroutine
 
+  ! G on the device -> the reference's COO triplets (iw(2:nar+1) rows, col, rw) and, when the caller's dense arrays are
+  ! given, GVs (GGc, GGs).  The dense copies hold EVERY entry of the cells with |fdm| >= ftol (inv/CalSurfG.f90:1369-1378),
+  ! the triplets only those with |row| > ftol (:1358): the matrix is built once with the library option rays.keep_small and
+  ! the second threshold is applied here, on the same fp32 values the kernel would have tested.
   subroutine build_G(joint, nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
-                     periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout)
+                     periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout, &
+                     dall, nparpi, GVs, GGc, GGs)
     logical :: joint
     integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
     real :: vels(nx, ny, nz), rw(*), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
@@ -272,17 +293,59 @@ contains
     integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     real*8, optional :: pvout(nx*ny, kmaxRc)
+    integer, optional :: dall, nparpi
+    real, optional :: GVs(*), GGc(*), GGs(*)
+    real, parameter :: ftol = 1e-4           ! inv/CalSurfG.f90:999
     real*8, allocatable :: pv(:, :)
-    integer, allocatable :: irow(:)
+    integer, allocatable :: irow(:), icol(:)
+    real, allocatable :: val(:)
     type(c_ptr) :: G
+    logical :: dense
+    integer :: nall, i, blk, c
+    integer(8) :: ld, np8, k8
+    dense = .false.
+    if (dazim_fill_dense .and. present(GVs) .and. present(dall) .and. present(nparpi)) dense = .true.
     allocate (pv(nx*ny, kmaxRc))
+    call dazim_init(0)
+    if (dense) call check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 1_c_int), 'option')
     call dazim_assemble_G(joint, nx, ny, nz, vels, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, minthk, &
-                          scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nar, pv)
+                          scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nall, pv)
+    if (dense) call check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 0_c_int), 'option')
     if (present(pvout)) pvout = pv
-    allocate (irow(max(nar, 1)))
-    call check(dazim_csr_to_coo(dazim_handle, G, irow, col, rw), 'CalSurfG/coo')
-    iw(2:nar + 1) = irow(1:nar)             ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
+    allocate (irow(max(nall, 1)), icol(max(nall, 1)), val(max(nall, 1)))
+    call check(dazim_csr_to_coo(dazim_handle, G, irow, icol, val), 'CalSurfG/coo')
     call check(dazim_csr_free(dazim_handle, G), 'free')
+    ld = 0; np8 = 0
+    if (dense) then                          ! GVs = 0 etc.: inv/Main_Jt.f90:388-390, inv/CalSurfGAniso_Joint.f90:436-438
+      ld = dall; np8 = nparpi
+      do k8 = 1, ld*np8
+        GVs(k8) = 0.0
+      end do
+      if (joint .and. present(GGc) .and. present(GGs)) then
+        do k8 = 1, ld*np8
+          GGc(k8) = 0.0; GGs(k8) = 0.0
+        end do
+      end if
+    end if
+    nar = 0
+    do i = 1, nall
+      if (dense) then
+        blk = (icol(i) - 1)/nparpi; c = icol(i) - blk*nparpi
+        k8 = int(c - 1, 8)*ld + irow(i)      ! element (irow, c) of a dall x nparpi array
+        if (blk == 0) then
+          GVs(k8) = val(i)
+        else if (present(GGc) .and. present(GGs)) then
+          if (blk == 1) then
+            GGc(k8) = val(i)
+          else
+            GGs(k8) = val(i)
+          end if
+        end if
+        if (.not. abs(val(i)) > ftol) cycle   ! if(abs(row(nn)).gt.ftol), inv/CalSurfG.f90:1358
+      end if
+      nar = nar + 1
+      rw(nar) = val(i); iw(nar + 1) = irow(i); col(nar) = icol(i)   ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
+    end do
   end subroutine
 
   ! The whole of CalSurfG (inv/CalSurfG.f90:909) / the GPU part of CalSurfGAnisoJoint on the device; G stays in HBM
@@ -300,7 +363,7 @@ contains
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     type(c_ptr) :: G
     real*8 :: pv(nx*ny, kmaxRc)
-    real*8, allocatable :: svs(:, :, :), svp(:, :, :), srho(:, :, :)
+    real*8, allocatable, target :: svs(:, :, :), svp(:, :, :), srho(:, :, :)
     real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
     integer, allocatable :: per(:), kidx(:), fray(:)
     type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box
@@ -310,8 +373,8 @@ contains
     integer(c_size_t) :: nn
     call dazim_init(0)
     allocate (svs(nx*ny, kmaxRc, nz), svp(nx*ny, kmaxRc, nz), srho(nx*ny, kmaxRc, nz))
-    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, svs, svp, srho, nfail), &
-               'CalSurfG/depthkernel')
+    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, c_loc(svs), c_loc(svp), &
+                                        c_loc(srho), nfail), 'CalSurfG/depthkernel')
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
     if (joint .and. present(ti_here)) then
       if (ti_here) call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
@@ -382,15 +445,102 @@ contains
     real, intent(out) :: x(n), normA, condA, normr, normAr, normx
     integer, intent(out) :: istop, itn
     type(c_ptr) :: A
+    type(dazim_lsmr_rec), allocatable :: tr(:)
     integer :: kk
+    integer(c_int) :: ntr, cap
     call dazim_init(0)
     kk = iw(1)
     call check(dazim_csr_from_coo(dazim_handle, int(m, c_int64_t), int(n, c_int64_t), int(kk, c_int64_t), &
                                   iw(2:kk + 1), iw(kk + 2:2*kk + 1), rw, A), 'LSMR')
-    call check(dazim_lsmr(dazim_handle, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
-                          normA, condA, normr, normAr, normx), 'LSMR')
+    cap = 1
+    if (nout > 0) cap = max(itnlim, 1) + 2
+    allocate (tr(cap))
+    call check(dazim_lsmr_traced(dazim_handle, A, b, damp, atol, btol, conlim, itnlim, localSize, x, istop, itn, &
+                                 normA, condA, normr, normAr, normx, tr, cap, ntr), 'LSMR')
     call check(dazim_csr_free(dazim_handle, A), 'LSMR')
-    if (nout > 0) write (nout, '(a,i3,a,i8,a,es12.5,a,es12.5)') ' Exit  LSMR.  istop =', istop, '  itn =', itn, &
-      '  normA =', normA, '  normr =', normr
+    if (nout > 0) call dazim_lsmr_log(nout, m, n, damp, atol, btol, conlim, itnlim, localSize, tr, int(ntr), &
+                                      istop, itn, normA, condA, normr, normAr, normx)
+  end subroutine
+
+  ! the reference's LSMR log on unit nout (inv/lsmrModule.f90:363-366 header, :462-471 first line, :653-682 iteration table
+  ! with its print rules, :686-697 exit block; formats 1000/1200/1300/1500/2000/3000 at :699-716) from the trace records
+  subroutine dazim_lsmr_log(nout, m, n, damp, atol, btol, conlim, itnlim, localSize, tr, ntr, istop, itn, normA, condA, &
+                            normr, normAr, normx)
+    integer, intent(in) :: nout, m, n, itnlim, localSize, ntr, istop, itn
+    real, intent(in) :: damp, atol, btol, conlim, normA, condA, normr, normAr, normx
+    type(dazim_lsmr_rec), intent(in) :: tr(*)
+    character(len=*), parameter :: enter = ' Enter LSMR.  ', exitt = ' Exit  LSMR.  '
+    character(len=53), parameter :: msg(0:7) = &
+      (/'The exact solution is  x = 0                         ', &
+        'Ax - b is small enough, given atol, btol             ', &
+        'The least-squares solution is good enough, given atol', &
+        'The estimate of cond(Abar) has exceeded conlim       ', &
+        'Ax - b is small enough for this machine              ', &
+        'The LS solution is good enough for this machine      ', &
+        'Cond(Abar) seems to be too large for this machine    ', &
+        'The iteration limit has been reached                 '/)
+    integer :: i, pcount, localVecs
+    integer, parameter :: pfreq = 20
+    logical :: prnt, damped
+    real :: ctol, normb
+    if (nout <= 0 .or. ntr < 1) return
+    damped = damp > 0.0
+    localVecs = min(localSize, m, n)
+    write (nout, 1000) enter, m, n, damp, atol, conlim, btol, itnlim, localVecs
+    normb = tr(1)%normr
+    if (tr(1)%normAr == 0.0) then            ! b = 0 or A'b = 0 (:455-460)
+      write (nout, '(a)') msg(1)
+      return
+    end if
+    if (damped) then
+      write (nout, 1300)
+    else
+      write (nout, 1200)
+    end if
+    write (nout, 1500) 0, tr(1)%x1, tr(1)%normr, tr(1)%normAr, tr(1)%test1, tr(1)%test2
+    ctol = 0.0
+    if (conlim > 0.0) ctol = 1.0/conlim
+    pcount = 0
+    do i = 2, ntr
+      prnt = .false.
+      if (n <= 40) prnt = .true.
+      if (tr(i)%itn <= 10) prnt = .true.
+      if (tr(i)%itn >= itnlim - 10) prnt = .true.
+      if (mod(tr(i)%itn, 10) == 0) prnt = .true.
+      if (tr(i)%test3 <= 1.1*ctol) prnt = .true.
+      if (tr(i)%test2 <= 1.1*atol) prnt = .true.
+      if (tr(i)%test1 <= 1.1*tr(i)%rtol) prnt = .true.
+      if (tr(i)%itn == itn .and. istop /= 0) prnt = .true.
+      if (prnt) then
+        if (pcount >= pfreq) then
+          pcount = 0
+          if (damped) then
+            write (nout, 1300)
+          else
+            write (nout, 1200)
+          end if
+        end if
+        pcount = pcount + 1
+        write (nout, 1500) tr(i)%itn, tr(i)%x1, tr(i)%normr, tr(i)%normAr, tr(i)%test1, tr(i)%test2, tr(i)%normA, tr(i)%condA
+      end if
+    end do
+    write (nout, 2000) exitt, istop, itn, exitt, normA, condA, exitt, normb, normx, exitt, normr, normAr
+    write (nout, 3000) exitt, msg(istop)
+1000 format(//a, '     Least-squares solution of  Ax = b' &
+           /' The matrix  A  has', i7, ' rows   and', i7, ' columns' &
+           /' damp   =', es22.14 &
+           /' atol   =', es10.2, 15x, 'conlim =', es10.2 &
+           /' btol   =', es10.2, 15x, 'itnlim =', i10 &
+           /' localSize (no. of vectors for local reorthogonalization) =', i7)
+1200 format(/"   Itn       x(1)            norm r         A'r   ", &
+            ' Compatible    LS      norm A    cond A')
+1300 format(/"   Itn       x(1)           norm rbar    Abar'rbar", &
+            ' Compatible    LS    norm Abar cond Abar')
+1500 format(i6, 2es17.9, 5es10.2)
+2000 format(/a, 5x, 'istop  =', i2, 15x, 'itn    =', i8 &
+           /a, 5x, 'normA  =', es12.5, 5x, 'condA  =', es12.5 &
+           /a, 5x, 'normb  =', es12.5, 5x, 'normx  =', es12.5 &
+           /a, 5x, 'normr  =', es12.5, 5x, 'normAr =', es12.5)
+3000 format(a, 5x, a)
   end subroutine
 end module dazim_mod

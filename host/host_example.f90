@@ -5,7 +5,8 @@
 !        vels (k, j, i fastest like the reference's MOD) / nsrc1(kmax) /
 !        per (period k, source s): scx scz nrc  then nrc lines rcx rcz   (radians)
 !        damp atol btol conlim itnlim localSize
-!   out: nar dall / dsurf / istop itn normA normr normx / x
+!   out: nar dall / dsurf / istop itn normA normr normx / x / rw / iw rows / col / matmul(GVs, x) (the product the reference
+!        forms with its dense copy, inv/CalSigamNorm.f90:73) ; the LSMR iteration log goes to <out>.lsmr (nout = 36)
 program host_example
   use dazim_mod
   implicit none
@@ -14,7 +15,7 @@ program host_example
   integer :: itnlim, localSize, istop, itn
   real :: normA, condA, normr, normAr, normx
   real, allocatable :: depz(:), vels(:, :, :), scxf(:, :), sczf(:, :), rcxf(:, :, :), rczf(:, :, :), rw(:), dsurf(:), GVs(:, :)
-  real, allocatable :: b(:), x(:)
+  real, allocatable :: b(:), x(:), gx(:)
   real*8, allocatable :: tRc(:)
   integer, allocatable :: nsrc1(:), nrc1(:, :), periods(:, :), iw(:), col(:)
   character(len=256) :: fin, fout
@@ -47,8 +48,9 @@ program host_example
   close (10)
   n = (nx - 2)*(ny - 2)*(nz - 1)
   maxnar = dall*n
-  allocate (rw(maxnar), iw(2*maxnar + 1), col(maxnar), dsurf(dall), GVs(1, 1))
-  call CalSurfG(nx, ny, nz, n, vels, iw, rw, col, dsurf, GVs, 1, goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
+  allocate (rw(maxnar), iw(2*maxnar + 1), col(maxnar), dsurf(dall), GVs(dall, n))
+  GVs = 0                                                        ! inv/Main_Jt.f90:390
+  call CalSurfG(nx, ny, nz, n, vels, iw, rw, col, dsurf, GVs, dall, goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
                 scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar)
   ! pack iw = [nar | rows | cols] like inv/Main_Jt.f90:529-532 and solve G x = dsurf*1e-3 with LSMR
   iw(1) = nar
@@ -58,8 +60,12 @@ program host_example
   m = dall
   allocate (b(m), x(n))
   b = dsurf*1.0e-3
-  call LSMR(m, n, 2*nar + 1, nar, iw, rw, b, damp, atol, btol, conlim, itnlim, localSize, 0, &
+  open (36, file=trim(fout)//'.lsmr')
+  call LSMR(m, n, 2*nar + 1, nar, iw, rw, b, damp, atol, btol, conlim, itnlim, localSize, 36, &
             x, istop, itn, normA, condA, normr, normAr, normx)
+  close (36)
+  allocate (gx(dall))
+  gx = matmul(GVs, x)                                            ! like CalVsReslNorm, inv/CalSigamNorm.f90:73
   open (11, file=fout)
   write (11, *) nar, dall
   write (11, '(5es16.8)') dsurf
@@ -68,6 +74,7 @@ program host_example
   write (11, '(5es16.8)') rw(1:nar)
   write (11, '(10i8)') iw(2:nar + 1)
   write (11, '(10i8)') col(1:nar)
+  write (11, '(5es16.8)') gx
   close (11)
   call dazim_finalize()
 end program

@@ -209,6 +209,20 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, f
                float btol, float conlim, int itnlim, int localSize, float *x, int *istop, int *itn,
                float *normA, float *condA, float *normr, float *normAr, float *normx);
 
+/* One line of the reference's iteration log (unit nout, inv/lsmrModule.f90:667-682, format 1500:
+ * itn, x(1), normr, normAr, test1, test2, normA, condA) plus test3 and rtol, which together with ctol/atol decide
+ * whether the reference prints the line (:653-661).  Record 0 is the line printed before the loop (:468-471).  */
+typedef struct {
+  int itn;
+  float x1, normr, normAr, test1, test2, test3, rtol, normA, condA;
+} dazim_lsmr_rec;
+/* dazim_lsmr that also returns the iteration log: trace[0..*trace_n) (HOST array of trace_cap records; iterations
+ * beyond trace_cap-1 are not recorded).  The Fortran drop-in LSMR prints it to `nout` in the reference's formats.  */
+int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,
+                      float btol, float conlim, int itnlim, int localSize, float *x, int *istop, int *itn,
+                      float *normA, float *condA, float *normr, float *normAr, float *normx,
+                      dazim_lsmr_rec *trace, int trace_cap, int *trace_n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,16 +48,21 @@ def test_no_cpu_fallback(lib):
 
 
 def test_product_does_not_reference_the_oracle():
-    """nothing under dazimsurftomo_amd/ or include/ may import, link or name the oracle"""
+    """nothing under dazimsurftomo_amd/, include/ or host/ (sources AND build recipes) may import, link or name the oracle,
+    or compile / link the reference's CPU routines (/root/reference, $(REF), its file names)"""
     bad = []
     for base in ("dazimsurftomo_amd", "include", "host"):
         for dp, _, fs in os.walk(os.path.join(ROOT, base)):
             for f in fs:
-                if f.endswith((".py", ".hip", ".h", ".cpp", ".f90")):
+                if f.endswith((".py", ".hip", ".h", ".cpp", ".f90", ".mk")) or f == "Makefile":
                     t = open(os.path.join(dp, f), errors="ignore").read()
                     if re.search(r"liboracle|pyoracle|oracle/|orc_[a-z]", t):
                         bad.append(os.path.join(dp, f))
+                    if f == "Makefile" or f.endswith(".mk"):
+                        if re.search(r"/root/reference|\$\(REF\)|\$\(INV\)|surfdisp96\.f|tregn96\.f|CalSurfG\.f90|depthkernelTI\.f90", t):
+                            bad.append(os.path.join(dp, f) + " (builds reference code)")
     assert not bad, bad
+    assert not os.path.exists(os.path.join(ROOT, "host", "ti_ref.f90"))
 
 
 def test_geometry_matches_reference_constants(lib):

@@ -21,7 +21,7 @@ def check(stdout, steps=1):
     assert d["unit"] == "fields/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["scaling"] == "weak"
     assert d["steps"] == steps and d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma")
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma", "latency")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert 0 < d["spmv"]["Ax"]["frac"] < 1 and 0 < d["spmv"]["ATy"]["frac"] < 1
     return d

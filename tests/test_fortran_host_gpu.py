@@ -2,6 +2,7 @@
 CalSurfG -> LSMR through ISO_C_BINDING; its outputs are compared with the oracle's CalSurfG and
 LSMR on the same input.  Tolerances as in test_rays_gpu.py / test_sparse_gpu.py."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -50,7 +51,8 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     x = np.array(toks[p:p + n], np.float32); p += n
     rw = np.array(toks[p:p + nar], np.float32); p += nar
     irow = np.array(toks[p:p + nar], np.int32); p += nar
-    icol = np.array(toks[p:p + nar], np.int32)
+    icol = np.array(toks[p:p + nar], np.int32); p += nar
+    gx = np.array(toks[p:p + dall], np.float32)          # matmul(GVs, x) formed by the Fortran caller from its dense copy
     rc, rw_o, ir_o, ic_o, ds_o, nb = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
                                                   nrc1, nsrc1, periods, 2_000_000)
     assert rc == 0 and dall == len(ds_o)
@@ -65,3 +67,31 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     assert istop == io["istop"] and abs(itn - io["itn"]) <= max(3, 0.03 * io["itn"])
     assert abs(normr - io["normr"]) <= 1e-3 * io["normr"] + 1e-7
     assert np.linalg.norm(x - xo) <= 5e-3 * np.linalg.norm(xo)
+    # ---- the dense copy GVs the drop-in fills like the reference (inv/CalSurfG.f90:1369-1378): the caller's matmul(GVs, x)
+    # (inv/CalSigamNorm.f90:73) must be the product of the resident matrix built WITHOUT the second threshold (the dense
+    # copy keeps the small entries of touched cells), i.e. dazim_aprod on a rays.keep_small build
+    ctx = dz.Context(0)
+    try:
+        ctx.set_option("rays.keep_small", 1)
+        from tests.test_rays_gpu import device_G
+        Gd = device_G(ctx, nx, ny, goxd, gozd, dv, dv, vel, depz, t, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+        y = np.zeros(dall, np.float32)
+        ctx.aprod(1, Gd, x.copy(), y)
+        assert Gd.nnz >= nar
+        assert np.abs(gx - y).max() <= 3e-6 * max(np.abs(y).max(), 1e-30) + 1e-9
+        # ... and it differs from the thresholded triplets' product by the dropped small entries only
+        yt = (D @ x.astype(np.float64)).astype(np.float32)
+        assert np.abs(gx - yt).max() <= 1e-4 * np.abs(x).sum()
+    finally:
+        ctx.close()
+    # ---- lsmr.txt: the reference's iteration log (inv/lsmrModule.f90:667-682) written by the drop-in LSMR to unit nout
+    log = open(str(fout) + ".lsmr").read()
+    assert "Enter LSMR.       Least-squares solution of  Ax = b" in log
+    assert "The matrix  A  has%7d rows   and%7d columns" % (dall, n) in log
+    assert "Itn       x(1)           norm rbar    Abar'rbar Compatible    LS    norm Abar cond Abar" in log   # damp > 0: format 1300
+    rows = [l.split() for l in log.splitlines() if re.match(r"^\s*\d+\s+-?\d\.\d{9}E[+-]\d\d", l)]
+    assert int(rows[0][0]) == 0 and len(rows[0]) == 6 and int(rows[-1][0]) == itn and len(rows[-1]) == 8
+    its = [int(r[0]) for r in rows]
+    assert its == sorted(set(its)) and all(i in its for i in range(0, min(itn, 10) + 1))   # the first ten are always printed
+    assert abs(float(rows[-1][2]) - normr) <= 1e-6 * normr                                 # norm rbar of the last line
+    assert "Exit  LSMR.       istop  =%2d               itn    =%8d" % (istop, itn) in log

@@ -1,0 +1,59 @@
+"""-m gpu: the row-sharded LSMR with more than one rank, one process per GPU under torch.distributed.run.
+
+`test_two_rank_*` needs a box with >= 2 GPUs and is skipped on the 1-GPU development boxes; `test_one_rank_*` runs the very
+same worker with a single rank (RCCL communicator of size 1), so that every line of the worker and of the in-library RCCL path
+is executed wherever the GPU tests run.  Both compare with the single-process oracle LSMR on the unsharded system: same istop,
+itn within 3, x to 1e-3 -- and x identical on all ranks.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_worker(nproc, tmp_path, port):
+    out = tmp_path / f"dist{nproc}.json"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_lsmr_worker.py"), str(out)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    return json.load(open(out))
+
+
+def check(res, orc, nproc):
+    from tests.dist_lsmr_worker import CFG, system
+    m, n, irow, icol, rw, b = system()
+    xo, io = orc.lsmr(m, n, irow, icol, rw, b, *CFG)
+    assert res["world"] == nproc and res["rccl_nranks"] == nproc            # RCCL really spans all the ranks
+    assert res["same_x_native"] and res["same_x_python"] and res["same_info"]
+    for key in ("native", "python"):
+        x, info = np.array(res["x_" + key], np.float32), res["info_" + key]
+        assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3, (key, info, io)
+        assert np.linalg.norm(x - xo) <= 1e-3 * np.linalg.norm(xo), key
+        assert abs(info["normr"] - io["normr"]) <= 1e-3 * io["normr"]
+
+
+def test_one_rank_worker_native_and_python_driver(orc, tmp_path):
+    check(run_worker(1, tmp_path, 29551), orc, 1)
+
+
+def test_two_rank_rccl_native_and_python_driver(orc, tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the round-end multi-GPU node); the 1-rank variant above runs everywhere")
+    check(run_worker(2, tmp_path, 29552), orc, 2)
+
+
+def test_all_gpus_rccl_native(orc, tmp_path):
+    import torch
+    n = torch.cuda.device_count()
+    if n < 4:
+        pytest.skip("needs >= 4 GPUs")
+    check(run_worker(n, tmp_path, 29553), orc, n)

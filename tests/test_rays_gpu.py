@@ -50,6 +50,16 @@ def flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods):
     return a(fs, np.float32), a(fz, np.float32), a(fp, np.int32), a(ray_f, np.int32), a(rx, np.float32), a(rz, np.float32)
 
 
+def device_G(ctx, nx, ny, goxd, gozd, dvx, dvz, vel, depz, t, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods):
+    """the whole device path (dispersion kernels -> eikonal fields -> rays) for a CalSurfG-shaped input; returns G"""
+    pv, sen, _ = ctx.depthkernel(vel, depz, t, minthk)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    # the kernel slot is the period-loop index (knumi), the velocity map the data file's period id: equal in these cases
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dvx, dvz, pv, scx, scz, per)
+    G, _, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dvx, dvz, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    return G
+
+
 def dense(m, n, irow, icol, rw):
     d = np.zeros((m, n), np.float64)
     d[irow - 1, icol - 1] = rw
