@@ -255,6 +255,33 @@ class Context:
         """aprod (inv/aprod.f90:7): mode 1: y += A x ; mode 2: x += A^T y (in place)"""
         self._check(self.lib.dazim_aprod(self._h, int(mode), A._h, _ptr(x, np.float32), _ptr(y, np.float32)))
 
+    # ---- N4: what surrounds the solve in the outer iteration -----------------------------------------
+    def weight_data(self, G, obst, dsyn):
+        """residual, CalDdatSigma weights (inv/CalSigamNorm.f90:2), weighted right-hand side; scales the data rows of G (nullable).
+        numpy in -> (res, datweight, rhs, stats dict)"""
+        obst = np.ascontiguousarray(obst, np.float32); dsyn = np.ascontiguousarray(dsyn, np.float32)
+        n = len(obst)
+        res, wgt, rhs = (np.zeros(n, np.float32) for _ in range(3))
+        st = np.zeros(8, np.float32)
+        self._check(self.lib.dazim_weight_data(self._h, G._h if G is not None else None, C.c_int64(n), _ptr(obst), _ptr(dsyn),
+                                               _ptr(res), _ptr(wgt), _ptr(rhs), _ptr(st)))
+        keys = ("mean", "std", "mean_abs", "rms", "meandeltaT", "stddeltaT", "mean_weight", "mean_abs_weighted")
+        return res, wgt, rhs, dict(zip(keys, map(float, st)))
+
+    def model_update(self, vs, dv, minvel, maxvel, joint):
+        """clamped model update (inv/Main_Jt.f90:582-620); vs[nz][ny][nx] and dv are updated in place (numpy).
+        Returns (gc, gs, stats[nblock][nz-1][3])"""
+        nz, ny, nx = vs.shape
+        maxvp = (nx - 2) * (ny - 2) * (nz - 1)
+        nblock = 3 if joint else 1
+        assert vs.dtype == np.float32 and dv.dtype == np.float32 and len(dv) == maxvp * nblock
+        gc = np.zeros((nz - 1, ny - 2, nx - 2), np.float32) if joint else None
+        gs = np.zeros((nz - 1, ny - 2, nx - 2), np.float32) if joint else None
+        st = np.zeros((nblock, nz - 1, 3), np.float32)
+        self._check(self.lib.dazim_model_update(self._h, nx, ny, nz, int(bool(joint)), _ptr(vs), _ptr(dv), C.c_float(minvel),
+                                                C.c_float(maxvel), _ptr(gc), _ptr(gs), _ptr(st)))
+        return gc, gs, st
+
     def lsmr(self, A, b, damp, atol, btol, conlim, itnlim, localSize, x=None):
         """LSMR (inv/lsmrModule.f90:36) -> x, info dict (istop, itn, normA, condA, normr, normAr, normx)"""
         if x is None:
@@ -292,6 +319,14 @@ class SparseMatrix:
                                                           _ptr(irow), _ptr(icol), _ptr(rw)))
         self.m += extra_m
         self.nnz += len(rw)
+
+    def append_tikhonov(self, nx, ny, nz, weights):
+        """Tikhonov rows generated on the device (inv/TikhRegul.f90:2): one block of (nx-2)(ny-2)(nz-1) rows per weight"""
+        w = np.ascontiguousarray(weights, np.float32)
+        m0, z0 = C.c_int64(0), C.c_int64(0)
+        self.ctx._check(self.ctx.lib.dazim_csr_append_tikhonov(self.ctx._h, self._h, nx, ny, nz, len(w), _ptr(w)))
+        self.ctx._check(self.ctx.lib.dazim_csr_dims(self._h, C.byref(m0), None, C.byref(z0)))
+        self.m, self.nnz = m0.value, z0.value
 
     def to_coo(self):
         irow = np.zeros(self.nnz, np.int32); icol = np.zeros(self.nnz, np.int32); rw = np.zeros(self.nnz, np.float32)

@@ -39,6 +39,44 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
   return 0;
 }
 
+// Staging cache: best fit among the free blocks, else a new allocation; at most 64 blocks / 2 GiB are kept, larger or surplus
+// blocks are released on return.
+int dz_stage_get(dazim_ctx *ctx, size_t bytes, void **out) {
+  if (bytes == 0) bytes = 16;
+  int best = -1;
+  for (size_t i = 0; i < ctx->stage.size(); i++) {
+    auto &b = ctx->stage[i];
+    if (!b.busy && b.bytes >= bytes && (best < 0 || b.bytes < ctx->stage[best].bytes)) best = (int)i;
+  }
+  if (best >= 0 && ctx->stage[best].bytes <= 4 * bytes + (1 << 20)) {
+    ctx->stage[best].busy = true;
+    *out = ctx->stage[best].p;
+    return 0;
+  }
+  void *p = nullptr;
+  DZ_HIP(hipMalloc(&p, bytes));
+  ctx->stage.push_back({p, bytes, true});
+  *out = p;
+  return 0;
+}
+void dz_stage_put(dazim_ctx *ctx, void *p) {
+  size_t kept = 0, nfree = 0;
+  for (auto &b : ctx->stage)
+    if (!b.busy) { kept += b.bytes; nfree++; }
+  for (size_t i = 0; i < ctx->stage.size(); i++) {
+    auto &b = ctx->stage[i];
+    if (b.p != p) continue;
+    if (nfree >= 64 || kept + b.bytes > ((size_t)2 << 30)) {
+      (void)hipFree(b.p);
+      ctx->stage.erase(ctx->stage.begin() + i);
+    } else {
+      b.busy = false;
+    }
+    return;
+  }
+  (void)hipFree(p);   // not from the cache
+}
+
 namespace {
 __global__ void k_range_flag(int64_t n, const int *a, int lo, int hi, int *bad) {
   bool b = false;
@@ -94,6 +132,8 @@ void dazim_destroy(dazim_ctx *ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && ctx->comm_release) ctx->comm_release(ctx);
+  for (auto &b : ctx->stage) (void)hipFree(b.p);
+  ctx->stage.clear();
   for (auto &kv : ctx->scratch)
     if (kv.second.first) (void)hipFree(kv.second.first);
   (void)hipEventDestroy(ctx->ev0);

@@ -22,6 +22,10 @@ struct dazim_ctx {
   // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
   std::map<std::string, std::pair<void *, size_t>> scratch;
   // RCCL communicator of a row-sharded solve (dazim_comm_init); nullptr = single GPU, RCCL never touched
+  // staging blocks for host-pointer arguments (DzBuf): released blocks are kept and handed out again, because a
+  // hipMalloc + hipFree pair per staged array costs milliseconds in a program that calls the library once per outer iteration
+  struct StageBlock { void *p; size_t bytes; bool busy; };
+  std::vector<StageBlock> stage;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
@@ -41,6 +45,8 @@ int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
 
 bool dz_is_device_ptr(const void *p);
+int dz_stage_get(dazim_ctx *ctx, size_t bytes, void **out);   // a device block of >= bytes from the context's staging cache
+void dz_stage_put(dazim_ctx *ctx, void *p);                   // give it back (kept for reuse; freed by dazim_destroy)
 
 // every a[i] of a DEVICE array inside lo..hi?  Returns 0, or DAZIM_E_BAD_ARG with "<what> outside lo..hi" as the message.
 int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what);
@@ -64,7 +70,12 @@ struct DzBuf {
       return 0;
     }
     staged = true;
-    DZ_HIP(hipMalloc((void **)&dev, n * sizeof(T)));
+    {
+      void *blk = nullptr;
+      int rc_ = dz_stage_get(ctx, n * sizeof(T), &blk);
+      if (rc_) return rc_;
+      dev = (T *)blk;
+    }
     if (copy_in) DZ_HIP(hipMemcpyAsync(dev, user, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return 0;
   }
@@ -76,7 +87,7 @@ struct DzBuf {
   ~DzBuf() {
     if (staged && dev) {
       (void)hipStreamSynchronize(ctx->stream);
-      (void)hipFree(dev);
+      dz_stage_put(ctx, dev);
     }
   }
 };

@@ -203,6 +203,33 @@ struct Heap {
     }
     put(c, key, node);
   }
+  // addtree / updtree (:738-783, :872-890) for the all-in-LDS heap in ONE LDS round instead of a loop over the levels: lane i of
+  // the group reads ancestor c >> (i+1) of the rising entry (a heap of < 4096 slots has at most 11); the entry rises past the
+  // leading run of ancestors whose key is larger (strict <, like the sequential loop), and each of those moves down one level --
+  // lane i writes its ancestor into slot c >> i and that node's back-pointer, lane L places the entry itself at c >> L.  Same
+  // comparisons, same final array.  Returns L, the number of levels risen (the caller shifts the slots of pending neighbours
+  // that sat on the path).  Groups with live == false read and write the dummy slot 0.
+  __device__ __forceinline__ int rise_par(bool live, int gl, int gbase, int c, float key, int node) {
+    const int a = c >> (gl + 1);
+    const bool valid = live && a >= 1;
+    const int rs = valid ? a : 0;
+    const float ak = keys[rs];
+    const NT an = nodes[rs];
+    const unsigned mb = (unsigned)(__ballot(valid && key < ak) >> gbase) & 0xffffu;
+    const int L = __builtin_ctz(~mb);                      // (bit 16 of ~mb is set: L <= 16, and <= 11 by the heap depth)
+    const bool mover = live && gl < L;
+    const int dst = mover ? (c >> gl) : 0;
+    keys[dst] = ak;
+    nodes[dst] = an;
+    if (mover) rec[idx(NodeCodec<NT>::dec(an))].s = dst;
+    if (live && gl == L) {
+      const int fin = c >> L;
+      keys[fin] = key;
+      nodes[fin] = NodeCodec<NT>::enc(node);
+      rec[idx(node)] = Node{key, fin};
+    }
+    return L;
+  }
   __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= CAP; }
   __device__ __forceinline__ void add(float key, int node) {
     const int nbn[4] = {0, 0, 0, 0};
@@ -607,22 +634,50 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
 #pragma unroll
         for (int n = 0; n < 4; n++)
           if (nbs[n] > 0 && nbm[n] > 0) nbs[n] = nbm[n];   // its entry moved during the sift-down
-      }
 #pragma unroll
-      for (int n = 0; n < 4; n++) {
-        if (nbs[n] == 0 || n < n0) continue;
-        const int node = nbn[n];
-        if (H.g0) rec[H.idx(node)].t = nbt[n];
-        int c = nbs[n];
-        if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
-          if (H.full()) {
-            overflow = true;
-            break;
+        for (int n = 0; n < 4; n++) {
+          if (nbs[n] == 0 || n < n0) continue;
+          const int node = nbn[n];
+          if (H.g0) rec[H.idx(node)].t = nbt[n];
+          int c = nbs[n];
+          if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
+            if (H.full()) {
+              overflow = true;
+              break;
+            }
+            H.ntr++;
+            c = H.ntr;
           }
-          H.ntr++;
-          c = H.ntr;
+          H.template sift_up<true>(c, nbt[n], node, nbn, nbs, n);
         }
-        H.template sift_up<true>(c, nbt[n], node, nbn, nbs, n);
+      } else {
+        // all-in-LDS heap: one parallel round per remaining neighbour, in the reference's order (the four groups of the
+        // wavefront run their n-th neighbour together; a round nobody needs is skipped)
+#pragma unroll
+        for (int n = 0; n < 4; n++) {
+          bool live = nbs[n] != 0 && n >= n0 && !overflow;
+          if (__ballot(live) == 0) continue;
+          int c = nbs[n];
+          if (live && c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
+            if (H.full()) {
+              overflow = true;
+              live = false;
+            } else {
+              H.ntr++;
+              c = H.ntr;
+            }
+          }
+          const int L = H.rise_par(live, gl, gbase, c, nbt[n], nbn[n]);
+          // a pending neighbour whose entry sat on the path moved down one level with it
+#pragma unroll
+          for (int m = n + 1; m < 4; m++) {
+            const int sm = nbs[m];
+            if (live && sm > 0 && sm < c) {
+              const int d = __clz(sm) - __clz(c);              // levels between the two slots
+              if (d >= 1 && d <= L && (c >> d) == sm) nbs[m] = c >> (d - 1);
+            }
+          }
+        }
       }
     }
     PROF(6);

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 struct dazim_csr {
   int64_t m = 0, n = 0, nnz = 0;
@@ -923,6 +924,173 @@ int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out,
   return 0;
 }
 
+
+// ---- N4: regularisation rows, data weights and the clamped model update on the device ---------------------------------------
+// One thread per regularisation row r = blk*maxvp + cell (cell in the reference's k, j, i loop order, inv/TikhRegul.f90:20-23):
+// a cell on a face of the block holds one entry 2w, an interior cell the 7-point stencil 6w, -w x 6 (inv/TikhRegul.f90:24-58).
+__device__ __forceinline__ bool tikh_face(int cell, int nvx, int nvz, int nzm1, int &i, int &j, int &k) {
+  k = cell / (nvx * nvz);
+  const int r = cell - k * nvx * nvz;
+  j = r / nvx;
+  i = r - j * nvx;
+  return i == 0 || i == nvx - 1 || j == 0 || j == nvz - 1 || k == 0 || k == nzm1 - 1;
+}
+__global__ void k_tikh_count(int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, long *cnt) {
+  const int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x;
+  if (r > nrow) return;
+  int i, j, k;
+  cnt[r] = r == nrow ? 0 : (tikh_face((int)(r % maxvp), nvx, nvz, nzm1, i, j, k) ? 1 : 7);
+}
+// entries written with ascending columns (the canonical order every other row of the matrix has)
+__global__ void k_tikh_fill(int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, const long *off, int64_t nnz0,
+                            const float *__restrict__ w, int64_t *__restrict__ rowptr, int *__restrict__ col,
+                            float *__restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x;
+  if (r > nrow) return;
+  rowptr[r] = nnz0 + off[r];
+  if (r == nrow) return;
+  const int blk = (int)(r / maxvp), cell = (int)(r - (int64_t)blk * maxvp);
+  int i, j, k;
+  const bool face = tikh_face(cell, nvx, nvz, nzm1, i, j, k);
+  const float wt = w[blk];
+  const int c = blk * maxvp + cell;
+  const int64_t p = nnz0 + off[r];
+  if (face) {
+    col[p] = c;
+    val[p] = 2.0f * wt;
+  } else {
+    const int d[7] = {-nvz * nvx, -nvx, -1, 0, 1, nvx, nvz * nvx};
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+      col[p + q] = c + d[q];
+      val[p + q] = q == 3 ? 6.0f * wt : -1.0f * wt;
+    }
+  }
+}
+// res = obst - dsyn ; rel = |res / obst|   (inv/Main_Jt.f90:432-435, inv/CalSigamNorm.f90:20-23)
+__global__ void k_residual(int64_t n, const float *obst, const float *dsyn, float *res, float *rel) {
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    const float r = obst[i] - dsyn[i];
+    res[i] = r;
+    rel[i] = fabsf(r / obst[i]);
+  }
+}
+// meandeltaT and stddeltaT of CalDdatSigma (inv/CalSigamNorm.f90:20-31): two sequential fp32 sums, kept sequential (one lane) so
+// that the weights are the reference's bit for bit -- 2 n dependent additions, 0.1 ms at test4's 20 877 rays
+__global__ void k_sigma_stats(int64_t n, const float *rel, float *out) {
+  // the workgroup stages chunks of rel in LDS (coalesced loads); lane 0 adds them in index order
+  constexpr int CH = 8192;
+  __shared__ float s_c[CH];
+  __shared__ float s_mean;
+  float acc = 0.0f;
+  for (int pass = 0; pass < 2; pass++) {
+    acc = 0.0f;
+    const float mean = pass ? s_mean : 0.0f;
+    for (int64_t base = 0; base < n; base += CH) {
+      const int len = (int)((n - base) < CH ? (n - base) : CH);
+      __syncthreads();
+      for (int i = threadIdx.x; i < len; i += blockDim.x) s_c[i] = rel[base + i];
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        if (pass == 0)
+          for (int i = 0; i < len; i++) acc = acc + s_c[i];
+        else
+          for (int i = 0; i < len; i++) acc = acc + (s_c[i] - mean) * (s_c[i] - mean);
+      }
+    }
+    if (threadIdx.x == 0) {
+      if (pass == 0) {
+        s_mean = acc / (float)n;
+        out[0] = s_mean;
+      } else {
+        out[1] = sqrtf(acc / (float)n);
+      }
+    }
+    __syncthreads();
+  }
+}
+// sigmaT (inv/CalSigamNorm.f90:32-40), datweight = 1/sigmaT, cbst = res*datweight (inv/Main_Jt.f90:462-466)
+__global__ void k_sigma_weights(int64_t n, const float *obst, const float *res, const float *rel, const float *ms, float *wgt,
+                                float *rhs) {
+  const float sd = ms[1];
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    const float ratio = fabsf(rel[i] / (1.5f * sd));
+    float sigma = sd * obst[i];
+    if (ratio > 1.0f) sigma = sigma * (float)exp((double)(ratio - 1.0f));   // correctly rounded expf like the host libm's
+    const float wt = 1.0f / sigma;
+    wgt[i] = wt;
+    rhs[i] = res[i] * wt;
+  }
+}
+// sums for the log lines: part[b][0..4] = sum res, sum |res|, sum res^2, sum wgt, sum |rhs|
+__global__ void k_weight_sums(int64_t n, const float *res, const float *wgt, const float *rhs, double *part) {
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+    const double r = res[i];
+    a[0] += r; a[1] += fabs(r); a[2] += r * r; a[3] += wgt[i]; a[4] += fabsf(rhs[i]);
+  }
+  __shared__ double s[5][VB / 64];
+#pragma unroll
+  for (int q = 0; q < 5; q++) {
+    const double t = wave_sum(a[q]);
+    if ((threadIdx.x & 63) == 0) s[q][threadIdx.x >> 6] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    double t = 0.0;
+    for (int i = 0; i < VB / 64; i++) t += s[threadIdx.x][i];
+    part[blockIdx.x * 5 + threadIdx.x] = t;
+  }
+}
+// clamped update of the shear velocities and the Gc, Gs maps (inv/Main_Jt.f90:582-620); one thread per inner cell
+__global__ void k_model_update(int nx, int ny, int nzm1, int joint, float *vs, float *dv, float minvel, float maxvel, float *gc,
+                               float *gs) {
+  const int nvx = nx - 2, nvz = ny - 2, maxvp = nvx * nvz * nzm1;
+  const int ii = blockIdx.x * VB + threadIdx.x;
+  if (ii >= maxvp) return;
+  const int k = ii / (nvx * nvz), r = ii - k * nvx * nvz, j = r / nvx, i = r - j * nvx;
+  float p = dv[ii];
+  if (p >= 0.500f) p = 0.500f;
+  if (p <= -0.500f) p = -0.500f;
+  if (fabsf(p) < 1e-5f) p = 0.0f;
+  dv[ii] = p;
+  const size_t iv = ((size_t)k * ny + (j + 1)) * nx + (i + 1);
+  float v = vs[iv] + p;
+  if (v < minvel) v = minvel;
+  if (v > maxvel) v = maxvel;
+  vs[iv] = v;
+  if (joint) {
+    if (gc) gc[ii] = dv[maxvp + ii];
+    if (gs) gs[ii] = dv[2 * maxvp + ii];
+  }
+}
+// per (block, depth) min, max and sum |.| of the update (the log lines of inv/Main_Jt.f90:621-666): one workgroup each
+__global__ void k_update_stats(int ncell, const float *dv, float *out) {
+  const float *x = dv + (size_t)blockIdx.x * ncell;
+  float mn = INFINITY, mx = -INFINITY;
+  double sa = 0.0;
+  for (int i = threadIdx.x; i < ncell; i += VB) {
+    const float v = x[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+    sa += fabsf(v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o));
+    mx = fmaxf(mx, __shfl_xor(mx, o));
+  }
+  sa = wave_sum(sa);
+  __shared__ float s_mn[VB / 64], s_mx[VB / 64];
+  __shared__ double s_sa[VB / 64];
+  if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; s_sa[threadIdx.x >> 6] = sa; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < VB / 64; i++) { mn = fminf(mn, s_mn[i]); mx = fmaxf(mx, s_mx[i]); sa += s_sa[i]; }
+    out[blockIdx.x * 3 + 0] = mn; out[blockIdx.x * 3 + 1] = mx; out[blockIdx.x * 3 + 2] = (float)sa;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1509,6 +1677,147 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
                float *normA_o, float *condA_o, float *normr_o, float *normAr_o, float *normx_o) {
   return dazim_lsmr_traced(ctx, A, b_u, damp, atol, btol, conlim, itnlim, localSize, x_u, istop_o, itn_o, normA_o, condA_o,
                            normr_o, normAr_o, normx_o, nullptr, 0, nullptr);
+}
+
+// ---- N4 ------------------------------------------------------------------------------------------------------------------------
+// = TikhonovRegularization / TikhRegul_joint (inv/TikhRegul.f90:2-104, :107-209): nblock*maxvp rows appended to the resident
+// matrix, generated on the device (block b regularises columns b*maxvp+1.., weight w[b])
+int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int nz, int nblock, const float *w_host) {
+  if (!ctx || !A || !w_host || nblock < 1 || nx < 3 || ny < 3 || nz < 2) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_append_tikhonov");
+  const int nvx = nx - 2, nvz = ny - 2, nzm1 = nz - 1;
+  const int64_t maxvp = (int64_t)nvx * nvz * nzm1, nrow = maxvp * nblock;
+  if (maxvp * nblock > A->n || maxvp > 0x7ffffff0) return dz_fail(ctx, DAZIM_E_BAD_ARG, "regularisation blocks do not fit the %lld columns", (long long)A->n);
+  DZ_HIP(hipSetDevice(ctx->device));
+  int rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "tikh.cnt", (size_t)(nrow + 1) * 8, &p))) return rc;
+  long *cnt = (long *)p;
+  if ((rc = dz_scratch(ctx, "tikh.off", (size_t)(nrow + 1) * 8, &p))) return rc;
+  long *off = (long *)p;
+  if ((rc = dz_scratch(ctx, "tikh.w", 64 * 4, &p))) return rc;
+  float *dw = (float *)p;
+  if (nblock > 64) return dz_fail(ctx, DAZIM_E_BAD_ARG, "too many regularisation blocks");
+  DZ_HIP(hipMemcpyAsync(dw, w_host, (size_t)nblock * 4, hipMemcpyHostToDevice, ctx->stream));
+  const unsigned nb = (unsigned)((nrow + 1 + VB - 1) / VB);
+  hipLaunchKernelGGL(k_tikh_count, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, cnt);
+  size_t tb = 0;
+  DZ_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, off, 0l, (size_t)(nrow + 1), rocprim::plus<long>(), ctx->stream));
+  if ((rc = dz_scratch(ctx, "tikh.scan", tb + 256, &p))) return rc;
+  DZ_HIP(rocprim::exclusive_scan(p, tb, cnt, off, 0l, (size_t)(nrow + 1), rocprim::plus<long>(), ctx->stream));
+  long nnz2 = 0;
+  DZ_HIP(hipMemcpyAsync(&nnz2, off + nrow, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t m2 = A->m + nrow, nz2 = A->nnz + nnz2;
+  if (nz2 > 0xfffffff0ll) return dz_fail(ctx, DAZIM_E_NNZ_OVERFLOW, "too many stored entries");
+  int64_t *rowptr;
+  int *col;
+  float *val;
+  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m2 + 1) * 8));
+  DZ_HIP(hipMalloc((void **)&col, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  DZ_HIP(hipMalloc((void **)&val, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  DZ_HIP(hipMemcpyAsync(rowptr, A->rowptr, (size_t)A->m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(col, A->col, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(val, A->val, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
+                     rowptr + A->m, col, val);
+  DZ_HIP(hipGetLastError());
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(A->rowptr);
+  (void)hipFree(A->col);
+  (void)hipFree(A->val);
+  A->rowptr = rowptr; A->col = col; A->val = val;
+  A->m = m2; A->nnz = nz2;
+  if ((rc = build_colblocks(ctx, A))) return rc;
+  if ((rc = invalidate_transpose(A))) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// = residuals + CalDdatSigma + data weights + weighted right-hand side + row scaling of G (inv/Main_Jt.f90:432-469,
+// inv/CalSigamNorm.f90:2-41) on the device.  obst, dsyn in; res (= Tdata), datweight, rhs (= cbst weighted) out, dall each
+// (host or device); G nullable.  stats (host, 8 floats): mean, std, mean |.|, rms of the residual; meandeltaT, stddeltaT;
+// mean weight; mean |weighted residual|.
+int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *obst_u, const float *dsyn_u, float *res_u,
+                      float *wgt_u, float *rhs_u, float *stats) {
+  if (!ctx || dall < 1 || !obst_u || !dsyn_u || !res_u || !wgt_u || !rhs_u || (G && G->m < dall))
+    return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_weight_data");
+  DZ_HIP(hipSetDevice(ctx->device));
+  DzBuf<float> obst, dsyn, res, wgt, rhs;
+  int rc;
+  if ((rc = obst.init(ctx, obst_u, dall, true, false)) || (rc = dsyn.init(ctx, dsyn_u, dall, true, false)) ||
+      (rc = res.init(ctx, res_u, dall, false, true)) || (rc = wgt.init(ctx, wgt_u, dall, false, true)) ||
+      (rc = rhs.init(ctx, rhs_u, dall, false, true)))
+    return rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "wd.rel", (size_t)dall * 4, &p))) return rc;
+  float *rel = (float *)p;
+  if ((rc = dz_scratch(ctx, "wd.ms", 64, &p))) return rc;
+  float *ms = (float *)p;
+  if ((rc = dz_scratch(ctx, "wd.part", (size_t)NPART * 5 * 8, &p))) return rc;
+  double *part = (double *)p;
+  const int nb = nblk(dall, NPART);
+  hipLaunchKernelGGL(k_residual, dim3(nb), dim3(VB), 0, ctx->stream, dall, obst.dev, dsyn.dev, res.dev, rel);
+  hipLaunchKernelGGL(k_sigma_stats, dim3(1), dim3(VB), 0, ctx->stream, dall, rel, ms);
+  hipLaunchKernelGGL(k_sigma_weights, dim3(nb), dim3(VB), 0, ctx->stream, dall, obst.dev, res.dev, rel, ms, wgt.dev, rhs.dev);
+  hipLaunchKernelGGL(k_weight_sums, dim3(nb), dim3(VB), 0, ctx->stream, dall, res.dev, wgt.dev, rhs.dev, part);
+  DZ_HIP(hipGetLastError());
+  std::vector<double> hp((size_t)nb * 5);
+  float hms[2];
+  DZ_HIP(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(hms, ms, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (G) {   // rw(i) = rw(i)*datweight(iw(1+i)) for the data rows; rows beyond dall (none yet in the reference's order) untouched
+    hipLaunchKernelGGL(k_scale_rows, dim3(spmv_blocks(ctx, dall, -1)), dim3(64 * WPB), 0, ctx->stream, dall, G->rowptr, G->val, wgt.dev);
+    if (G->tperm) hipLaunchKernelGGL(k_gather_f, dim3(nblk(G->nnz)), dim3(VB), 0, ctx->stream, G->nnz, G->tperm, G->val, G->tval);
+    DZ_HIP(hipGetLastError());
+  }
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  if (G && (rc = build_colblocks(ctx, G))) return rc;
+  if (stats) {
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int b = 0; b < nb; b++)
+      for (int q = 0; q < 5; q++) a[q] += hp[(size_t)b * 5 + q];
+    const double n = (double)dall, mean = a[0] / n;
+    stats[0] = (float)mean;
+    stats[1] = (float)sqrt(fmax(a[2] / n - mean * mean, 0.0));
+    stats[2] = (float)(a[1] / n);
+    stats[3] = (float)sqrt(a[2] / n);
+    stats[4] = hms[0];
+    stats[5] = hms[1];
+    stats[6] = (float)(a[3] / n);
+    stats[7] = (float)(a[4] / n);
+  }
+  if ((rc = res.finish()) || (rc = wgt.finish()) || (rc = rhs.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// = the clamped model update (inv/Main_Jt.f90:582-620) on the device: dv (n = maxvp or 3*maxvp, in/out: the dVs block is clamped
+// to +-0.5 and zeroed below 1e-5), vs[nz][ny][nx] in/out (+= dVs on the inner cells, clamped to [minvel, maxvel]), gc, gs
+// [nz-1][ny-2][nx-2] out (joint, nullable).  stats (host, nullable): per block (dVs, Gc, Gs) and depth k: min, max, sum |.| of
+// the update -> [nblock][nz-1][3].
+int dazim_model_update(dazim_ctx *ctx, int nx, int ny, int nz, int joint, float *vs_u, float *dv_u, float minvel, float maxvel,
+                       float *gc_u, float *gs_u, float *stats) {
+  if (!ctx || !vs_u || !dv_u || nx < 3 || ny < 3 || nz < 2) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_model_update");
+  DZ_HIP(hipSetDevice(ctx->device));
+  const int nzm1 = nz - 1, ncell = (nx - 2) * (ny - 2), maxvp = ncell * nzm1, nblock = joint ? 3 : 1;
+  DzBuf<float> vs, dv, gc, gs;
+  int rc;
+  if ((rc = vs.init(ctx, vs_u, (size_t)nx * ny * nz, true, true)) || (rc = dv.init(ctx, dv_u, (size_t)maxvp * nblock, true, true)) ||
+      (rc = gc.init(ctx, gc_u, joint ? maxvp : 0, false, true)) || (rc = gs.init(ctx, gs_u, joint ? maxvp : 0, false, true)))
+    return rc;
+  hipLaunchKernelGGL(k_model_update, dim3((maxvp + VB - 1) / VB), dim3(VB), 0, ctx->stream, nx, ny, nzm1, joint, vs.dev, dv.dev,
+                     minvel, maxvel, joint ? gc.dev : nullptr, joint ? gs.dev : nullptr);
+  DZ_HIP(hipGetLastError());
+  if (stats) {
+    void *p;
+    if ((rc = dz_scratch(ctx, "mu.stats", (size_t)nblock * nzm1 * 3 * 4, &p))) return rc;
+    hipLaunchKernelGGL(k_update_stats, dim3(nblock * nzm1), dim3(VB), 0, ctx->stream, ncell, dv.dev, (float *)p);
+    DZ_HIP(hipGetLastError());
+    DZ_HIP(hipMemcpyAsync(stats, p, (size_t)nblock * nzm1 * 3 * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if ((rc = vs.finish()) || (rc = dv.finish()) || (rc = gc.finish()) || (rc = gs.finish())) return rc;
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 }  // extern "C"

@@ -43,8 +43,14 @@ program DAzimSurfTomo_amd
   integer(8) :: maxnar
   type(c_ptr) :: G
   integer :: c0, c1, crate
+  real :: wstats(8)
+  real, allocatable :: ustats(:, :, :)       ! (3: min, max, sum |.| ; nz-1 ; block) of the update, from dazim_model_update
+  integer(8) :: tk0, tk1, tkrate
+  real(8) :: tph(9) = 0                      ! wall seconds per phase, printed when DAZIM_TIMING is set (tools/run_test4_program.sh)
+  character(len=8) :: timing_env
 
   call system_clock(c0, crate)
+  call system_clock(tk0, tkrate)
   open (36, file='lsmr.txt')
   write (*, *)
   write (*, *) '                       DAzimSurfTomo (MI355X hot path)'
@@ -204,7 +210,10 @@ program DAzimSurfTomo_amd
   write (*, *) ' grid points in depth direction:(km)'
   write (*, '(50f7.2)') depz
 
+  allocate (ustats(3, nz - 1, 3))
+  call tick(1)                               ! inputs read
   call dazim_init(0)
+  call tick(2)                               ! HIP context
   open (34, file='IterVel.out')
   do iter = 1, maxiter
     write (6, *) ' -----------------------------------------------------------'
@@ -237,57 +246,54 @@ program DAzimSurfTomo_amd
         end do
       end do
     end if
+    call tick(3)                             ! dispersion + eikonal + rays + G on the device
     if (iter == 1) then
       open (77, file='period_phaseVMOD.dat')
       call write_phase_maps(77)
     end if
+    call tick(9)
 
-    ! ---- residuals and data weights, inv/Main_Jt.f90:432-470 -------------------------------------------------
-    cbst = 0
-    do i = 1, dall
-      cbst(i) = obst(i) - dsyn(i)
-      Tdata(i) = cbst(i)
-    end do
-    mean = sum(cbst(1:dall))/dall
-    std_devs = sqrt(sum((cbst(1:dall) - mean)**2)/dall)
-    meanAbs = sum(abs(cbst(1:dall)))/dall
-    write (6, '(a, f12.4,a,f10.2,a,f10.2,a)') '  Before Inversion: abs mean, std, RMS of Res:', meanAbs, ' s ', &
-      std_devs, ' s ', nrm2(dall, cbst)/sqrt(real(dall)), ' s'
-    write (66, '(a, f12.4,a,f10.2,a,f10.2,a)') '  Before Inversion: abs mean, std, RMS of Res:', meanAbs, ' s ', &
-      std_devs, ' s ', nrm2(dall, cbst)/sqrt(real(dall)), ' s'
-    call data_sigma(dall, obst, cbst, sigmaT, meandeltaT)
-    do i = 1, dall
-      datweight(i) = 1/sigmaT(i)
-      cbst(i) = cbst(i)*datweight(i)
-    end do
-    call dazim_check(dazim_csr_scale_rows(dazim_handle, G, datweight), 'scale_rows')   ! rw(i)=rw(i)*datweight(iw(1+i))
-    meanAbs = sum(abs(cbst(1:dall)))/dall
-    write (6, '(a, f8.3, a, f8.3,a, f7.3, a)') '  mean data weight:', sum(datweight(1:dall))/dall, &
-      ' |  abs data mean with weight:', meanAbs, 's  |  dt/t0:', meandeltaT*100, ' %'
-    write (66, '(a, f8.3, a, f8.3,a, f7.3, a)') '  mean data weight:', sum(datweight(1:dall))/dall, &
-      ' |  abs data mean with weight:', meanAbs, 's  |  dt/t0:', meandeltaT*100, ' %'
+    ! ---- residuals, CalDdatSigma weights, weighted right-hand side and row scaling on the device, inv/Main_Jt.f90:432-470 ----
+    cbst = 0                                  ! (the rows of the regularisation block keep a zero right-hand side)
+    call dazim_check(dazim_weight_data(dazim_handle, G, int(dall, c_int64_t), obst, dsyn, Tdata, datweight, cbst, wstats), &
+                     'data weights')
+    meandeltaT = wstats(5)
+    write (6, '(a, f12.4,a,f10.2,a,f10.2,a)') '  Before Inversion: abs mean, std, RMS of Res:', wstats(3), ' s ', &
+      wstats(2), ' s ', wstats(4), ' s'
+    write (66, '(a, f12.4,a,f10.2,a,f10.2,a)') '  Before Inversion: abs mean, std, RMS of Res:', wstats(3), ' s ', &
+      wstats(2), ' s ', wstats(4), ' s'
+    write (6, '(a, f8.3, a, f8.3,a, f7.3, a)') '  mean data weight:', wstats(7), &
+      ' |  abs data mean with weight:', wstats(8), 's  |  dt/t0:', meandeltaT*100, ' %'
+    write (66, '(a, f8.3, a, f8.3,a, f7.3, a)') '  mean data weight:', wstats(7), &
+      ' |  abs data mean with weight:', wstats(8), 's  |  dt/t0:', meandeltaT*100, ' %'
     if (iso_mod) call dazim_check(dazim_csr_col_abs_sums(dazim_handle, G, norm), 'DWS')   ! inv/Main_Jt.f90:477-481
 
+    call tick(4)                             ! residuals, weights, row scaling, DWS
     ! ---- regularisation rows appended to the resident matrix, inv/Main_Jt.f90:483-500 ----------------------------
     nar1 = nar
-    nreg = 0; count3 = 0; narVs = 0
-    if (iso_mod) then
+    if (iter == 1) then                       ! the rows depend on the grid and the weights only: the host copy (used by the ||Lm||
+      nreg = 0; count3 = 0; narVs = 0         ! diagnostics) is made once, the matrix block is generated on the device every time
       call laplacian_rows(0, weightVs)
-    else
-      call laplacian_rows(0, weightVs)
-      narVs = nreg
-      call laplacian_rows(1, weightGcs)
-      call laplacian_rows(2, weightGcs)
+      if (.not. iso_mod) then
+        narVs = nreg
+        call laplacian_rows(1, weightGcs)
+        call laplacian_rows(2, weightGcs)
+      end if
     end if
     nar = nar1 + nreg
     if (int(nar, 8) > maxnar) stop 'increase sparsity fraction(spfra)'                   ! inv/Main_Jt.f90:523
-    call dazim_check(dazim_csr_append_coo(dazim_handle, G, int(count3, c_int64_t), int(nreg, c_int64_t), rowreg, colreg, rwreg), &
-                     'append Tikhonov rows')
+    if (iso_mod) then
+      call dazim_check(dazim_csr_append_tikhonov(dazim_handle, G, nx, ny, nz, 1_c_int, [weightVs]), 'Tikhonov rows')
+    else
+      call dazim_check(dazim_csr_append_tikhonov(dazim_handle, G, nx, ny, nz, 3_c_int, [weightVs, weightGcs, weightGcs]), &
+                       'Tikhonov rows')
+    end if
     write (*, '(a,3f8.2)') '  damp,  lamebda Gsc, lamebda Vs: ', damp, weightGcs, weightVs
     write (66, '(a,3f8.2)') '  damp,  lamebda Gsc, lamebda Vs: ', damp, weightGcs, weightVs
     m = dall + count3
     n = maxm
 
+    call tick(5)                             ! Tikhonov rows
     ! ---- LSMR on the device, inv/Main_Jt.f90:534-574 ----------------------------------------------------------------
     dv = 0
     if (iso_mod) then
@@ -318,52 +324,34 @@ program DAzimSurfTomo_amd
     write (*, '(a, f7.1)') '  arnorm=            ', arnorm
     write (*, '(a, f7.3)') '  norm of dv =       ', xnorm
 
+    call tick(6)                             ! LSMR + its log
     ! ---- clamped model update, inv/Main_Jt.f90:576-618 ------------------------------------------------------------------
     if (.not. iso_mod) then
       gcf = 0; gsf = 0
     end if
-    do k = 1, nz - 1
-      do j = 1, ny - 2
-        do i = 1, nx - 2
-          ii = (k - 1)*(nx - 2)*(ny - 2) + (j - 1)*(nx - 2) + i
-          pertV = dv(ii)
-          if (pertV >= 0.500) pertV = 0.500
-          if (pertV <= -0.500) pertV = -0.500
-          if (abs(pertV) < 1e-5) pertV = 0.0
-          dv(ii) = pertV
-          vsf(i + 1, j + 1, k) = vsf(i + 1, j + 1, k) + dv(ii)
-          if (vsf(i + 1, j + 1, k) < Minvel) vsf(i + 1, j + 1, k) = Minvel
-          if (vsf(i + 1, j + 1, k) > Maxvel) vsf(i + 1, j + 1, k) = Maxvel
-          if (.not. iso_mod) then
-            gcf(i, j, k) = dv(maxvp + ii)
-            gsf(i, j, k) = dv(maxvp*2 + ii)
-          end if
-        end do
-      end do
-    end do
+    call dazim_check(dazim_model_update(dazim_handle, nx, ny, nz, merge(0_c_int, 1_c_int, iso_mod), vsf, dv, Minvel, Maxvel, &
+                                        gcf, gsf, ustats), 'model update')
 
-    ! ---- statistics of the update, inv/Main_Jt.f90:621-666 ------------------------------------------------------------
-    mindVs = minval(dv(1:maxvp)); maxdVs = maxval(dv(1:maxvp)); meadVs = sum(abs(dv(1:maxvp)))/maxvp
+    ! ---- statistics of the update, inv/Main_Jt.f90:621-666 (min, max, sum |.| per block and depth from the device) ----------
+    mindVs = minval(ustats(1, :, 1)); maxdVs = maxval(ustats(2, :, 1)); meadVs = sum(ustats(3, :, 1))/maxvp
     write (6, '(a,3f10.4)') '  min  max and abs mean  dVs (km/s)', mindVs, maxdVs, meadVs
     write (66, '(a,3f10.4)') '  min  max and abs mean  dVs (km/s)', mindVs, maxdVs, meadVs
     if (.not. iso_mod) then
-      minGc = minval(dv(maxvp + 1:2*maxvp))*100; maxGc = maxval(dv(maxvp + 1:2*maxvp))*100
-      meaGc = sum(abs(dv(maxvp + 1:2*maxvp)))/maxvp*100
-      minGs = minval(dv(2*maxvp + 1:3*maxvp))*100; maxGs = maxval(dv(2*maxvp + 1:3*maxvp))*100
-      meaGs = sum(abs(dv(2*maxvp + 1:3*maxvp)))/maxvp*100
+      minGc = minval(ustats(1, :, 2))*100; maxGc = maxval(ustats(2, :, 2))*100; meaGc = sum(ustats(3, :, 2))/maxvp*100
+      minGs = minval(ustats(1, :, 3))*100; maxGs = maxval(ustats(2, :, 3))*100; meaGs = sum(ustats(3, :, 3))/maxvp*100
       write (6, '(a,3f10.4)') '  min  max and abs mean   Gc/L (%) ', minGc, maxGc, meaGc
       write (66, '(a,3f10.4)') '  min  max and abs mean   Gc/L (%) ', minGc, maxGc, meaGc
       write (6, '(a,3f10.4)') '  min  max and abs mean   Gs/L (%) ', minGs, maxGs, meaGs
       write (66, '(a,3f10.4)') '  min  max and abs mean   Gs/L (%) ', minGs, maxGs, meaGs
     end if
     do k = 1, nz - 1
-      VariVs = sum(abs(dv((k - 1)*(nx - 2)*(ny - 2) + 1:k*(nx - 2)*(ny - 2))))/((nx - 2)*(ny - 2))
+      VariVs = ustats(3, k, 1)/((nx - 2)*(ny - 2))
       if (iso_mod) then
         write (66, '(a,f5.1,a,f5.1,a,f10.4)') '  Z ', depz(k), ' - ', depz(k + 1), ' km  abs mean dVs (km/s)', VariVs
         write (6, '(a,f5.1,a,f5.1,a,f10.4)') '  Z ', depz(k), ' - ', depz(k + 1), ' km  abs mean dVs (km/s)', VariVs
       else
-        VariGc = sum(abs(gcf(1:nx - 2, 1:ny - 2, k)))/((nx - 2)*(ny - 2))
-        VariGs = sum(abs(gsf(1:nx - 2, 1:ny - 2, k)))/((nx - 2)*(ny - 2))
+        VariGc = ustats(3, k, 2)/((nx - 2)*(ny - 2))
+        VariGs = ustats(3, k, 3)/((nx - 2)*(ny - 2))
         write (66, '(a, f5.1, a, f5.1, a, 2f10.3, f9.4)') '  Z ', depz(k), ' - ', depz(k + 1), &
           ' km  Abs Mean Gc (%)  Gs (%)   dVs (km/s)', VariGc*100, VariGs*100, VariVs
         write (6, '(a, f5.1, a, f5.1, a, 2f10.3, f9.4)') '  Z ', depz(k), ' - ', depz(k + 1), &
@@ -371,9 +359,11 @@ program DAzimSurfTomo_amd
       end if
     end do
 
+    call tick(7)                             ! update + statistics
     ! ---- model-norm and residual diagnostics (Calmodel2Norm*, Cal*ReslNorm*, inv/CalSigamNorm.f90) -----------------------
     call model_norms()
     call residual_norms()
+    call tick(8)                             ! G*dv diagnostics
     if (iter == 1 .or. iter == maxiter) then            ! inv/Main_Jt.f90:701-718 (id stays '00' in the reference)
       open (88, file='Traveltime_statis_00th.dat')
       if (iso_mod) then
@@ -415,6 +405,7 @@ program DAzimSurfTomo_amd
     write (66, '(a)') ' '
     write (6, '(a)') '  '
     call dazim_check(dazim_csr_free(dazim_handle, G), 'free G')
+    call tick(9)                             ! output files of the iteration
   end do
 
   ! ---- final models, inv/Main_Jt.f90:751-790 ---------------------------------------------------------------------------------
@@ -456,6 +447,9 @@ program DAzimSurfTomo_amd
   write (66, *) '  Program finishes successfully'
   write (*, *) '  Output inverted shear velocity model: Vs_model_Syn.rela  Vs_model_Syn.abs'
   write (66, *) '  Output inverted shear velocity model: Vs_model_Syn.rela  Vs_model_Syn.abs'
+  call tick(9)
+  call get_environment_variable('DAZIM_TIMING', timing_env)
+  if (len_trim(timing_env) > 0) write (0, '(a,9f8.3)') ' phase seconds: read init assemble weights tikhonov lsmr update diag output ', tph
   call system_clock(c1)
   write (*, '(a, f13.1, a)') '   All time cost= ', real(c1 - c0)/real(crate), "s"
   write (66, '(a, f13.1, a)') '   All time cost= ', real(c1 - c0)/real(crate), "s"
@@ -463,6 +457,13 @@ program DAzimSurfTomo_amd
   call dazim_finalize()
 
 contains
+
+  subroutine tick(i)                         ! wall time since the previous tick goes to phase i
+    integer, intent(in) :: i
+    call system_clock(tk1)
+    tph(i) = tph(i) + real(tk1 - tk0, 8)/real(tkrate, 8)
+    tk0 = tk1
+  end subroutine
 
   ! great-circle distance on a 6371 km sphere from colatitude/longitude in radians (haversine, fp32); inv/delsph.f90:1
   subroutine great_circle(colat1, lon1, colat2, lon2, del)
@@ -497,36 +498,6 @@ contains
     end do
     nrm2 = scale*sqrt(ssq)
   end function
-
-  ! sigma_i = std(|res/t_obs|) * t_obs, inflated exponentially beyond 1.5 std; inv/CalSigamNorm.f90:2
-  subroutine data_sigma(nd, tobs, res, sigma, meanrel)
-    integer, intent(in) :: nd
-    real, intent(in) :: tobs(nd), res(nd)
-    real, intent(out) :: sigma(nd), meanrel
-    real, allocatable :: rel(:)
-    real :: stdrel, ratio
-    integer :: id
-    allocate (rel(nd))
-    meanrel = 0
-    do id = 1, nd
-      rel(id) = abs(res(id)/tobs(id))
-      meanrel = meanrel + rel(id)
-    end do
-    meanrel = meanrel/nd
-    stdrel = 0
-    do id = 1, nd
-      stdrel = stdrel + (rel(id) - meanrel)**2
-    end do
-    stdrel = sqrt(stdrel/nd)
-    do id = 1, nd
-      ratio = abs(rel(id)/(1.5*stdrel))
-      if (ratio > 1.0) then
-        sigma(id) = stdrel*tobs(id)*exp(ratio - 1)
-      else
-        sigma(id) = stdrel*tobs(id)
-      end if
-    end do
-  end subroutine
 
   ! first-order Tikhonov rows of one column block: 7-point Laplacian (6,-1 x6) inside, a lone 2 on the faces;
   ! inv/TikhRegul.f90:2 (iso) and :108 (joint: blocks dVs | Gc | Gs).  Appends to rowreg/colreg/rwreg.

@@ -24,11 +24,15 @@ module dazim_mod
   public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
-            dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec
+            dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
+            dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
   logical, save :: dazim_fill_dense = .true.
+  ! device buffers of the eikonal fields, kept between calls of dazim_assemble_G (one per outer iteration, same sizes)
+  type(c_ptr), save :: fld_ptr(5) = c_null_ptr
+  integer(c_size_t), save :: fld_bytes(5) = 0
 
   type, bind(C) :: dazim_refbox
     integer(c_int) :: vnl, vnr, vnt, vnb, nnxr, nnzr, isx, isz
@@ -145,6 +149,26 @@ module dazim_mod
       integer(c_int) :: irow(*), icol(*)
       real(c_float) :: rw(*)
     end function
+    integer(c_int) function dazim_csr_append_tikhonov(ctx, A, nx, ny, nz, nblock, w) bind(C, name="dazim_csr_append_tikhonov")
+      import
+      type(c_ptr), value :: ctx, A
+      integer(c_int), value :: nx, ny, nz, nblock
+      real(c_float) :: w(*)
+    end function
+    integer(c_int) function dazim_weight_data(ctx, G, dall, obst, dsyn, res, datweight, rhs, stats) bind(C, name="dazim_weight_data")
+      import
+      type(c_ptr), value :: ctx, G
+      integer(c_int64_t), value :: dall
+      real(c_float) :: obst(*), dsyn(*), res(*), datweight(*), rhs(*), stats(8)
+    end function
+    integer(c_int) function dazim_model_update(ctx, nx, ny, nz, joint, vs, dv, minvel, maxvel, gc, gs, stats) &
+        bind(C, name="dazim_model_update")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nx, ny, nz, joint
+      real(c_float), value :: minvel, maxvel
+      real(c_float) :: vs(*), dv(*), gc(*), gs(*), stats(*)
+    end function
     integer(c_int) function dazim_aprod(ctx, mode, A, x, y) bind(C, name="dazim_aprod")
       import
       type(c_ptr), value :: ctx, A
@@ -183,6 +207,14 @@ contains
   end subroutine
 
   subroutine dazim_finalize()
+    integer :: q
+    integer(c_int) :: rc
+    if (c_associated(dazim_handle)) then
+      do q = 1, 5
+        if (c_associated(fld_ptr(q))) rc = dazim_free(dazim_handle, fld_ptr(q))
+        fld_ptr(q) = c_null_ptr; fld_bytes(q) = 0
+      end do
+    end if
     if (c_associated(dazim_handle)) call dazim_destroy(dazim_handle)
     dazim_handle = c_null_ptr
   end subroutine
@@ -400,11 +432,11 @@ contains
     nnx = (nx - 3)*5 + 1; nnz = (ny - 3)*5 + 1
     nn = int(nnx, c_size_t)*nnz
     ! eikonal fields stay on the device between the two calls
-    call check(dazim_malloc(dazim_handle, d_veln, nn*kmaxRc*4), 'malloc')
-    call check(dazim_malloc(dazim_handle, d_ttn, nn*nfield*4), 'malloc')
-    call check(dazim_malloc(dazim_handle, d_ttnr, int(129*129, c_size_t)*nfield*4), 'malloc')
-    call check(dazim_malloc(dazim_handle, d_nstsr, int(129*129, c_size_t)*nfield*4), 'malloc')
-    call check(dazim_malloc(dazim_handle, d_box, int(48, c_size_t)*nfield), 'malloc')
+    call field_buffer(1, nn*kmaxRc*4, d_veln)
+    call field_buffer(2, nn*nfield*4, d_ttn)
+    call field_buffer(3, int(129*129, c_size_t)*nfield*4, d_ttnr)
+    call field_buffer(4, int(129*129, c_size_t)*nfield*4, d_nstsr)
+    call field_buffer(5, int(48, c_size_t)*nfield, d_box)
     call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, pv, nfield, scx, scz, per, &
                                d_veln, d_ttn, d_ttnr, d_nstsr, d_box, c_null_ptr), 'CalSurfG/travel')
     if (joint) then
@@ -418,9 +450,20 @@ contains
     end if
     nar = int(nnz64)
     if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
-    call check(dazim_free(dazim_handle, d_veln), 'free'); call check(dazim_free(dazim_handle, d_ttn), 'free')
-    call check(dazim_free(dazim_handle, d_ttnr), 'free'); call check(dazim_free(dazim_handle, d_nstsr), 'free')
-    call check(dazim_free(dazim_handle, d_box), 'free')
+  end subroutine
+
+  ! device buffer q of at least `bytes` bytes, reused from the previous call when it is large enough
+  subroutine field_buffer(q, bytes, p)
+    integer, intent(in) :: q
+    integer(c_size_t), intent(in) :: bytes
+    type(c_ptr), intent(out) :: p
+    if (.not. c_associated(fld_ptr(q)) .or. fld_bytes(q) < bytes) then
+      if (c_associated(fld_ptr(q))) call check(dazim_free(dazim_handle, fld_ptr(q)), 'free')
+      fld_ptr(q) = c_null_ptr
+      call check(dazim_malloc(dazim_handle, fld_ptr(q), max(bytes, 16_c_size_t)), 'malloc')
+      fld_bytes(q) = bytes
+    end if
+    p = fld_ptr(q)
   end subroutine
 
   ! ---- inv/aprod.f90:7 -----------------------------------------------------------------------------

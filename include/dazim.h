@@ -191,6 +191,24 @@ int dazim_rays_build_G_joint(dazim_ctx *ctx, int nx, int ny, int nz, float goxd,
                              const double *sen_vp, const double *sen_rho, const float *Lsen_Gsc,
                              float *tpred, dazim_csr **G, int64_t *nnz, int *n_boundary);
 
+/* ---- N4: what surrounds the solve in the outer iteration, on the device ------------------------------
+ * = TikhonovRegularization / TikhRegul_joint (inv/TikhRegul.f90:2-104, :107-209): appends nblock * maxvp rows, maxvp =
+ *   (nx-2)(ny-2)(nz-1); block b regularises columns b*maxvp+1 .. (b+1)*maxvp with weight w[b] (host array): a cell on a face
+ *   of the block gets the single entry 2w, an inner cell the 7-point Laplacian 6w, -w x 6.  Rows in the reference's k, j, i order. */
+int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int nz, int nblock, const float *w);
+/* = residual cbst = obst - dsyn, CalDdatSigma (inv/CalSigamNorm.f90:2-41), datweight = 1/sigmaT, cbst *= datweight and
+ *   rw(i) = rw(i)*datweight(iw(1+i)) on the first dall rows of G (inv/Main_Jt.f90:432-469).  obst, dsyn [dall] in; res
+ *   (the reference's Tdata), datweight, rhs [dall] out; host or device arrays; G nullable.  stats (host, 8 floats, nullable):
+ *   mean, std, mean |.|, rms of res; meandeltaT, stddeltaT; mean datweight; mean |rhs|.  The two sums of CalDdatSigma run in
+ *   the reference's sequential fp32 order, so the weights are the reference's bit for bit.                              */
+int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *obst, const float *dsyn, float *res,
+                      float *datweight, float *rhs, float *stats);
+/* = the clamped model update (inv/Main_Jt.f90:582-620): dv [maxvp, or 3*maxvp when joint] in/out (dVs clamped to +-0.5, zeroed
+ *   below 1e-5), vs [nz][ny][nx] in/out (inner cells += dVs, clamped to [minvel, maxvel]), gc, gs [nz-1][ny-2][nx-2] out
+ *   (joint; nullable).  stats (host, nullable): [nblock][nz-1][3] = min, max, sum |.| of the update per block and depth.   */
+int dazim_model_update(dazim_ctx *ctx, int nx, int ny, int nz, int joint, float *vs, float *dv, float minvel, float maxvel,
+                       float *gc, float *gs, float *stats);
+
 /* = aprod (inv/aprod.f90:7): mode 1: y(m) += A*x(n) ; mode 2: x(n) += A^T*y(m)                    */
 int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y);
 
