@@ -363,17 +363,30 @@ def main():
 
     stats = {}
 
+    wall = {}
+    tw = [time.perf_counter()]
+
+    def lap(name):          # host wall time per call of the step (DAZIM_BENCH_WALL=1 prints it to stderr)
+        now = time.perf_counter()
+        wall[name] = wall.get(name, 0.0) + now - tw[0]
+        tw[0] = now
+
     def step():
+        tw[0] = time.perf_counter()
         pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
+        lap("depthkernel")
         stats["disp_s"] = ctx.kernel_seconds("disp")
         fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, d_pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
+        lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, d_sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
+        lap("rays_build_G")
         stats["nnz_data"] = G.nnz
         G.append_coo(c3, t_ir, t_ic, t_rw)
+        lap("append")
         stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
         if not use_dist or native:
             x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
@@ -389,7 +402,9 @@ def main():
         stats["spmv_kind"], stats["spmvt_kind"] = ctx.kernel_seconds("spmv.kind"), ctx.kernel_seconds("spmvt.kind")
         stats["lsmr_itn"] = info["itn"]
         stats["nfail"] = nfail
+        lap("lsmr")
         G.free()
+        lap("free")
 
     def barrier():
         if use_dist:
@@ -409,6 +424,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if rank == 0 and os.environ.get("DAZIM_BENCH_WALL") == "1":
+        print("host wall ms per step:", {k: round(v / (a.steps + a.warmup) * 1e3, 2) for k, v in wall.items()}, file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
         total_fields = nfield * world

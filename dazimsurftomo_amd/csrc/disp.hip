@@ -38,6 +38,13 @@ struct DispArgs {
   const Layer *lay;  // [mmax]
   const double *t;   // [kmax]
   float *cg;         // [ncol*nvar][kmax]
+  // task queue (see disp_kernel): groups of DT work items x chunks of `pchunk` consecutive periods
+  int ngroup, nchunk, pchunk;
+  unsigned *counter;   // next task
+  int *ready;          // [nchunk][ngroup]: chunk c of group g is finished
+  double *st_c;        // [ncol*nvar] root of the last finished period (c1 at :297), carried to the next chunk
+  double *st_d;        // [ncol*nvar] del1st (the SAVEd first secular value of getsol, :409,424)
+  int *st_f;           // [ncol*nvar] 1: the search failed, the remaining periods are 0 (:342-348)
 };
 
 __device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
@@ -187,6 +194,12 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
     const double rrho1 = frcp(rho1), rrho2 = rrho1 * rrho1;
     const double p = ra * dpth, q = rb * dpth;
     double w, x, y, z, cosp, cosq, sinp, sinq, fac, pex = 0.0, sex = 0.0;
+    // The three exponentials of a layer, exp(-2p), exp(-2q) and exp(-(pex+sex)) (:893,:927,:951), come from two: ep = exp(-pex),
+    // eq = exp(-sex) (1 for an oscillatory part), then ep*ep, eq*eq and ep*eq -- fp64 rounding noise inside the secular
+    // function, like the reciprocals above.
+    if (wvno > xka) pex = p;
+    if (wvno > xkb) sex = q;
+    const double ep = pex > 0.0 ? exp(-pex) : 1.0, eq = sex > 0.0 ? exp(-sex) : 1.0;
     if (wvno < xka) {
       sincos(p, &sinp, &cosp);   // one argument reduction for both
       w = sinp * rra;
@@ -196,9 +209,8 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
       w = dpth;
       x = 0.0;
     } else {
-      pex = p;
       fac = 0.0;
-      if (p < 16) fac = exp(-2.0 * p);
+      if (p < 16) fac = ep * ep;
       cosp = (1.0 + fac) * 0.5;
       sinp = (1.0 - fac) * 0.5;
       w = sinp * rra;
@@ -213,9 +225,8 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
       y = dpth;
       z = 0.0;
     } else {
-      sex = q;
       fac = 0.0;
-      if (q < 16) fac = exp(-2.0 * q);
+      if (q < 16) fac = eq * eq;
       cosq = (1.0 + fac) * 0.5;
       sinq = (1.0 - fac) * 0.5;
       y = sinq * rrb;
@@ -223,7 +234,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
     }
     const double exa = pex + sex;
     double a0 = 0.0;
-    if (exa < 60.0) a0 = exp(-exa);
+    if (exa < 60.0) a0 = ep * eq;
     const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
     const double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
     const double gamm1 = gam - 1.0;
@@ -300,241 +311,294 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
 
 enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
 
+// Scheduling.  A work item's periods chain (the root of period k seeds the search of period k+1, :262-266), so an item is a
+// long serial job: ~15 secular evaluations x layers x periods, and a launch whose workgroups do not fill a whole number of
+// rounds pays one item's latency for the stragglers (S-256: 832 workgroups on 768 slots: 56 ms for the first round + 16 ms for
+// the 64 left over).  Persistent workgroups pull tasks = (group of DT items, chunk of `pchunk` consecutive periods) from an
+// atomic counter, chunk-major; the state an item carries from one chunk to the next is two doubles (the last root and del1st)
+// and a fail flag in HBM, and task (g, c) waits for (g, c-1), which was handed out a whole generation earlier (no deadlock:
+// tasks only wait for earlier tasks).  Measured on S-256 (tools/disp_only.py): chunks of 2 / 4 / 8 periods 67.1 / 69.0 / 72.6 ms
+// against 69.0 ms unchunked -- the lanes of a wavefront run their periods independently and only meet at the end of a task,
+// so every chunk boundary adds the wait for the slowest lane (+15 % at one round's worth of work) and eats what the shorter
+// tail saves.  The default is therefore one chunk (pchunk = kmax); option "disp.pchunk" selects shorter ones (bit-identical
+// results: tests/test_disp_gpu.py).
 template <int RDEN>
 __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
   extern __shared__ __attribute__((aligned(16))) float s_knot[];  // [cpb][3][nz]
   __shared__ double s_x[NEVN][DT], s_y[NEVN][DT];
+  __shared__ unsigned s_task;
   const int tid = threadIdx.x;
   const int nz = A.nz, kmax = A.kmax, mmax = A.mmax, nvar = A.nvar;
-  const long w0 = (long)blockIdx.x * DT;
   const long nwork = (long)A.ncol * nvar;
-  const int col0 = (int)(w0 / nvar);
   for (int i = tid; i < mmax; i += DT) s_lay[i] = A.lay[i];
   for (int i = tid; i < kmax; i += DT) s_t[i] = A.t[i];
-  const int cpb = (DT + nvar - 1) / nvar + 1;  // columns this workgroup's work items may span
-  for (int i = tid; i < cpb * nz; i += DT) {
-    const int c = i / nz, k = i - c * nz, col = col0 + c;
-    if (col < A.ncol) {
-      const float vs = A.vel[(size_t)k * A.ncol + col];
-      float vp, rho;
-      brocher(vs, vp, rho);
-      s_knot[(c * 3 + 0) * nz + k] = vs;
-      s_knot[(c * 3 + 1) * nz + k] = vp;
-      s_knot[(c * 3 + 2) * nz + k] = rho;
-    }
-  }
-  __syncthreads();
-  const long w = w0 + tid;
-  const bool active = w < nwork;
-  const int col = active ? (int)(w / nvar) : col0;
-  const int var = active ? (int)(w - (long)col * nvar) : 0;
-  Knots K;
-  K.vs = s_knot + ((col - col0) * 3 + 0) * nz;
-  K.vp = s_knot + ((col - col0) * 3 + 1) * nz;
-  K.rho = s_knot + ((col - col0) * 3 + 2) * nz;
-  K.pi = 0;
-  K.pq = -1;
-  K.pv = 0.0f;
-  if (var > 0) {  // depthkernel's perturbation order: knot i, then (vs,vp,rho), then (-,+)  (:76-124)
-    const int v1 = var - 1;
-    K.pi = v1 / 6 + 1;
-    const int r = v1 - (K.pi - 1) * 6;
-    K.pq = r >> 1;
-    const float b0 = (K.pq == 0 ? K.vs : (K.pq == 1 ? K.vp : K.rho))[K.pi - 1];
-    const float dln = 0.01f;
-    K.pv = (r & 1) ? b0 + 0.5f * dln * b0 : b0 - 0.5f * dln * b0;
-  }
-  bool fast = false;
-  if (RDEN == 2) {   // every knot difference the interpolation will see is 0 or inside the range the shortcut was verified on
-    bool ok = true;
-    for (int i = 1; i < nz; i++)
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const float ad = fabsf(K.get(q, i + 1) - K.get(q, i));
-        ok = ok && (ad == 0.0f || (ad >= 1.0e-30f && ad <= 1.0e28f));
+  const int cpb = (DT + nvar - 1) / nvar + 1;  // columns the work items of one group may span
+  const unsigned ntask = (unsigned)A.ngroup * (unsigned)A.nchunk;
+  for (;;) {
+    __syncthreads();   // (the previous task's LDS reads are over)
+    if (tid == 0) {
+      const unsigned t = atomicAdd(A.counter, 1u);
+      s_task = t;
+      if (t < ntask && t >= (unsigned)A.ngroup) {   // chunk c > 0: its predecessor (same group, chunk c-1) must have published its state
+        const int *flag = A.ready + (t - (unsigned)A.ngroup);
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(20);
       }
-    fast = __all(ok);
-  }
-  // ---- start-up of surfdisp96 (:134-216): extremal velocities, half-space start value ----
-  float betmx = -1.e20f, betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
-  int jsol = 1;
-  for (int m = 1; m <= mmax; m++) {
-    float fa, fb, fr, fd;
-    layer_model<RDEN>(K, s_lay, m, nz, fast, fa, fb, fr, fd);
-    if (fb > 0.01f && fb < betmn) {
-      betmn = fb;
-      a_mn = fa;
-      b_mn = fb;
-      jsol = 1;
-    } else if (fb <= 0.01f && fa < betmn) {
-      betmn = fa;
-      a_mn = fa;
-      b_mn = fb;
-      jsol = 0;
     }
-    if (fb > betmx) betmx = fb;
-  }
-  const float ddc = 0.005f, sone = 1.5f;
-  const double onea = (double)sone, TWOPI = 2.0 * 3.141592653589793;
-  float cc1 = jsol == 0 ? betmn : gtsolh(a_mn, b_mn);
-  cc1 = .95f * cc1;
-  cc1 = .90f * cc1;
-  const double cc = (double)cc1, dc = fabs((double)ddc), cm = cc;
-  float *cg = A.cg + (size_t)(active ? w : 0) * kmax;
+    __syncthreads();
+    const unsigned task = s_task;
+    if (task >= ntask) break;
+    __threadfence();   // acquire side for the lanes that did not spin: the state written by another workgroup is visible
+    const int chunk = (int)(task / (unsigned)A.ngroup), grp = (int)(task - (unsigned)chunk * (unsigned)A.ngroup);
+    const int kbeg = chunk * A.pchunk, kend = min(kbeg + A.pchunk, kmax);
+    const long w0 = (long)grp * DT;
+    const int col0 = (int)(w0 / nvar);
+    for (int i = tid; i < cpb * nz; i += DT) {
+      const int c = i / nz, k = i - c * nz, col = col0 + c;
+      if (col < A.ncol) {
+        const float vs = A.vel[(size_t)k * A.ncol + col];
+        float vp, rho;
+        brocher(vs, vp, rho);
+        s_knot[(c * 3 + 0) * nz + k] = vs;
+        s_knot[(c * 3 + 1) * nz + k] = vp;
+        s_knot[(c * 3 + 2) * nz + k] = rho;
+      }
+    }
+    __syncthreads();
+    const long w = w0 + tid;
+    const bool active = w < nwork;
+    const int col = active ? (int)(w / nvar) : col0;
+    const int var = active ? (int)(w - (long)col * nvar) : 0;
+    Knots K;
+    K.vs = s_knot + ((col - col0) * 3 + 0) * nz;
+    K.vp = s_knot + ((col - col0) * 3 + 1) * nz;
+    K.rho = s_knot + ((col - col0) * 3 + 2) * nz;
+    K.pi = 0;
+    K.pq = -1;
+    K.pv = 0.0f;
+    if (var > 0) {  // depthkernel's perturbation order: knot i, then (vs,vp,rho), then (-,+)  (:76-124)
+      const int v1 = var - 1;
+      K.pi = v1 / 6 + 1;
+      const int r = v1 - (K.pi - 1) * 6;
+      K.pq = r >> 1;
+      const float b0 = (K.pq == 0 ? K.vs : (K.pq == 1 ? K.vp : K.rho))[K.pi - 1];
+      const float dln = 0.01f;
+      K.pv = (r & 1) ? b0 + 0.5f * dln * b0 : b0 - 0.5f * dln * b0;
+    }
+    bool fast = false;
+    if (RDEN == 2) {   // every knot difference the interpolation will see is 0 or inside the range the shortcut was verified on
+      bool ok = true;
+      for (int i = 1; i < nz; i++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const float ad = fabsf(K.get(q, i + 1) - K.get(q, i));
+          ok = ok && (ad == 0.0f || (ad >= 1.0e-30f && ad <= 1.0e28f));
+        }
+      fast = __all(ok);
+    }
+    // ---- start-up of surfdisp96 (:134-216): extremal velocities, half-space start value (recomputed per chunk: one pass
+    // over the layers, the cost of a fraction of one secular evaluation) ----
+    float betmx = -1.e20f, betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
+    int jsol = 1;
+    for (int m = 1; m <= mmax; m++) {
+      float fa, fb, fr, fd;
+      layer_model<RDEN>(K, s_lay, m, nz, fast, fa, fb, fr, fd);
+      if (fb > 0.01f && fb < betmn) {
+        betmn = fb;
+        a_mn = fa;
+        b_mn = fb;
+        jsol = 1;
+      } else if (fb <= 0.01f && fa < betmn) {
+        betmn = fa;
+        a_mn = fa;
+        b_mn = fb;
+        jsol = 0;
+      }
+      if (fb > betmx) betmx = fb;
+    }
+    const float ddc = 0.005f, sone = 1.5f;
+    const double onea = (double)sone, TWOPI = 2.0 * 3.141592653589793;
+    float cc1 = jsol == 0 ? betmn : gtsolh(a_mn, b_mn);
+    cc1 = .95f * cc1;
+    cc1 = .90f * cc1;
+    const double cc = (double)cc1, dc = fabs((double)ddc), cm = cc;
+    const size_t wi = (size_t)(active ? w : 0);
+    float *cg = A.cg + wi * kmax;
 
-  // ---- per-lane root-search state (getsol :384-476, nevill :551-668) ----
-  int k = 0, phase = active ? P_G1 : P_DONE, ifirst = 1, idir = 1, nev = 1, nctrl = 1, mm = 1;
-  double c1 = cc, c2 = cc, del1 = 0, del2 = 0, del1st = 0, clow = cc, c3 = cc, del3 = 0, cprev = cc;
-  double omega = TWOPI / s_t[0];
-  double ceval = c1;
+    // ---- per-lane root-search state (getsol :384-476, nevill :551-668) ----
+    int k = kbeg, phase = active ? P_G1 : P_DONE, ifirst = 1, idir = 1, nev = 1, nctrl = 1, mm = 1;
+    double c1 = cc, c2 = cc, del1 = 0, del2 = 0, del1st = 0, clow = cc, c3 = cc, del3 = 0, cprev = cc;
+    if (chunk > 0 && active) {   // resume where the previous chunk stopped: the "next period" step of :262-266
+      if (A.st_f[wi]) {
+        phase = P_DONE;          // the search failed earlier: the remaining periods are already 0
+      } else {
+        cprev = A.st_c[wi];
+        del1st = A.st_d[wi];
+        ifirst = 0;
+        c1 = cprev - onea * dc;
+        clow = cm;
+      }
+    }
+    double omega = TWOPI / s_t[kbeg];
+    double ceval = c1;
+    bool failed = false;
 
-  while (__any(phase != P_DONE)) {
-    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega);
-    if (phase == P_DONE) continue;
-    bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
-    switch (phase) {
-      case P_G1:
-        del1 = del;
-        if (ifirst == 1) del1st = del1;
-        idir = (ifirst == 1) ? 1 : (sgn(del1st) * sgn(del1) >= 0.0 ? 1 : -1);
-        advance_bracket = true;
-        break;
-      case P_G2:
-        del2 = del;
-        if (sgn(del1) != sgn(del2)) {  // root bracketed -> nevill: first half()
+    while (__any(phase != P_DONE)) {
+      const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega);
+      if (phase == P_DONE) continue;
+      bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
+      switch (phase) {
+        case P_G1:
+          del1 = del;
+          if (ifirst == 1) del1st = del1;
+          idir = (ifirst == 1) ? 1 : (sgn(del1st) * sgn(del1) >= 0.0 ? 1 : -1);
+          advance_bracket = true;
+          break;
+        case P_G2:
+          del2 = del;
+          if (sgn(del1) != sgn(del2)) {  // root bracketed -> nevill: first half()
+            c3 = 0.5 * (c1 + c2);
+            ceval = c3;
+            phase = P_N0;
+            nev = 1;
+            nctrl = 1;
+            mm = 1;
+          } else {
+            c1 = c2;
+            del1 = del2;
+            if (c1 < cm || c1 >= ((double)betmx + dc))
+              fail = true;
+            else
+              advance_bracket = true;
+          }
+          break;
+        case P_N0:
+        case P_NB:
+          del3 = del;
+          nev_top = true;
+          break;
+        case P_NA:
+          del3 = del;
+          nev_body = true;
+          break;
+      }
+      if (advance_bracket) {
+        for (;;) {
+          c2 = (idir > 0) ? c1 + dc : c1 - dc;
+          if (c2 <= clow) {
+            idir = 1;
+            c1 = clow;
+            continue;
+          }
+          break;
+        }
+        ceval = c2;
+        phase = P_G2;
+      }
+      if (nev_top) {
+        nctrl++;
+        if (nctrl >= 100)
+          finish = true;
+        else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {
+          nev = 0;
           c3 = 0.5 * (c1 + c2);
           ceval = c3;
-          phase = P_N0;
-          nev = 1;
-          nctrl = 1;
-          mm = 1;
-        } else {
-          c1 = c2;
-          del1 = del2;
-          if (c1 < cm || c1 >= ((double)betmx + dc))
-            fail = true;
-          else
-            advance_bracket = true;
-        }
-        break;
-      case P_N0:
-      case P_NB:
-        del3 = del;
-        nev_top = true;
-        break;
-      case P_NA:
-        del3 = del;
-        nev_body = true;
-        break;
-    }
-    if (advance_bracket) {
-      for (;;) {
-        c2 = (idir > 0) ? c1 + dc : c1 - dc;
-        if (c2 <= clow) {
-          idir = 1;
-          c1 = clow;
-          continue;
-        }
-        break;
+          phase = P_NA;
+        } else
+          nev_body = true;
       }
-      ceval = c2;
-      phase = P_G2;
-    }
-    if (nev_top) {
-      nctrl++;
-      if (nctrl >= 100)
-        finish = true;
-      else if (c3 < fmin(c1, c2) || c3 > fmax(c1, c2)) {
-        nev = 0;
-        c3 = 0.5 * (c1 + c2);
-        ceval = c3;
-        phase = P_NA;
-      } else
-        nev_body = true;
-    }
-    if (nev_body) {
-      const double s13 = del1 - del3, s32 = del3 - del2;
-      if (sgn(del3) * sgn(del1) < 0.0) {
-        c2 = c3;
-        del2 = del3;
-      } else {
-        c1 = c3;
-        del1 = del3;
-      }
-      if (fabs(c1 - c2) <= 1.e-6 * c1)
-        finish = true;
-      else {
-        if (sgn(s13) != sgn(s32)) nev = 0;
-        const double ss1 = fabs(del1), s1 = (double)0.01f * ss1;
-        const double ss2 = fabs(del2), s2 = (double)0.01f * ss2;
-        if (s1 > ss2 || s2 > ss1 || nev == 0) {
-          c3 = 0.5 * (c1 + c2);
-          nev = 1;
-          mm = 1;
+      if (nev_body) {
+        const double s13 = del1 - del3, s32 = del3 - del2;
+        if (sgn(del3) * sgn(del1) < 0.0) {
+          c2 = c3;
+          del2 = del3;
         } else {
-          if (nev == 2) {
-            s_x[mm][tid] = c3;
-            s_y[mm][tid] = del3;
-          } else {
-            s_x[0][tid] = c1;
-            s_y[0][tid] = del1;
-            s_x[1][tid] = c2;
-            s_y[1][tid] = del2;
-            mm = 1;
-          }
-          bool bad = false;
-          const double ym = s_y[mm][tid];
-          for (int kk = 1; kk <= mm; kk++) {
-            const int j = mm - kk + 1;
-            const double yj = s_y[j - 1][tid];
-            const double denom = ym - yj;
-            if (fabs(denom) < 1.0e-10 * fabs(ym)) {
-              bad = true;
-              break;
-            }
-            s_x[j - 1][tid] = (-yj * s_x[j][tid] + ym * s_x[j - 1][tid]) / denom;
-          }
-          if (!bad) {
-            c3 = s_x[0][tid];
-            nev = 2;
-            mm = mm + 1;
-            if (mm > 10) mm = 10;
-          } else {
+          c1 = c3;
+          del1 = del3;
+        }
+        if (fabs(c1 - c2) <= 1.e-6 * c1)
+          finish = true;
+        else {
+          if (sgn(s13) != sgn(s32)) nev = 0;
+          const double ss1 = fabs(del1), s1 = (double)0.01f * ss1;
+          const double ss2 = fabs(del2), s2 = (double)0.01f * ss2;
+          if (s1 > ss2 || s2 > ss1 || nev == 0) {
             c3 = 0.5 * (c1 + c2);
             nev = 1;
             mm = 1;
+          } else {
+            if (nev == 2) {
+              s_x[mm][tid] = c3;
+              s_y[mm][tid] = del3;
+            } else {
+              s_x[0][tid] = c1;
+              s_y[0][tid] = del1;
+              s_x[1][tid] = c2;
+              s_y[1][tid] = del2;
+              mm = 1;
+            }
+            bool bad = false;
+            const double ym = s_y[mm][tid];
+            for (int kk = 1; kk <= mm; kk++) {
+              const int j = mm - kk + 1;
+              const double yj = s_y[j - 1][tid];
+              const double denom = ym - yj;
+              if (fabs(denom) < 1.0e-10 * fabs(ym)) {
+                bad = true;
+                break;
+              }
+              s_x[j - 1][tid] = (-yj * s_x[j][tid] + ym * s_x[j - 1][tid]) / denom;
+            }
+            if (!bad) {
+              c3 = s_x[0][tid];
+              nev = 2;
+              mm = mm + 1;
+              if (mm > 10) mm = 10;
+            } else {
+              c3 = 0.5 * (c1 + c2);
+              nev = 1;
+              mm = 1;
+            }
+          }
+          ceval = c3;
+          phase = P_NB;
+        }
+      }
+      if (finish) {
+        c1 = c3;
+        if (c1 > (double)betmx)
+          fail = true;
+        else {
+          cg[k] = (float)c1;  // cg(k) = sngl(c(k)), :292-297
+          cprev = c1;
+          k++;
+          if (k == kend)
+            phase = P_DONE;   // chunk finished (k == kmax: the item is finished)
+          else {  // next period, :262-266
+            ifirst = 0;
+            c1 = cprev - onea * dc;
+            clow = cm;
+            omega = TWOPI / s_t[k];
+            ceval = c1;
+            phase = P_G1;
           }
         }
-        ceval = c3;
-        phase = P_NB;
+      }
+      if (fail) {  // :1750-1770
+        for (int i = k; i < kmax; i++) cg[i] = 0.0f;
+        failed = true;
+        phase = P_DONE;
       }
     }
-    if (finish) {
-      c1 = c3;
-      if (c1 > (double)betmx)
-        fail = true;
-      else {
-        cg[k] = (float)c1;  // cg(k) = sngl(c(k)), :292-297
-        cprev = c1;
-        k++;
-        if (k == kmax)
-          phase = P_DONE;
-        else {  // next period, :262-266
-          ifirst = 0;
-          c1 = cprev - onea * dc;
-          clow = cm;
-          omega = TWOPI / s_t[k];
-          ceval = c1;
-          phase = P_G1;
-        }
-      }
+    if (active && kend < kmax && !(chunk > 0 && A.st_f[wi])) {   // hand the chain to the next chunk
+      A.st_c[wi] = cprev;
+      A.st_d[wi] = del1st;
+      A.st_f[wi] = failed ? 1 : 0;
     }
-    if (fail) {  // :1750-1770
-      for (int i = k; i < kmax; i++) cg[i] = 0.0f;
-      phase = P_DONE;
-    }
+    __threadfence();   // release: the state above before the flag below
+    __syncthreads();
+    if (tid == 0 && kend < kmax) __hip_atomic_store(A.ready + task, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -667,14 +731,36 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   {
-    DzTimer t(ctx, "disp");
     const long nwork = (long)ncol * nvar;
+    // task queue: groups of DT items x chunks of pchunk periods (see disp_kernel); persistent workgroups, as many as are resident
+    A.ngroup = (int)((nwork + DT - 1) / DT);
+    A.pchunk = kmax;
+    if (ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0) A.pchunk = ctx->opts["disp.pchunk"];
+    if (A.pchunk > kmax) A.pchunk = kmax;
+    A.nchunk = (kmax + A.pchunk - 1) / A.pchunk;
+    const size_t ntask = (size_t)A.ngroup * A.nchunk;
+    if ((rc = dz_scratch(ctx, "disp.ready", ntask * 4 + 64, &p))) return rc;
+    A.ready = (int *)p;
+    A.counter = (unsigned *)((char *)p + ntask * 4 + 16 - (ntask * 4) % 16);
+    DZ_HIP(hipMemsetAsync(p, 0, ntask * 4 + 64, ctx->stream));
+    if ((rc = dz_scratch(ctx, "disp.st_c", (size_t)nwork * 8, &p))) return rc;
+    A.st_c = (double *)p;
+    if ((rc = dz_scratch(ctx, "disp.st_d", (size_t)nwork * 8, &p))) return rc;
+    A.st_d = (double *)p;
+    if ((rc = dz_scratch(ctx, "disp.st_f", (size_t)nwork * 4, &p))) return rc;
+    A.st_f = (int *)p;
+    const void *kf = rden == 1 ? (const void *)disp_kernel<1> : (rden == 2 ? (const void *)disp_kernel<2> : (const void *)disp_kernel<0>);
+    int occ = 3;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, DT, dyn_lds) != hipSuccess || occ < 1) occ = 1;
+    long nwg = (long)ctx->num_cu * occ;
+    if (nwg > (long)ntask) nwg = (long)ntask;
+    DzTimer t(ctx, "disp");
     if (rden == 1)
-      hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+      hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
     else if (rden == 2)
-      hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+      hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
     else
-      hipLaunchKernelGGL(disp_kernel<0>, dim3((unsigned)((nwork + DT - 1) / DT)), dim3(DT), dyn_lds, ctx->stream, A);
+      hipLaunchKernelGGL(disp_kernel<0>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     const long nf = (long)ncol * kmax;
     hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,

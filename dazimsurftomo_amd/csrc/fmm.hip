@@ -124,6 +124,18 @@ constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 // LDS layout is structure-of-arrays: fp32 keys + node ids.  NT = unsigned short packs the node as
 // (ix-1)<<8 | (iz-1), possible when both grid sides are <= 256 (the S-256 case: 6 bytes per entry,
 // a third more fields in flight per CU); NT = int keeps (ix<<16)|iz for larger grids.
+// Node records live in HBM in 4 x 4 tiles of 8-byte records (one 128-byte line per tile): node (ix0, iz0), 0-based, of a grid
+// with ntz = ceil(nz/4) tiles per column of tiles is record ((ix0>>2)*ntz + (iz0>>2))*16 + (ix0&3)*4 + (iz0&3).  The stencil
+// of a pop reaches +-3 nodes in both directions: in the reference's column-major order that is 7 columns = 7-8 lines, tiled it
+// is 4-6 (measured below).  The two coordinates contribute separately, so the five addresses of a lane cost three X and three
+// Z parts.  tzs = ntz*16 is the record stride between columns of tiles.
+__device__ __forceinline__ int tile_x(int x0, int tzs) { return __mul24(x0 >> 2, tzs) + ((x0 & 3) << 2); }
+__device__ __forceinline__ int tile_z(int z0) { return ((z0 & ~3) << 2) | (z0 & 3); }
+__host__ __device__ constexpr int tile_stride(int nz) { return ((nz + 3) >> 2) * 16; }
+__host__ __device__ constexpr int tile_records(int nx, int nz) { return ((nx + 3) >> 2) * tile_stride(nz); }
+constexpr int TZS_R = tile_stride(DAZIM_RMAX);                      // refined grid: 33 tiles per column of tiles
+constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 17 424 records per refined field
+
 template <class NT> struct NodeCodec;
 template <> struct NodeCodec<unsigned short> {
   __device__ __forceinline__ static unsigned short enc(int node) { return (unsigned short)((((node >> 16) - 1) << 8) | ((node & 0xffff) - 1)); }
@@ -139,13 +151,12 @@ struct Heap {
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
-  Node *rec;   // node records of the grid being marched
-  int ld;
+  Node *rec;   // node records of the grid being marched (4 x 4 tiles)
+  int tzs;     // record stride between columns of tiles of that grid
   int ntr;
   bool g0;     // lane 0 of the group
 
-  // operands < 2^15: v_mad_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
-  __device__ __forceinline__ int idx(int node) const { return __mul24((node >> 16) - 1, ld) + ((node & 0xffff) - 1); }
+  __device__ __forceinline__ int idx(int node) const { return tile_x((node >> 16) - 1, tzs) + tile_z((node & 0xffff) - 1); }
   // SPILL=false: the whole band lives in LDS (no VMEM load inside the sift loops, so the back-pointer
   // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
@@ -314,7 +325,7 @@ struct Heap {
   // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
   // where a pending neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
   static constexpr int NSTEP = 4;   // 3 levels each: reaches slot 4095
-  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int *nbq, int (&cnode)[NSTEP],
+  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NSTEP],
                                                int (&cslot)[NSTEP], int &fin_node, int &fin_slot) {
     static_assert(CAP <= 4096, "pop_root_par covers 12 levels");
     const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
@@ -479,16 +490,16 @@ __device__ unsigned long long g_fmm_prof[8];
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
 template <int CAP, bool SPILL, class NT, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow,
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow, int lld,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
-                                      int ex, int lane, int *nbq) {
+                                      int ex, int lane) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
   const int nb = gl >> 2, q = gl & 3;
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
   Node *rec = H.rec;
-  const int ld = H.ld;
+  const int tzs = H.tzs;
   bool overflow = false;
   PROF_DECL;
   while (H.ntr > 0 && !overflow) {
@@ -503,11 +514,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) rec[__mul24(ix - 1, ld) + (iz - 1)].s = 0;
+        if (H.g0) rec[tile_x(ix - 1, tzs) + tile_z(iz - 1)].s = 0;
         break;
       }
     }
-    if (H.g0) rec[__mul24(ix - 1, ld) + (iz - 1)].s = 0;
+    const int iroot = tile_x(ix - 1, tzs) + tile_z(iz - 1);
+    if (H.g0) rec[iroot].s = 0;
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
@@ -517,16 +529,17 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     const int j = nix + jd, j2 = nix + 2 * jd, k = niz + kd, k2 = niz + 2 * kd;
     const bool vj = nvalid && j >= 1 && j <= nnx, vj2 = vj && j2 >= 1 && j2 <= nnx;
     const bool vk = nvalid && k >= 1 && k <= nnz, vk2 = vk && k2 >= 1 && k2 <= nnz;
-    const int iroot = __mul24(ix - 1, ld) + (iz - 1);
-    // record indices by offsets from the neighbour's own record (one multiply for all seven loads)
-    const int iself = iroot + __mul24(dix, ld) + diz;
-    const int sj = jd > 0 ? ld : -ld;
-    Node nself = rec[nvalid ? iself : iroot];
-    Node nj = rec[vj ? iself + sj : iroot];
-    Node nj2 = rec[vj2 ? iself + 2 * sj : iroot];
-    Node nk = rec[vk ? iself + kd : iroot];
-    Node nk2 = rec[vk2 ? iself + 2 * kd : iroot];
-    const float vel = slow[nvalid ? iself : iroot];   // slowness of the neighbour (1/velocity, precomputed)
+    // tiled record indices: an X part per column (neighbour, +-1, +-2) and a Z part per row; out-of-grid coordinates give
+    // garbage that the validity flags replace by the root's own record
+    const int xn = tile_x(nix - 1, tzs), xj = tile_x(j - 1, tzs), xj2 = tile_x(j2 - 1, tzs);
+    const int zn = tile_z(niz - 1), zk = tile_z(k - 1), zk2 = tile_z(k2 - 1);
+    Node nself = rec[nvalid ? xn + zn : iroot];
+    Node nj = rec[vj ? xj + zn : iroot];
+    Node nj2 = rec[vj2 ? xj2 + zn : iroot];
+    Node nk = rec[vk ? xn + zk : iroot];
+    Node nk2 = rec[vk2 ? xn + zk2 : iroot];
+    // slowness of the neighbour (1/velocity, precomputed; the shared velocity grids keep the reference's column-major order)
+    const float vel = slow[nvalid ? __mul24(nix - 1, lld) + (niz - 1) : __mul24(ix - 1, lld) + (iz - 1)];
     const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
@@ -543,7 +556,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     if (SPILL) {
       H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
     } else {
-      H.pop_root_par(lane, nbn, nbq, cnode, cslot, fin_node, fin_slot);
+      H.pop_root_par(lane, nbn, cnode, cslot, fin_node, fin_slot);
       cbar();
     }
     PROF(1);
@@ -690,14 +703,14 @@ template <int CAP, bool SPILL, class NT>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
-  __shared__ __attribute__((aligned(16))) int s_nbq[FPW][8];   // [4..7]: write-only spare  // new slots of pending neighbours moved by a sift-down
   __shared__ unsigned s_base;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
+  const int tzs_c = tile_stride(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
-  Node *rec_c = A.rec_c + slot * nn;
-  Node *rec_r = A.rec_r + slot * RM * RM;
+  Node *rec_c = A.rec_c + slot * nrec_c;
+  Node *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * RM * RM;
   Heap<CAP, SPILL, NT> H;
@@ -791,14 +804,14 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             const float vr = sum[0] + sum[1] + sum[2] + sum[3];
             velnr[idx] = vr;
             slownr[idx] = 1.0f / vr;
-            rec_r[idx] = Node{0.0f, -1};
+            rec_r[tile_x(idm2 - 1, TZS_R) + tile_z(idm1 - 1)] = Node{0.0f, -1};
           }
         }
         cbar();
         // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 ----
         H.ntr = 0;
         H.rec = rec_r;
-        H.ld = RM;
+        H.tzs = TZS_R;
         int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
         int rsz = (int)((scz - bx.gozr) / bx.dnzr) + 1;
         if (rsx == nnxr) rsx--;
@@ -829,7 +842,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
               const float ds = sqrtf(ax * ax + az * az);
               const float t0 = 2.0f * ds / (vss[i - 1][jj - 1] + vsrc);
               const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
-              if (gl == 0) rec_r[(ux - 1) * RM + (uz - 1)].t = t0;
+              if (gl == 0) rec_r[tile_x(ux - 1, TZS_R) + tile_z(uz - 1)].t = t0;
               H.add(t0, (ux << 16) | uz);
             }
         }
@@ -837,7 +850,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, s_nbq[grp]);
+        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, RM, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -847,21 +860,21 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             for (int idx = gl; idx < RM * RM; idx += GP) {
               const int c = idx / RM, r = idx - c * RM;
               Node nd{0.0f, -9};
-              if (c < nnxr && r < nnzr) nd = rec_r[idx];
+              if (c < nnxr && r < nnzr) nd = rec_r[tile_x(c, TZS_R) + tile_z(r)];
               if (nstsr) nstsr[idx] = nd.s;
               if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
             }
-          for (int i = gl; i < nn; i += GP) rec_c[i] = Node{0.0f, -1};
+          for (int i = gl; i < nrec_c; i += GP) rec_c[i] = Node{0.0f, -1};
         }
         cbar();
         // ---- inject every sgdl-th refined node (inv/CalSurfG.f90:1252-1262) ----
         const int bw = bx.vnr - bx.vnl + 1, bh = bx.vnb - bx.vnt + 1, nbox = bw * bh;
         for (int i = gl; i < nbox; i += GP) {
           const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
-          const Node nd = rec_r[(bxi * SGDL) * RM + bzi * SGDL];
+          const Node nd = rec_r[tile_x(bxi * SGDL, TZS_R) + tile_z(bzi * SGDL)];
           Node o{0.0f, nd.s};
           if (nd.s >= 0) o.t = nd.t;
-          rec_c[(bx.vnl - 1 + bxi) * nnz + (bx.vnt - 1 + bzi)] = o;
+          rec_c[tile_x(bx.vnl - 1 + bxi, tzs_c) + tile_z(bx.vnt - 1 + bzi)] = o;
         }
         cbar();
         // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only
@@ -874,12 +887,13 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-            p = &rec_c[(cx - 1) * nnz + (cz - 1)];
+            const int tx = tile_x(cx - 1, tzs_c), tz = tile_z(cz - 1);
+            p = &rec_c[tx + tz];
             if (p->s == 0) {
-              if (cz - 1 >= 1 && p[-1].s == -1) promote = true;
-              if (cz + 1 <= nnz && p[1].s == -1) promote = true;
-              if (cx - 1 >= 1 && p[-nnz].s == -1) promote = true;
-              if (cx + 1 <= nnx && p[nnz].s == -1) promote = true;
+              if (cz - 1 >= 1 && rec_c[tx + tile_z(cz - 2)].s == -1) promote = true;
+              if (cz + 1 <= nnz && rec_c[tx + tile_z(cz)].s == -1) promote = true;
+              if (cx - 1 >= 1 && rec_c[tile_x(cx - 2, tzs_c) + tz].s == -1) promote = true;
+              if (cx + 1 <= nnx && rec_c[tile_x(cx, tzs_c) + tz].s == -1) promote = true;
             }
           }
           cbar();
@@ -889,7 +903,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
         H.ntr = 0;
         H.rec = rec_c;
-        H.ld = nnz;
+        H.tzs = tzs_c;
         for (int base = 0; base < nbox; base += GP) {
           const int i = base + gl;
           Node nd{0.0f, -1};
@@ -897,7 +911,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-            nd = rec_c[(cx - 1) * nnz + (cz - 1)];
+            nd = rec_c[tile_x(cx - 1, tzs_c) + tile_z(cz - 1)];
             node = (cx << 16) | cz;
           }
           unsigned m = (unsigned)((__ballot(nd.s > 0) >> (grp * GP)) & 0xffffull);
@@ -909,12 +923,15 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nn, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, s_nbq[grp]);
+        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nn, nnz, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
         } else {
-          for (int i = gl; i < nn; i += GP) ttn[i] = rec_c[i].t;  // traveltime-grid write
+          for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
+            const int tx = tile_x(cx, tzs_c);
+            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = rec_c[tx + tile_z(cz)].t;
+          }
         }
       }
     }
@@ -935,9 +952,9 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
   A.ovfcap = ovfcap;
-  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * nn * sizeof(Node), &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(Node), &p))) return rc;
   A.rec_c = (Node *)p;
-  if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * nr * sizeof(Node), &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(Node), &p))) return rc;
   A.rec_r = (Node *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;

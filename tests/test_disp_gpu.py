@@ -107,3 +107,25 @@ def test_division_free_sublayer_interpolation_is_exact(ctx, sublayers):
     assert nf0 == nf1 and np.array_equal(pv0, pv1)
     for a, b in zip(sen0, sen1):
         assert np.array_equal(a, b)
+
+
+def test_period_chunked_task_queue_is_bit_identical(orc):
+    """option disp.pchunk: the periods of a work item handed from task to task (state = last root, del1st, fail flag in HBM,
+    workgroups synchronised through release/acquire flags) must give exactly the unchunked results"""
+    import dazimsurftomo_amd as dz
+    depz = np.array([0.0, 4.0, 10.0, 18.0, 30.0, 45.0, 60.0], np.float32)
+    vel = model(21, 19, depz, 11)
+    t = np.arange(4.0, 41.0, 3.0)
+    base = None
+    for pc in (0, 1, 3, 5):
+        c = dz.Context(0)
+        if pc:
+            c.set_option("disp.pchunk", pc)
+        pv, sen, nf = c.depthkernel(vel, depz, t, 2.0)
+        c.close()
+        if base is None:
+            base = (pv, sen, nf)
+        else:
+            assert nf == base[2] and np.array_equal(pv, base[0])
+            for a, b in zip(sen, base[1]):
+                assert np.array_equal(a, b)

@@ -5,6 +5,8 @@ sys.path.insert(0, "/root/repo")
 import bench
 import dazimsurftomo_amd as dz
 ctx = dz.Context(0)
+import os
+if os.environ.get("DISP_PCHUNK"): ctx.set_option("disp.pchunk", int(os.environ["DISP_PCHUNK"]))
 dev = torch.device("cuda:0")
 for nx in [int(a) for a in sys.argv[1:]] or [54]:
     bench.NX = bench.NY = nx
