@@ -42,7 +42,8 @@ struct FmmArgs {
   int nfield, kmax;
   const double *pv;
   const float *veln;  // [kmax][nnx][nnz]
-  const float *slown; // [kmax][nnx][nnz]  1/veln (the slown = 1.0/vel of fouds2 :583, one IEEE division per node instead of one per update)
+  const float *slown; // [kmax][tiled nnx x nnz]  1/veln (the slown = 1.0/vel of fouds2 :583, one IEEE division per node instead of
+                      // one per update), in the same 4 x 4 tiles as the node records: one index serves both
   const float *scx, *scz;
   const int *period;
   const float *risti_c;  // [nnx]       EARTH*sin(gox+(ix-1)*dnx)
@@ -54,7 +55,7 @@ struct FmmArgs {
   Node *rec_c;   // [nwg][nnx*nnz]
   Node *rec_r;   // [nwg][RM*RM]
   float *velnr;  // [nwg][RM*RM]
-  float *slownr; // [nwg][RM*RM]  1/velnr
+  float *slownr; // [nwg][tiled RM x RM]  1/velnr
   HEnt *ovf;     // [nwg][ovfcap]
   int ovfcap;
   unsigned *counter;
@@ -98,7 +99,9 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
     sumi = sumi + vi[i1 - 1] * sumj;
   }
   veln[tid] = sumi;
-  slown[tid] = 1.0f / sumi;
+  const int tzs = ((g.nnz + 3) >> 2) * 16, nrec = ((g.nnx + 3) >> 2) * tzs;   // 4 x 4 tiles, see tile_x / tile_z below
+  const int x0 = stx - 1, z0 = stz - 1;
+  slown[(size_t)k * nrec + (x0 >> 2) * tzs + ((x0 & 3) << 2) + (((z0 & ~3) << 2) | (z0 & 3))] = 1.0f / sumi;
 }
 
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
@@ -490,7 +493,7 @@ __device__ unsigned long long g_fmm_prof[8];
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
 template <int CAP, bool SPILL, class NT, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow, int lld,
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
@@ -538,8 +541,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     Node nj2 = rec[vj2 ? xj2 + zn : iroot];
     Node nk = rec[vk ? xn + zk : iroot];
     Node nk2 = rec[vk2 ? xn + zk2 : iroot];
-    // slowness of the neighbour (1/velocity, precomputed; the shared velocity grids keep the reference's column-major order)
-    const float vel = slow[nvalid ? __mul24(nix - 1, lld) + (niz - 1) : __mul24(ix - 1, lld) + (iz - 1)];
+    const float vel = slow[nvalid ? xn + zn : iroot];     // slowness of the neighbour (1/velocity, precomputed, same tiling)
     const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
@@ -712,7 +714,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   Node *rec_c = A.rec_c + slot * nrec_c;
   Node *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
-  float *slownr = A.slownr + slot * RM * RM;
+  float *slownr = A.slownr + slot * NREC_R;
   Heap<CAP, SPILL, NT> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
@@ -803,8 +805,9 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             }
             const float vr = sum[0] + sum[1] + sum[2] + sum[3];
             velnr[idx] = vr;
-            slownr[idx] = 1.0f / vr;
-            rec_r[tile_x(idm2 - 1, TZS_R) + tile_z(idm1 - 1)] = Node{0.0f, -1};
+            const int ti = tile_x(idm2 - 1, TZS_R) + tile_z(idm1 - 1);
+            slownr[ti] = 1.0f / vr;
+            rec_r[ti] = Node{0.0f, -1};
           }
         }
         cbar();
@@ -850,7 +853,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, RM, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -923,7 +926,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nn, nnz, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -958,7 +961,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.rec_r = (Node *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;
-  if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * nr * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * 4, &p))) return rc;
   A.slownr = (float *)p;
   if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * ovfcap * sizeof(HEnt), &p))) return rc;
   A.ovf = (HEnt *)p;
@@ -1079,7 +1082,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if ((rc = dz_scratch(ctx, "fmm.veln", nn * kmax * 4, &p))) return rc;
     d_veln = (float *)p;
   }
-  if ((rc = dz_scratch(ctx, "fmm.slown", nn * kmax * 4, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.slown", (size_t)tile_records(g.nnx, g.nnz) * kmax * 4, &p))) return rc;
   float *d_slown = (float *)p;
   {
     DzTimer t(ctx, "gridder");
