@@ -312,15 +312,23 @@ def main():
     native = use_dist and want != "0"
     lsmr_note = ""
     if native:
-        ok = 1
-        try:
-            box = [dz.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            ctx.comm_init(world, rank, box[0])
-        except Exception as e:      # (a rank that cannot even create the id still reaches the vote below)
-            ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
-            if want == "1":
-                raise
+        ok, uid = 1, None
+        if rank == 0:
+            try:
+                uid = dz.comm_unique_id()
+            except Exception as e:
+                lsmr_note = f"ncclGetUniqueId failed: {e}"
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)          # (every rank reaches this, whatever happened on rank 0)
+        if box[0] is None:
+            ok = 0
+        else:
+            try:
+                ctx.comm_init(world, rank, box[0])
+            except Exception as e:
+                ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
+        if want == "1" and not ok:
+            raise RuntimeError(lsmr_note or "in-library RCCL set-up failed")
         vote = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(vote, op=dist.ReduceOp.MIN)
         if int(vote.item()) == 0:

@@ -334,6 +334,13 @@ class SparseMatrix:
         return irow, icol, rw
 
     def free(self):
+        """release the device arrays (also done when the object is collected; safe after the context was closed)"""
         if self._h:
-            self.ctx.lib.dazim_csr_free(self.ctx._h, self._h)
+            self.ctx.lib.dazim_csr_free(self.ctx._h if self.ctx._h else None, self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

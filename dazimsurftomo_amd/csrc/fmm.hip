@@ -143,10 +143,14 @@ template <class NT> struct NodeCodec;
 template <> struct NodeCodec<unsigned short> {
   __device__ __forceinline__ static unsigned short enc(int node) { return (unsigned short)((((node >> 16) - 1) << 8) | ((node & 0xffff) - 1)); }
   __device__ __forceinline__ static int dec(unsigned short c) { return (((int)(c >> 8) + 1) << 16) | ((int)(c & 0xff) + 1); }
+  __device__ __forceinline__ static int x0(unsigned short c) { return (int)(c >> 8); }        // 0-based coordinates of a code
+  __device__ __forceinline__ static int z0(unsigned short c) { return (int)(c & 0xff); }
 };
 template <> struct NodeCodec<int> {
   __device__ __forceinline__ static int enc(int node) { return node; }
   __device__ __forceinline__ static int dec(int c) { return c; }
+  __device__ __forceinline__ static int x0(int c) { return (c >> 16) - 1; }
+  __device__ __forceinline__ static int z0(int c) { return (c & 0xffff) - 1; }
 };
 
 template <int CAP, bool SPILL, class NT>
@@ -160,6 +164,7 @@ struct Heap {
   bool g0;     // lane 0 of the group
 
   __device__ __forceinline__ int idx(int node) const { return tile_x((node >> 16) - 1, tzs) + tile_z((node & 0xffff) - 1); }
+  __device__ __forceinline__ int idx_code(NT c) const { return tile_x(NodeCodec<NT>::x0(c), tzs) + tile_z(NodeCodec<NT>::z0(c)); }
   // SPILL=false: the whole band lives in LDS (no VMEM load inside the sift loops, so the back-pointer
   // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
@@ -235,7 +240,7 @@ struct Heap {
     const int dst = mover ? (c >> gl) : 0;
     keys[dst] = ak;
     nodes[dst] = an;
-    if (mover) rec[idx(NodeCodec<NT>::dec(an))].s = dst;
+    if (mover) rec[idx_code(an)].s = dst;
     if (live && gl == L) {
       const int fin = c >> L;
       keys[fin] = key;
@@ -327,7 +332,7 @@ struct Heap {
   // A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child tail.
   // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
   // where a pending neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
-  static constexpr int NSTEP = 4;   // 3 levels each: reaches slot 4095
+  static constexpr int NSTEP = CAP <= 1024 ? 3 : 4;   // 3 levels each: three steps reach slot 1023, four slot 4095
   __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NSTEP],
                                                int (&cslot)[NSTEP], int &fin_node, int &fin_slot) {
     static_assert(CAP <= 4096, "pop_root_par covers 12 levels");
@@ -382,8 +387,7 @@ struct Heap {
       const int dst = mine ? slot >> 1 : 0;
       keys[dst] = k;
       nodes[dst] = c;
-      const int nd = NodeCodec<NT>::dec(c);
-      cnode[b] = nd;
+      cnode[b] = (int)c;                                    // (the stored code; decoded when the back-pointer is flushed)
       cslot[b] = dst;
       const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
@@ -397,7 +401,7 @@ struct Heap {
     }
     keys[p] = mvk;
     nodes[p] = mvc;
-    fin_node = NodeCodec<NT>::dec(mvc);
+    fin_node = (int)mvc;
     fin_slot = p;
   }
 };
@@ -528,21 +532,25 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
     // stay in flight while the root is sifted down in LDS. ----
     const int nix = ix + dix, niz = iz + diz;
-    const bool nvalid = nix >= 1 && nix <= nnx && niz >= 1 && niz <= nnz;
-    const int j = nix + jd, j2 = nix + 2 * jd, k = niz + kd, k2 = niz + 2 * kd;
-    const bool vj = nvalid && j >= 1 && j <= nnx, vj2 = vj && j2 >= 1 && j2 <= nnx;
-    const bool vk = nvalid && k >= 1 && k <= nnz, vk2 = vk && k2 >= 1 && k2 <= nnz;
+    // 0-based coordinates and one unsigned comparison per range test ((unsigned)(x) < n  <=>  0 <= x < n)
+    const int nx0 = nix - 1, nz0 = niz - 1;
+    const unsigned unx = (unsigned)nnx, unz = (unsigned)nnz;
+    const bool nvalid = (unsigned)nx0 < unx && (unsigned)nz0 < unz;
+    const int j0 = nx0 + jd, j20 = nx0 + 2 * jd, k0 = nz0 + kd, k20 = nz0 + 2 * kd;
+    const bool vj = nvalid && (unsigned)j0 < unx, vj2 = vj && (unsigned)j20 < unx;
+    const bool vk = nvalid && (unsigned)k0 < unz, vk2 = vk && (unsigned)k20 < unz;
     // tiled record indices: an X part per column (neighbour, +-1, +-2) and a Z part per row; out-of-grid coordinates give
-    // garbage that the validity flags replace by the root's own record
-    const int xn = tile_x(nix - 1, tzs), xj = tile_x(j - 1, tzs), xj2 = tile_x(j2 - 1, tzs);
-    const int zn = tile_z(niz - 1), zk = tile_z(k - 1), zk2 = tile_z(k2 - 1);
-    Node nself = rec[nvalid ? xn + zn : iroot];
-    Node nj = rec[vj ? xj + zn : iroot];
-    Node nj2 = rec[vj2 ? xj2 + zn : iroot];
-    Node nk = rec[vk ? xn + zk : iroot];
-    Node nk2 = rec[vk2 ? xn + zk2 : iroot];
-    const float vel = slow[nvalid ? xn + zn : iroot];     // slowness of the neighbour (1/velocity, precomputed, same tiling)
-    const float risti = risti_tab[nvalid ? nix - 1 : ix - 1];
+    // garbage that the validity flags replace by the root's own record.  Unsigned indices: no sign extension per address.
+    const int xn = tile_x(nx0, tzs), xj = tile_x(j0, tzs), xj2 = tile_x(j20, tzs);
+    const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
+    const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
+    Node nself = rec[uself];
+    Node nj = rec[vj ? (unsigned)(xj + zn) : uroot];
+    Node nj2 = rec[vj2 ? (unsigned)(xj2 + zn) : uroot];
+    Node nk = rec[vk ? (unsigned)(xn + zk) : uroot];
+    Node nk2 = rec[vk2 ? (unsigned)(xn + zk2) : uroot];
+    const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
+    const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
 #pragma unroll
@@ -574,8 +582,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     } else {
 #pragma unroll
       for (int b = 0; b < Heap<CAP, SPILL, NT>::NSTEP; b++)
-        if (cslot[b] > 0) rec[H.idx(cnode[b])].s = cslot[b];
-      if (H.g0 && fin_slot > 0) rec[H.idx(fin_node)].s = fin_slot;
+        if (cslot[b] > 0) rec[H.idx_code((NT)cnode[b])].s = cslot[b];
+      if (H.g0 && fin_slot > 0) rec[H.idx_code((NT)fin_node)].s = fin_slot;
     }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
