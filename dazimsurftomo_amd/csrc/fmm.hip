@@ -153,8 +153,14 @@ template <> struct NodeCodec<int> {
   __device__ __forceinline__ static int z0(int c) { return (c & 0xffff) - 1; }
 };
 
-template <int CAP, bool SPILL, class NT>
+// HYB (grids above 341 nodes a side, where 3*max(nnx,nnz) slots of LDS would leave three workgroups per CU): levels 1..10 of
+// the heap (slots < CAP = 1024) live in LDS and are sifted by the parallel routines exactly as in the all-LDS heap; level 11
+// (slots CAP .. 2*CAP-1) lives in the HBM array `ovf` and is reached by one extra sequential step of the sift-down and by the
+// owner lanes' direct writes.  Only fields whose band outgrows 1023 entries ever touch it (sources far from every edge of a
+// 511 x 511 grid, and only while the front is near its largest), so the common path pays a few wave-uniform tests.
+template <int CAP, bool SPILL, class NT, bool HYB = false>
 struct Heap {
+  static constexpr int TOT = HYB ? 2 * CAP : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
@@ -169,7 +175,7 @@ struct Heap {
   // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
   __device__ __forceinline__ HEnt get(int slot) const {
-    if (SPILL && slot >= CAP) return ovf[slot - CAP];
+    if ((SPILL || HYB) && slot >= CAP) return ovf[slot - CAP];
     return HEnt{keys[slot], NodeCodec<NT>::dec(nodes[slot])};
   }
   __device__ __forceinline__ void get2(int slot, HEnt &a, HEnt &b) const {  // slot even
@@ -194,7 +200,7 @@ struct Heap {
   // (same address, same value -- no exec-mask branch inside the sift loops); the HBM back-pointer
   // and spill stores are issued by lane 0 only.
   __device__ __forceinline__ void put(int slot, float key, int node) {
-    if (SPILL && slot >= CAP) {
+    if ((SPILL || HYB) && slot >= CAP) {
       if (g0) ovf[slot - CAP] = HEnt{key, node};
     } else {
       keys[slot] = key;
@@ -238,18 +244,27 @@ struct Heap {
     const int L = __builtin_ctz(~mb);                      // (bit 16 of ~mb is set: L <= 16, and <= 11 by the heap depth)
     const bool mover = live && gl < L;
     const int dst = mover ? (c >> gl) : 0;
-    keys[dst] = ak;
-    nodes[dst] = an;
+    // (HYB: only slot c itself can lie in the HBM level -- lane 0's destination, or the entry's own if it does not rise)
+    const bool dhi = HYB && dst >= CAP;
+    const int ldst = dhi ? 0 : dst;
+    keys[ldst] = ak;
+    nodes[ldst] = an;
     if (mover) rec[idx_code(an)].s = dst;
-    if (live && gl == L) {
-      const int fin = c >> L;
+    const bool last = live && gl == L;
+    const int fin = c >> L;
+    const bool fhi = HYB && last && fin >= CAP;
+    if (last && !fhi) {
       keys[fin] = key;
       nodes[fin] = NodeCodec<NT>::enc(node);
-      rec[idx(node)] = Node{key, fin};
+    }
+    if (last) rec[idx(node)] = Node{key, fin};
+    if (HYB && __ballot(dhi || fhi) != 0) {
+      if (dhi) ovf[dst - CAP] = HEnt{ak, NodeCodec<NT>::dec(an)};
+      if (fhi) ovf[fin - CAP] = HEnt{key, node};
     }
     return L;
   }
-  __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= CAP; }
+  __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= TOT; }
   __device__ __forceinline__ void add(float key, int node) {
     const int nbn[4] = {0, 0, 0, 0};
     int nbs[4] = {0, 0, 0, 0};
@@ -333,20 +348,31 @@ struct Heap {
   // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
   // where a pending neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
   static constexpr int NSTEP = CAP <= 1024 ? 3 : 4;   // 3 levels each: three steps reach slot 1023, four slot 4095
-  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NSTEP],
-                                               int (&cslot)[NSTEP], int &fin_node, int &fin_slot) {
+  static constexpr int NCAP = NSTEP + (HYB ? 1 : 0);  // captured moves: one per parallel step (+ the HBM level's)
+  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NCAP],
+                                               int (&cslot)[NCAP], int &fin_node, int &fin_slot) {
     static_assert(CAP <= 4096, "pop_root_par covers 12 levels");
+    static_assert(!HYB || CAP == 1024 || CAP == 128 || CAP == 16, "HYB: the LDS levels must end where a 3-level step ends");
     const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
 #pragma unroll
-    for (int b = 0; b < NSTEP; b++) cslot[b] = 0;
+    for (int b = 0; b < NCAP; b++) cslot[b] = 0;
     fin_slot = 0;
     fin_node = 0;
     if (ntr == 1) {
       ntr = 0;
       return;
     }
-    const float mvk = keys[ntr];
-    const NT mvc = nodes[ntr];
+    const bool mhi = HYB && ntr >= CAP;                   // the last entry sits in the HBM level
+    const int mls = mhi ? 0 : ntr;
+    float mvk = keys[mls];
+    NT mvc = nodes[mls];
+    if (HYB && __ballot(mhi) != 0) {
+      if (mhi) {
+        const HEnt e = ovf[ntr - CAP];
+        mvk = e.key;
+        mvc = NodeCodec<NT>::enc(e.node);
+      }
+    }
     ntr--;
     const int r = gl + 2;                                 // position in the 3-level subtree: 2..15 (lanes 14,15 idle)
     const int d = r >= 8 ? 3 : (r >= 4 ? 2 : 1);
@@ -399,8 +425,37 @@ struct Heap {
         active = false;
       }
     }
-    keys[p] = mvk;
-    nodes[p] = mvc;
+    if (HYB) {
+      // the hole went down three full levels in the last step (it is on level 10) and has children: they live in HBM.  One
+      // sequential step of downtree (:857-866): the smaller child, ties to the left, moves up if it is smaller than the moving key.
+      if (__ballot(active) != 0) {
+        if (active) {
+          const HEnt *ch = ovf + (2 * p - CAP);
+          const HEnt c0 = ch[0];
+          HEnt c1 = HEnt{INFINITY, 0};
+          if (2 * p + 1 <= ntr) c1 = ch[1];
+          const bool right = c0.key > c1.key;
+          const float ck = right ? c1.key : c0.key;
+          const int cn = right ? c1.node : c0.node;
+          if (ck < mvk) {
+            keys[p] = ck;
+            nodes[p] = NodeCodec<NT>::enc(cn);
+            if (g0) {
+              cnode[NSTEP] = (int)NodeCodec<NT>::enc(cn);
+              cslot[NSTEP] = p;
+            }
+            p = 2 * p + (right ? 1 : 0);
+          }
+        }
+      }
+    }
+    const bool phi = HYB && p >= CAP;
+    const int lp = phi ? 0 : p;
+    keys[lp] = mvk;
+    nodes[lp] = mvc;
+    if (HYB && __ballot(phi) != 0) {
+      if (phi && g0) ovf[p - CAP] = HEnt{mvk, NodeCodec<NT>::dec(mvc)};
+    }
     fin_node = (int)mvc;
     fin_slot = p;
   }
@@ -496,8 +551,8 @@ __device__ unsigned long long g_fmm_prof[8];
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
-template <int CAP, bool SPILL, class NT, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__restrict__ slow,
+template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED>
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
@@ -561,7 +616,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
     }
     int mynode = 0, myslot = 0, nmoves = 0;
     const int ntr_old = H.ntr;                               // slot of the entry the pop drops into the hole
-    int cnode[Heap<CAP, SPILL, NT>::NSTEP], cslot[Heap<CAP, SPILL, NT>::NSTEP], fin_node = 0, fin_slot = 0;
+    constexpr int NCAP = Heap<CAP, SPILL, NT, HYB>::NCAP, TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
+    int cnode[NCAP], cslot[NCAP], fin_node = 0, fin_slot = 0;
     PROF(0);
     if (SPILL) {
       H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
@@ -581,7 +637,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       if (gl < nmoves) rec[H.idx(mynode)].s = myslot;   // deferred back-pointers of the sift-down
     } else {
 #pragma unroll
-      for (int b = 0; b < Heap<CAP, SPILL, NT>::NSTEP; b++)
+      for (int b = 0; b < NCAP; b++)
         if (cslot[b] > 0) rec[H.idx_code((NT)cnode[b])].s = cslot[b];
       if (H.g0 && fin_slot > 0) rec[H.idx_code((NT)fin_node)].s = fin_slot;
     }
@@ -620,7 +676,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
       const int cnt = __popc(newb);
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
-      const bool room = H.ntr + cnt < CAP;
+      const bool room = H.ntr + cnt < TOT;
       const int pc = c >> 1;
       float pk = H.keys[(act && room) ? pc : 0];
       const int cact = act ? c : 0;
@@ -636,10 +692,14 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
       fast = n0 == 4;
       {
         const bool wr = owner && act && nb < n0;
-        const int dst = wr ? c : 0;                        // slot 0 is never a heap entry
+        const bool whi = HYB && wr && c >= CAP;            // (HYB) the entry's slot lies in the HBM level
+        const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = NodeCodec<NT>::enc(mynode);
         if (wr) rec[H.idx(mynode)] = Node{trav, c};
+        if (HYB && __ballot(whi) != 0) {
+          if (whi) H.ovf[c - CAP] = HEnt{trav, mynode};
+        }
         H.ntr += __popc(newb & ((1u << (4 * n0)) - 1u));
       }
     }
@@ -709,11 +769,13 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT> &H, const float *__re
   return overflow;
 }
 
-template <int CAP, bool SPILL, class NT>
+template <int CAP, bool SPILL, class NT, bool HYB>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
-  __shared__ unsigned s_base;
+  // the queue position is handed to the wavefront through slot 0 of the first field's keys (the dummy slot of the marching
+  // loop, idle between fields): the kernel's LDS is exactly the heaps, so five 32 KB workgroups of the hybrid heap fill 160 KB
+  unsigned &s_base = *reinterpret_cast<unsigned *>(&s_keys[0][0]);
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
@@ -723,7 +785,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   Node *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * NREC_R;
-  Heap<CAP, SPILL, NT> H;
+  Heap<CAP, SPILL, NT, HYB> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
   H.ovf = A.ovf + slot * A.ovfcap;
@@ -861,7 +923,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        bool ovf = march<CAP, SPILL, NT, HYB, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -934,7 +996,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (!ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -950,19 +1012,22 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
 }
 
 
-template <int CAP, class NT>
+template <int CAP, class NT, bool HYB = false>
 int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::vector<int> &hs) {
   int rc;
   void *p;
   // workgroups (one wavefront, FPW fields each): as many as the LDS heaps allow per CU
-  int per_cu = (int)(160 * 1024 / ((4 + sizeof(NT)) * CAP * FPW + 64));
+  int per_cu = 0;
+  DZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmm_kernel<CAP, false, NT, HYB>, 64, 0));
+  if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;
+  ctx->ksec["fmm.wg_per_cu"] = (double)per_cu;
   if (ctx->opts.count("fmm.wg_per_cu") && ctx->opts["fmm.wg_per_cu"] > 0 && ctx->opts["fmm.wg_per_cu"] < per_cu) per_cu = ctx->opts["fmm.wg_per_cu"];
   int nwg = ctx->num_cu * per_cu;
   if (nwg > (nfield + FPW - 1) / FPW) nwg = (nfield + FPW - 1) / FPW;
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
-  A.ovfcap = ovfcap;
+  A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
   if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(Node), &p))) return rc;
   A.rec_c = (Node *)p;
   if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(Node), &p))) return rc;
@@ -971,7 +1036,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.velnr = (float *)p;
   if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * 4, &p))) return rc;
   A.slownr = (float *)p;
-  if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * ovfcap * sizeof(HEnt), &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * A.ovfcap * sizeof(HEnt) + 64, &p))) return rc;
   A.ovf = (HEnt *)p;
   if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
   A.counter = (unsigned *)p;
@@ -1000,7 +1065,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   std::vector<int> redo;
   if (!force_spill) {
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
-    hipLaunchKernelGGL((fmm_kernel<CAP, false, NT>), dim3(nwg), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1018,7 +1083,11 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
     int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
     if (nwg2 > nwg) nwg2 = nwg;
-    hipLaunchKernelGGL((fmm_kernel<CAP, true, NT>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
+    // the spill kernel keeps every slot >= CAP in HBM: maxbt entries per resident field, allocated only when a field needs it
+    A.ovfcap = ovfcap;
+    if ((rc = dz_scratch(ctx, "fmm.ovf_spill", (size_t)nwg2 * FPW * ovfcap * sizeof(HEnt), &p))) return rc;
+    A.ovf = (HEnt *)p;
+    hipLaunchKernelGGL((fmm_kernel<CAP, true, NT, false>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1133,6 +1202,8 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    // grids of 342 .. 682 nodes a side (S-512): levels 1-10 in LDS + level 11 in HBM, four instead of three workgroups per CU
+    else if (cap <= 2048 && !(ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"])) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1536) rc = run_fmm<1536, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else rc = run_fmm<2048, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     if (rc) return rc;

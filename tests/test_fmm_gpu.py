@@ -12,9 +12,9 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(ctx, orc, nx, ny, kmax, nsrc, seed, goxd=30.0, gozd=100.0, dv=0.25, edge_sources=False):
+def _run_case(ctx, orc, nx, ny, kmax, nsrc, seed, goxd=30.0, gozd=100.0, dv=0.25, edge_sources=False, shrink=0.3):
     pv = synth.phase_velocity_maps(nx, ny, kmax, seed)
-    lat, lon = synth.stations(nx, ny, goxd, gozd, dv, dv, nsrc, seed + 1, shrink=0.02 if edge_sources else 0.3)
+    lat, lon = synth.stations(nx, ny, goxd, gozd, dv, dv, nsrc, seed + 1, shrink=0.02 if edge_sources else shrink)
     if edge_sources:  # corners and exact node positions exercise the clipped refined boxes
         lat[:4] = [goxd, goxd, goxd - (nx - 3) * dv, goxd - (nx - 3) * dv]
         lon[:4] = [gozd, gozd + (ny - 3) * dv, gozd, gozd + (ny - 3) * dv]
@@ -64,8 +64,26 @@ def test_fmm_126(ctx, orc):
 
 
 def test_fmm_511(ctx, orc):
-    """BASELINE S-512 geometry: 105x105 -> 511x511 nodes (32-bit node ids, heap capacity 1536, 4-step sift-down to level 11)"""
+    """BASELINE S-512 geometry: 105x105 -> 511x511 nodes (32-bit node ids; hybrid heap: levels 1-10 in LDS, level 11 in HBM)"""
     _run_case(ctx, orc, 105, 105, 1, 5, seed=8, edge_sources=True)
+
+
+def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
+    """sources far from every edge of a 511x511 grid: the narrow band outgrows the 1023 LDS slots of the hybrid heap and lives
+    partly in its HBM level -- still bit-exact and without a rerun; that the band really gets that large is shown by the plain
+    1024-slot heap, which has to hand the same fields to the spill kernel; the all-LDS 1536-slot heap gives the same fields"""
+    _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+    assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+    try:
+        ctx.set_option("fmm.no_hybrid", 1)
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+        ctx.set_option("fmm.cap", 1024)
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") >= 3
+    finally:
+        ctx.set_option("fmm.cap", 0)
+        ctx.set_option("fmm.no_hybrid", 0)
 
 
 def test_fmm_source_outside(ctx):

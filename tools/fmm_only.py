@@ -2,14 +2,14 @@
 fmm.cap / fmm.wg_per_cu options.  With a library built by DAZIM_HIPCC_EXTRA=-DDZ_FMM_PROF the per-phase shader-clock totals of the
 marching loop are printed to stderr."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dazimsurftomo_amd as dz
 from tests import synth
-import os
 nx = ny = int(os.environ.get('NX','54')); kmax = 16; nsrc = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pv = synth.phase_velocity_maps(nx, ny, kmax)
-lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc)
+lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc, shrink=float(os.environ.get('SHRINK','0.3')))
 sx, sz = synth.radians(lat, lon)
 scx = np.tile(sx, kmax); scz = np.tile(sz, kmax); per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
 nf = len(scx)
@@ -28,8 +28,10 @@ cap=int(os.environ.get('CAP','0'))
 if cap: ctx.set_option('fmm.cap', cap)
 wpc=int(os.environ.get('WPC','0'))
 if wpc: ctx.set_option('fmm.wg_per_cu', wpc)
+for kv in os.environ.get('OPTS','').split(','):   # OPTS=fmm.no_hybrid=1,...
+    if '=' in kv: ctx.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 for it in range(reps):
     ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, d_pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn, ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
     ks = ctx.kernel_seconds("fmm")
-    print(f"wpc {wpc} cap {cap} fields {nf} kernel {ks:.4f}s {nf/ks:.0f} fields/s spilled {ctx.kernel_seconds('fmm.spilled_fields')}")
+    print(f"wpc {wpc} cap {cap} fields {nf} kernel {ks:.4f}s {nf/ks:.0f} fields/s spilled {ctx.kernel_seconds('fmm.spilled_fields')} wg/cu {ctx.kernel_seconds('fmm.wg_per_cu')}")
 print("checksum", float(d_ttn.double().sum()), int(d_nstsr.long().sum()))
