@@ -8,7 +8,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-LIB_PATH = os.path.join(HERE, "lib", "libdazim_hip.so")
+# DAZIM_LIB selects another build of the same sources (kernel A/B experiments on one box, tools/); the product is lib/libdazim_hip.so
+LIB_PATH = os.environ.get("DAZIM_LIB") or os.path.join(HERE, "lib", "libdazim_hip.so")
 CSRC = os.path.join(HERE, "csrc")
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

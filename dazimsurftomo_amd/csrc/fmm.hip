@@ -34,7 +34,7 @@ struct __align__(8) Node {
 };
 struct __align__(8) HEnt {
   float key;
-  int node;  // (ix << 16) | iz, both 1-based (the reference's int16 px,pz: inv/CalSurfG.f90:238)
+  int node;  // index of the node's record in the tiled layout (tile_x + tile_z below; the reference keeps int16 px,pz: inv/CalSurfG.f90:238)
 };
 
 struct FmmArgs {
@@ -71,6 +71,23 @@ __device__ __forceinline__ void bspl4(float u, float w[4]) {
   w[3] = u * u * u / 6.0f;
 }
 
+// Node records live in HBM in 4 x 4 tiles of 8-byte records (one 128-byte line per tile): node (ix0, iz0), 0-based, of a grid
+// with ntz tiles per column of tiles (ceil(nz/4) rounded up to a power of two) is record
+// ((ix0>>2)*ntz + (iz0>>2))*16 + (ix0&3)*4 + (iz0&3).  The stencil of a pop reaches +-3 nodes in both directions: in the
+// reference's column-major order that is 7 columns = 7-8 lines, tiled it is 4-6.  The two coordinates contribute separately, so
+// the five addresses of a lane cost three X and three Z parts.  That record index is also the node's name in the heap (16 bits
+// on grids up to 256 x 256, 32 bits otherwise): entries that move need no decoding to find their record, and only the root of a
+// pop is turned back into coordinates (rid_x0 / rid_z0).  tsh = log2 of the record stride between columns of tiles.
+__host__ __device__ constexpr int tile_shift(int nz) { int l = 0; while ((1 << l) < ((nz + 3) >> 2)) l++; return l + 4; }
+__host__ __device__ constexpr int tile_stride(int nz) { return 1 << tile_shift(nz); }
+__host__ __device__ constexpr int tile_records(int nx, int nz) { return ((nx + 3) >> 2) * tile_stride(nz); }
+__host__ __device__ __forceinline__ constexpr int tile_x(int x0, int tsh) { return ((x0 >> 2) << tsh) + ((x0 & 3) << 2); }
+__host__ __device__ __forceinline__ constexpr int tile_z(int z0) { return ((z0 & ~3) << 2) | (z0 & 3); }
+__device__ __forceinline__ int rid_x0(int rid, int tsh) { return ((rid >> tsh) << 2) | ((rid >> 2) & 3); }
+__device__ __forceinline__ int rid_z0(int rid, int tsh) { return (((rid & ((1 << tsh) - 1)) >> 4) << 2) | (rid & 3); }
+constexpr int TSH_R = tile_shift(DAZIM_RMAX);                       // refined grid: 33 tiles per column of tiles, stride 64 tiles
+constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 33 792 record slots per refined field
+
 // ---- gridder: inv/CalSurfG.f90:1423-1516, one thread per propagation node -------------------
 __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict__ pv,
                                float *__restrict__ veln, float *__restrict__ slown) {
@@ -99,9 +116,7 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
     sumi = sumi + vi[i1 - 1] * sumj;
   }
   veln[tid] = sumi;
-  const int tzs = ((g.nnz + 3) >> 2) * 16, nrec = ((g.nnx + 3) >> 2) * tzs;   // 4 x 4 tiles, see tile_x / tile_z below
-  const int x0 = stx - 1, z0 = stz - 1;
-  slown[(size_t)k * nrec + (x0 >> 2) * tzs + ((x0 & 3) << 2) + (((z0 & ~3) << 2) | (z0 & 3))] = 1.0f / sumi;
+  slown[(size_t)k * tile_records(g.nnx, g.nnz) + tile_x(stx - 1, tile_shift(g.nnz)) + tile_z(stz - 1)] = 1.0f / sumi;   // 4 x 4 tiles
 }
 
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
@@ -124,34 +139,9 @@ constexpr int DPP_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
 constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 
-// LDS layout is structure-of-arrays: fp32 keys + node ids.  NT = unsigned short packs the node as
-// (ix-1)<<8 | (iz-1), possible when both grid sides are <= 256 (the S-256 case: 6 bytes per entry,
-// a third more fields in flight per CU); NT = int keeps (ix<<16)|iz for larger grids.
-// Node records live in HBM in 4 x 4 tiles of 8-byte records (one 128-byte line per tile): node (ix0, iz0), 0-based, of a grid
-// with ntz = ceil(nz/4) tiles per column of tiles is record ((ix0>>2)*ntz + (iz0>>2))*16 + (ix0&3)*4 + (iz0&3).  The stencil
-// of a pop reaches +-3 nodes in both directions: in the reference's column-major order that is 7 columns = 7-8 lines, tiled it
-// is 4-6 (measured below).  The two coordinates contribute separately, so the five addresses of a lane cost three X and three
-// Z parts.  tzs = ntz*16 is the record stride between columns of tiles.
-__device__ __forceinline__ int tile_x(int x0, int tzs) { return __mul24(x0 >> 2, tzs) + ((x0 & 3) << 2); }
-__device__ __forceinline__ int tile_z(int z0) { return ((z0 & ~3) << 2) | (z0 & 3); }
-__host__ __device__ constexpr int tile_stride(int nz) { return ((nz + 3) >> 2) * 16; }
-__host__ __device__ constexpr int tile_records(int nx, int nz) { return ((nx + 3) >> 2) * tile_stride(nz); }
-constexpr int TZS_R = tile_stride(DAZIM_RMAX);                      // refined grid: 33 tiles per column of tiles
-constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 17 424 records per refined field
-
-template <class NT> struct NodeCodec;
-template <> struct NodeCodec<unsigned short> {
-  __device__ __forceinline__ static unsigned short enc(int node) { return (unsigned short)((((node >> 16) - 1) << 8) | ((node & 0xffff) - 1)); }
-  __device__ __forceinline__ static int dec(unsigned short c) { return (((int)(c >> 8) + 1) << 16) | ((int)(c & 0xff) + 1); }
-  __device__ __forceinline__ static int x0(unsigned short c) { return (int)(c >> 8); }        // 0-based coordinates of a code
-  __device__ __forceinline__ static int z0(unsigned short c) { return (int)(c & 0xff); }
-};
-template <> struct NodeCodec<int> {
-  __device__ __forceinline__ static int enc(int node) { return node; }
-  __device__ __forceinline__ static int dec(int c) { return c; }
-  __device__ __forceinline__ static int x0(int c) { return (c >> 16) - 1; }
-  __device__ __forceinline__ static int z0(int c) { return (c & 0xffff) - 1; }
-};
+// LDS layout is structure-of-arrays: fp32 keys + node ids (the node's record index, see tile_x above): NT = unsigned short when
+// both grids of a field have at most 65 536 record slots (sides <= 256, the S-256 case: 6 bytes per entry, a third more fields
+// in flight per CU), NT = int otherwise.
 
 // HYB (grids above 341 nodes a side, where 3*max(nnx,nnz) slots of LDS would leave three workgroups per CU): levels 1..10 of
 // the heap (slots < CAP = 1024) live in LDS and are sifted by the parallel routines exactly as in the all-LDS heap; level 11
@@ -165,18 +155,16 @@ struct Heap {
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
   Node *rec;   // node records of the grid being marched (4 x 4 tiles)
-  int tzs;     // record stride between columns of tiles of that grid
+  int tsh;     // log2 of the record stride between columns of tiles of that grid
   int ntr;
   bool g0;     // lane 0 of the group
 
-  __device__ __forceinline__ int idx(int node) const { return tile_x((node >> 16) - 1, tzs) + tile_z((node & 0xffff) - 1); }
-  __device__ __forceinline__ int idx_code(NT c) const { return tile_x(NodeCodec<NT>::x0(c), tzs) + tile_z(NodeCodec<NT>::z0(c)); }
   // SPILL=false: the whole band lives in LDS (no VMEM load inside the sift loops, so the back-pointer
   // stores never have to be waited for); a field whose band outgrows CAP is flagged and redone by
   // the SPILL=true instantiation, which keeps slots >= CAP in HBM.
   __device__ __forceinline__ HEnt get(int slot) const {
     if ((SPILL || HYB) && slot >= CAP) return ovf[slot - CAP];
-    return HEnt{keys[slot], NodeCodec<NT>::dec(nodes[slot])};
+    return HEnt{keys[slot], (int)nodes[slot]};
   }
   __device__ __forceinline__ void get2(int slot, HEnt &a, HEnt &b) const {  // slot even
     if (SPILL && slot >= CAP) {
@@ -188,11 +176,11 @@ struct Heap {
       b.key = k2.y;
       if (sizeof(NT) == 2) {
         const unsigned v = *reinterpret_cast<const unsigned *>(&nodes[slot]);
-        a.node = NodeCodec<NT>::dec((NT)(v & 0xffffu));
-        b.node = NodeCodec<NT>::dec((NT)(v >> 16));
+        a.node = (int)(v & 0xffffu);
+        b.node = (int)(v >> 16);
       } else {
-        a.node = NodeCodec<NT>::dec(nodes[slot]);
-        b.node = NodeCodec<NT>::dec(nodes[slot + 1]);
+        a.node = (int)nodes[slot];
+        b.node = (int)nodes[slot + 1];
       }
     }
   }
@@ -204,9 +192,9 @@ struct Heap {
       if (g0) ovf[slot - CAP] = HEnt{key, node};
     } else {
       keys[slot] = key;
-      nodes[slot] = NodeCodec<NT>::enc(node);
+      nodes[slot] = (NT)node;
     }
-    if (g0) rec[idx(node)].s = slot;
+    if (g0) rec[node].s = slot;
   }
   // sift (key,node) up from slot c.  If `track`, entries that move down are compared with the
   // pending neighbours' node ids so that their slots stay current (nbs[m] for m > from).
@@ -249,17 +237,17 @@ struct Heap {
     const int ldst = dhi ? 0 : dst;
     keys[ldst] = ak;
     nodes[ldst] = an;
-    if (mover) rec[idx_code(an)].s = dst;
+    if (mover) rec[(unsigned)an].s = dst;
     const bool last = live && gl == L;
     const int fin = c >> L;
     const bool fhi = HYB && last && fin >= CAP;
     if (last && !fhi) {
       keys[fin] = key;
-      nodes[fin] = NodeCodec<NT>::enc(node);
+      nodes[fin] = (NT)node;
     }
-    if (last) rec[idx(node)] = Node{key, fin};
+    if (last) rec[node] = Node{key, fin};
     if (HYB && __ballot(dhi || fhi) != 0) {
-      if (dhi) ovf[dst - CAP] = HEnt{ak, NodeCodec<NT>::dec(an)};
+      if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
     }
     return L;
@@ -277,7 +265,7 @@ struct Heap {
       if (g0) ovf[slot - CAP] = HEnt{key, node};
     } else {
       keys[slot] = key;
-      nodes[slot] = NodeCodec<NT>::enc(node);
+      nodes[slot] = (NT)node;
     }
   }
   // downtree.  The back-pointer stores of the entries that move are NOT issued here: move #i is
@@ -370,7 +358,11 @@ struct Heap {
       if (mhi) {
         const HEnt e = ovf[ntr - CAP];
         mvk = e.key;
-        mvc = NodeCodec<NT>::enc(e.node);
+        int mvi = e.node;
+        // the wait for this load belongs inside the branch: left to the join below it would be executed by every pop and
+        // drain the stencil loads that were issued before the sift-down (vmcnt is in-order)
+        asm volatile("" : "+v"(mvk), "+v"(mvi));
+        mvc = (NT)mvi;
       }
     }
     ntr--;
@@ -413,7 +405,7 @@ struct Heap {
       const int dst = mine ? slot >> 1 : 0;
       keys[dst] = k;
       nodes[dst] = c;
-      cnode[b] = (int)c;                                    // (the stored code; decoded when the back-pointer is flushed)
+      cnode[b] = (int)c;                                    // (the entry's node = its record index, for the back-pointer store)
       cslot[b] = dst;
       const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
@@ -439,9 +431,9 @@ struct Heap {
           const int cn = right ? c1.node : c0.node;
           if (ck < mvk) {
             keys[p] = ck;
-            nodes[p] = NodeCodec<NT>::enc(cn);
+            nodes[p] = (NT)cn;
             if (g0) {
-              cnode[NSTEP] = (int)NodeCodec<NT>::enc(cn);
+              cnode[NSTEP] = cn;
               cslot[NSTEP] = p;
             }
             p = 2 * p + (right ? 1 : 0);
@@ -454,7 +446,7 @@ struct Heap {
     keys[lp] = mvk;
     nodes[lp] = mvc;
     if (HYB && __ballot(phi) != 0) {
-      if (phi && g0) ovf[p - CAP] = HEnt{mvk, NodeCodec<NT>::dec(mvc)};
+      if (phi && g0) ovf[p - CAP] = HEnt{mvk, (int)mvc};
     }
     fin_node = (int)mvc;
     fin_slot = p;
@@ -561,14 +553,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
   Node *rec = H.rec;
-  const int tzs = H.tzs;
+  const int tsh = H.tsh;
   bool overflow = false;
   PROF_DECL;
   while (H.ntr > 0 && !overflow) {
     cbar();
     PROF(7);
     const HEnt root = H.get(1);
-    const int ix = root.node >> 16, iz = root.node & 0xffff;
+    const int iroot = root.node;                            // record index of the node being accepted
+    const int ix = rid_x0(iroot, tsh) + 1, iz = rid_z0(iroot, tsh) + 1;
     if (REFINED) {
       bool swrg = false;
       if (ix == 1 && (ex & 1)) swrg = true;
@@ -576,11 +569,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) rec[tile_x(ix - 1, tzs) + tile_z(iz - 1)].s = 0;
+        if (H.g0) rec[iroot].s = 0;
         break;
       }
     }
-    const int iroot = tile_x(ix - 1, tzs) + tile_z(iz - 1);
     if (H.g0) rec[iroot].s = 0;
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
@@ -596,7 +588,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const bool vk = nvalid && (unsigned)k0 < unz, vk2 = vk && (unsigned)k20 < unz;
     // tiled record indices: an X part per column (neighbour, +-1, +-2) and a Z part per row; out-of-grid coordinates give
     // garbage that the validity flags replace by the root's own record.  Unsigned indices: no sign extension per address.
-    const int xn = tile_x(nx0, tzs), xj = tile_x(j0, tzs), xj2 = tile_x(j20, tzs);
+    const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
     const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
     const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
     Node nself = rec[uself];
@@ -608,12 +600,17 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
-#pragma unroll
-    for (int n = 0; n < 4; n++) {
-      const int ux = ix + (n == 0 ? -1 : (n == 1 ? 1 : 0)), uz = iz + (n == 2 ? -1 : (n == 3 ? 1 : 0));
-      nbn[n] = (ux << 16) | uz;
-      nbm[n] = 0;
+    // the four neighbours' record indices, from their owner lanes (nb, q = 0); -1 outside the grid.  Needed before the pop only
+    // by the spill kernel's sequential sift-down (which entry moved where); the parallel kernel fetches them in its slow path.
+    const int nrid = nvalid ? (int)uself : -1;
+    if (SPILL) {
+      nbn[0] = dpp_i<DPP_BCAST0 + 0>(nrid); nbn[1] = dpp_i<DPP_BCAST0 + 4>(nrid);
+      nbn[2] = dpp_i<DPP_BCAST0 + 8>(nrid); nbn[3] = dpp_i<DPP_BCAST0 + 12>(nrid);
+    } else {
+      nbn[0] = nbn[1] = nbn[2] = nbn[3] = 0;
     }
+#pragma unroll
+    for (int n = 0; n < 4; n++) nbm[n] = 0;
     int mynode = 0, myslot = 0, nmoves = 0;
     const int ntr_old = H.ntr;                               // slot of the entry the pop drops into the hole
     constexpr int NCAP = Heap<CAP, SPILL, NT, HYB>::NCAP, TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
@@ -634,12 +631,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
                  "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
                  : "memory");
     if (SPILL) {
-      if (gl < nmoves) rec[H.idx(mynode)].s = myslot;   // deferred back-pointers of the sift-down
+      if (gl < nmoves) rec[mynode].s = myslot;   // deferred back-pointers of the sift-down
     } else {
 #pragma unroll
       for (int b = 0; b < NCAP; b++)
-        if (cslot[b] > 0) rec[H.idx_code((NT)cnode[b])].s = cslot[b];
-      if (H.g0 && fin_slot > 0) rec[H.idx_code((NT)fin_node)].s = fin_slot;
+        if (cslot[b] > 0) rec[(unsigned)cnode[b]].s = cslot[b];
+      if (H.g0 && fin_slot > 0) rec[(unsigned)fin_node].s = fin_slot;
     }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
@@ -666,7 +663,6 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // Did the sift-down move this neighbour's heap entry?  The hole went from slot 1 down to fin_slot and every entry on
       // that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its ancestors (except the
       // root); the last entry of the old heap is the one that was dropped into the hole.
-      const int mynode = (nix << 16) | niz;
       if (stfix > 1 && fin_slot > 0) {
         const int dP = 31 - __clz(fin_slot), ds = 31 - __clz(stfix);
         if (stfix == ntr_old) stfix = fin_slot;
@@ -695,10 +691,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         const bool whi = HYB && wr && c >= CAP;            // (HYB) the entry's slot lies in the HBM level
         const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
-        H.nodes[dst] = NodeCodec<NT>::enc(mynode);
-        if (wr) rec[H.idx(mynode)] = Node{trav, c};
+        H.nodes[dst] = (NT)uself;
+        if (wr) rec[uself] = Node{trav, c};
         if (HYB && __ballot(whi) != 0) {
-          if (whi) H.ovf[c - CAP] = HEnt{trav, mynode};
+          if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
         H.ntr += __popc(newb & ((1u << (4 * n0)) - 1u));
       }
@@ -713,6 +709,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       nbs[2] = dpp_i<DPP_BCAST0 + 8>(stfix); nbs[3] = dpp_i<DPP_BCAST0 + 12>(stfix);
       nbt[0] = dpp_f<DPP_BCAST0 + 0>(trav); nbt[1] = dpp_f<DPP_BCAST0 + 4>(trav);
       nbt[2] = dpp_f<DPP_BCAST0 + 8>(trav); nbt[3] = dpp_f<DPP_BCAST0 + 12>(trav);
+      if (!SPILL) {
+        nbn[0] = dpp_i<DPP_BCAST0 + 0>(nrid); nbn[1] = dpp_i<DPP_BCAST0 + 4>(nrid);
+        nbn[2] = dpp_i<DPP_BCAST0 + 8>(nrid); nbn[3] = dpp_i<DPP_BCAST0 + 12>(nrid);
+      }
       if (SPILL) {
 #pragma unroll
         for (int n = 0; n < 4; n++)
@@ -721,7 +721,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         for (int n = 0; n < 4; n++) {
           if (nbs[n] == 0 || n < n0) continue;
           const int node = nbn[n];
-          if (H.g0) rec[H.idx(node)].t = nbt[n];
+          if (H.g0) rec[node].t = nbt[n];
           int c = nbs[n];
           if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
             if (H.full()) {
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const dazim_geom g = A.g;
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
-  const int tzs_c = tile_stride(nnz), nrec_c = tile_records(nnx, nnz);
+  const int tsh_c = tile_shift(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
   Node *rec_c = A.rec_c + slot * nrec_c;
   Node *rec_r = A.rec_r + slot * NREC_R;
@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             }
             const float vr = sum[0] + sum[1] + sum[2] + sum[3];
             velnr[idx] = vr;
-            const int ti = tile_x(idm2 - 1, TZS_R) + tile_z(idm1 - 1);
+            const int ti = tile_x(idm2 - 1, TSH_R) + tile_z(idm1 - 1);
             slownr[ti] = 1.0f / vr;
             rec_r[ti] = Node{0.0f, -1};
           }
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 ----
         H.ntr = 0;
         H.rec = rec_r;
-        H.tzs = TZS_R;
+        H.tsh = TSH_R;
         int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
         int rsz = (int)((scz - bx.gozr) / bx.dnzr) + 1;
         if (rsx == nnxr) rsx--;
@@ -915,8 +915,9 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
               const float ds = sqrtf(ax * ax + az * az);
               const float t0 = 2.0f * ds / (vss[i - 1][jj - 1] + vsrc);
               const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
-              if (gl == 0) rec_r[tile_x(ux - 1, TZS_R) + tile_z(uz - 1)].t = t0;
-              H.add(t0, (ux << 16) | uz);
+              const int urid = tile_x(ux - 1, TSH_R) + tile_z(uz - 1);
+              if (gl == 0) rec_r[urid].t = t0;
+              H.add(t0, urid);
             }
         }
         // exit-rule quirk kept verbatim (inv/CalSurfG.f90:366-377): vnr/vnb (coarse indices) are
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             for (int idx = gl; idx < RM * RM; idx += GP) {
               const int c = idx / RM, r = idx - c * RM;
               Node nd{0.0f, -9};
-              if (c < nnxr && r < nnzr) nd = rec_r[tile_x(c, TZS_R) + tile_z(r)];
+              if (c < nnxr && r < nnzr) nd = rec_r[tile_x(c, TSH_R) + tile_z(r)];
               if (nstsr) nstsr[idx] = nd.s;
               if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
             }
@@ -944,10 +945,10 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         const int bw = bx.vnr - bx.vnl + 1, bh = bx.vnb - bx.vnt + 1, nbox = bw * bh;
         for (int i = gl; i < nbox; i += GP) {
           const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
-          const Node nd = rec_r[tile_x(bxi * SGDL, TZS_R) + tile_z(bzi * SGDL)];
+          const Node nd = rec_r[tile_x(bxi * SGDL, TSH_R) + tile_z(bzi * SGDL)];
           Node o{0.0f, nd.s};
           if (nd.s >= 0) o.t = nd.t;
-          rec_c[tile_x(bx.vnl - 1 + bxi, tzs_c) + tile_z(bx.vnt - 1 + bzi)] = o;
+          rec_c[tile_x(bx.vnl - 1 + bxi, tsh_c) + tile_z(bx.vnt - 1 + bzi)] = o;
         }
         cbar();
         // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only
@@ -960,13 +961,13 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-            const int tx = tile_x(cx - 1, tzs_c), tz = tile_z(cz - 1);
+            const int tx = tile_x(cx - 1, tsh_c), tz = tile_z(cz - 1);
             p = &rec_c[tx + tz];
             if (p->s == 0) {
               if (cz - 1 >= 1 && rec_c[tx + tile_z(cz - 2)].s == -1) promote = true;
               if (cz + 1 <= nnz && rec_c[tx + tile_z(cz)].s == -1) promote = true;
-              if (cx - 1 >= 1 && rec_c[tile_x(cx - 2, tzs_c) + tz].s == -1) promote = true;
-              if (cx + 1 <= nnx && rec_c[tile_x(cx, tzs_c) + tz].s == -1) promote = true;
+              if (cx - 1 >= 1 && rec_c[tile_x(cx - 2, tsh_c) + tz].s == -1) promote = true;
+              if (cx + 1 <= nnx && rec_c[tile_x(cx, tsh_c) + tz].s == -1) promote = true;
             }
           }
           cbar();
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
         H.ntr = 0;
         H.rec = rec_c;
-        H.tzs = tzs_c;
+        H.tsh = tsh_c;
         for (int base = 0; base < nbox; base += GP) {
           const int i = base + gl;
           Node nd{0.0f, -1};
@@ -984,8 +985,8 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
-            nd = rec_c[tile_x(cx - 1, tzs_c) + tile_z(cz - 1)];
-            node = (cx << 16) | cz;
+            node = tile_x(cx - 1, tsh_c) + tile_z(cz - 1);
+            nd = rec_c[node];
           }
           unsigned m = (unsigned)((__ballot(nd.s > 0) >> (grp * GP)) & 0xffffull);
           while (m) {
@@ -1002,7 +1003,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
         } else {
           for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
-            const int tx = tile_x(cx, tzs_c);
+            const int tx = tile_x(cx, tsh_c);
             for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = rec_c[tx + tile_z(cz)].t;
           }
         }
