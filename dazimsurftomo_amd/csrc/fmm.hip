@@ -327,20 +327,23 @@ struct Heap {
     nmoves++;
   }
 
-  // downtree for the all-in-LDS heap, three levels per step.  Which child a hole descends to does not depend
-  // on the moving entry (always the smaller child, ties to the left, :857-866), only the stopping depth does,
-  // so 14 lanes of the group read the 2+4+8 descendants of the hole at once, the sibling comparisons and the
-  // comparisons with the moving key are exchanged with two ballots, and every lane that sits on the chosen
-  // path copies its entry into its parent slot.  Same comparisons, same final array as the sequential loop.
-  // A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child tail.
-  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores;
-  // where a pending neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
-  static constexpr int NSTEP = CAP <= 1024 ? 3 : 4;   // 3 levels each: three steps reach slot 1023, four slot 4095
+  // downtree for the heap in LDS, four levels per step.  Which child a hole descends to does not depend on the moving
+  // entry (always the smaller child, ties to the left, :857-866), only the stopping depth does.  Lane i < 15 of the group is
+  // parent position q = i + 1 of the 4-level subtree below the hole (q = 1: the hole itself): it reads ITS TWO CHILDREN (one
+  // 8-byte key pair + one node pair), picks the smaller one, and two ballots tell every lane which way each of the 15 parents
+  // would send the hole and whether the child going up is smaller than the moving key.  A lane whose ancestors all point at
+  // it and all move (per-lane constant masks G/E/A) copies its smaller child into its own slot: same comparisons, same final
+  // array as the sequential loop.  A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child
+  // tail.  Two steps empty a heap below 512 slots (every refined grid, grids up to ~170 nodes a side), three one below 8192.
+  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores; where a pending
+  // neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
+  static constexpr int NSTEP = CAP <= 32 ? 1 : (CAP <= 512 ? 2 : 3);
   static constexpr int NCAP = NSTEP + (HYB ? 1 : 0);  // captured moves: one per parallel step (+ the HBM level's)
   __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NCAP],
                                                int (&cslot)[NCAP], int &fin_node, int &fin_slot) {
-    static_assert(CAP <= 4096, "pop_root_par covers 12 levels");
-    static_assert(!HYB || CAP == 1024 || CAP == 128 || CAP == 16, "HYB: the LDS levels must end where a 3-level step ends");
+    static_assert(CAP <= 8192, "pop_root_par covers 13 levels");
+    static_assert((CAP & 1) == 0, "pairs of children are read together");
+    static_assert(!HYB || (CAP & (CAP - 1)) == 0, "HYB: the LDS part of the heap is whole levels");
     const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
 #pragma unroll
     for (int b = 0; b < NCAP; b++) cslot[b] = 0;
@@ -366,62 +369,69 @@ struct Heap {
       }
     }
     ntr--;
-    const int r = gl + 2;                                 // position in the 3-level subtree: 2..15 (lanes 14,15 idle)
-    const int d = r >= 8 ? 3 : (r >= 4 ? 2 : 1);
-    const int o = r - (1 << d);
-    // lane constants: this lane's entry moves up iff every sibling comparison on the way down from the hole
-    // chose its ancestor line ((gt & G) == E: bit 2a-2 of gt says "children of subtree position a: go right")
-    // and it and its ancestors are all smaller than the moving key ((lt & A) == A: bit r-2 per position r)
-    unsigned G = 1u << (2 * (r >> 1) - 2), E = (unsigned)(r & 1) << (2 * (r >> 1) - 2), A = 1u << (r - 2);
-    if (d >= 2) {
-      G |= 1u << (2 * (r >> 2) - 2);
-      E |= (unsigned)((r >> 1) & 1) << (2 * (r >> 2) - 2);
-      A |= 1u << ((r >> 1) - 2);
-    }
-    if (d == 3) {
-      G |= 1u;
-      E |= (unsigned)((r >> 2) & 1);
-      A |= 1u << ((r >> 2) - 2);
-    }
-    if (gl >= 14) A = 0x10000u;                           // idle lanes never match
+    // lane constants: position q, its depth dq and offset oq in the subtree; G = its proper ancestors' bits (bit a-1 per
+    // position a), E = the directions those ancestors must choose to reach q, A = G + its own bit (all of them must move)
+    const int q = gl + 1;
+    const int dq = 31 - __clz(q), oq = q - (1 << dq);
+    unsigned G = 0, E = 0;
+    if (dq >= 1) { G |= 1u << ((q >> 1) - 1); E |= (unsigned)(q & 1) << ((q >> 1) - 1); }
+    if (dq >= 2) { G |= 1u << ((q >> 2) - 1); E |= (unsigned)((q >> 1) & 1) << ((q >> 2) - 1); }
+    if (dq >= 3) { G |= 1u; E |= (unsigned)((q >> 2) & 1); }
+    unsigned A = G | (1u << (q - 1));
+    if (gl == 15) A = 0x10000u;                            // the idle lane never matches (lt is cut to 16 bits)
     int p = 1;
-    bool active = true;
+    bool active = true, deep = false;
 #pragma unroll
     for (int b = 0; b < NSTEP; b++) {
       if (b > 0 && __ballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
-      // straight-line code: lanes with nothing to read use slot 0 (never a heap entry), lanes with nothing
-      // to move write their entry to slot 0
-      const int slot = (p << d) + o;
-      const bool valid = active && slot <= ntr;
-      const int rs = valid ? slot : 0;
-      const float kr = keys[rs];
-      const NT c = nodes[rs];
-      const float k = valid ? kr : INFINITY;
-      const float ksib = dpp_f<DPP_XOR1>(k);              // right sibling's key on even lanes
-      const unsigned long long gtm = __ballot(k > ksib);  // even lanes: left child strictly greater -> go right
-      const unsigned long long ltm = __ballot(k < mvk);
+      // straight-line code: lanes with nothing to read use the pair at slot 0 (slot 0 is never a heap entry, slot 1 is only
+      // read), lanes with nothing to move write their entry to slot 0
+      const int s = (p << dq) + oq;                        // this lane's parent slot
+      const int c0 = 2 * s;
+      const bool lds = !HYB || c0 < CAP;                   // (HYB: deeper levels live in HBM, see below)
+      const bool v0 = active && lds && c0 <= ntr, v1 = active && lds && c0 < ntr;
+      const int rs = v0 ? c0 : 0;
+      const float2 kk = *reinterpret_cast<const float2 *>(&keys[rs]);
+      int n0, n1;
+      if (sizeof(NT) == 2) {
+        const unsigned v = *reinterpret_cast<const unsigned *>(&nodes[rs]);
+        n0 = (int)(v & 0xffffu);
+        n1 = (int)(v >> 16);
+      } else {
+        const int2 v = *reinterpret_cast<const int2 *>(&nodes[rs]);
+        n0 = v.x;
+        n1 = v.y;
+      }
+      const float k0 = v0 ? kk.x : INFINITY, k1 = v1 ? kk.y : INFINITY;
+      const bool right = k0 > k1;                          // left child strictly greater -> the hole goes right
+      const float ck = right ? k1 : k0;
+      const int cn = right ? n1 : n0;
+      const unsigned long long gtm = __ballot(right);
+      const unsigned long long ltm = __ballot(ck < mvk);
       const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & 0xffffu;
-      const bool mine = active && (gt & G) == E && (lt & A) == A;
-      const int dst = mine ? slot >> 1 : 0;
-      keys[dst] = k;
-      nodes[dst] = c;
-      cnode[b] = (int)c;                                    // (the entry's node = its record index, for the back-pointer store)
+      const bool mine = (gt & G) == E && (lt & A) == A;    // (an inactive group has ck = +inf everywhere: nobody moves)
+      const int dst = mine ? s : 0;
+      keys[dst] = ck;
+      nodes[dst] = (NT)cn;
+      cnode[b] = cn;                                       // (the entry's node = its record index, for the back-pointer store)
       cslot[b] = dst;
       const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
-        const int rt = 33 - __clz(mb);                    // deepest entry that moved: the hole is there now
+        const int qs = 32 - __clz(mb);                    // deepest parent whose child moved up: the hole is at that child now
+        const int rt = 2 * qs + (int)((gt >> (qs - 1)) & 1u);
         const int dt = 31 - __clz(rt);
         p = (p << dt) + rt - (1 << dt);
-        active = dt == 3 && 2 * p <= ntr;
+        active = dt == 4 && 2 * p <= ntr;
+        if (HYB) deep = p >= CAP / 2 && 2 * p <= ntr;     // on the last LDS level, with children: they are in HBM
       } else {
         active = false;
       }
     }
     if (HYB) {
-      // the hole went down three full levels in the last step (it is on level 10) and has children: they live in HBM.  One
-      // sequential step of downtree (:857-866): the smaller child, ties to the left, moves up if it is smaller than the moving key.
-      if (__ballot(active) != 0) {
-        if (active) {
+      // the hole reached the last level of the LDS part and has children: they live in HBM.  One sequential step of downtree
+      // (:857-866): the smaller child, ties to the left, moves up if it is smaller than the moving key.
+      if (__ballot(deep) != 0) {
+        if (deep) {
           const HEnt *ch = ovf + (2 * p - CAP);
           const HEnt c0 = ch[0];
           HEnt c1 = HEnt{INFINITY, 0};
