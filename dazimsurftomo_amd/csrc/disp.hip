@@ -45,6 +45,11 @@ struct DispArgs {
   double *st_c;        // [ncol*nvar] root of the last finished period (c1 at :297), carried to the next chunk
   double *st_d;        // [ncol*nvar] del1st (the SAVEd first secular value of getsol, :409,424)
   int *st_f;           // [ncol*nvar] 1: the search failed, the remaining periods are 0 (:342-348)
+  // first-period fast-forward (see disp_bracket_kernel): per column, the number of dc steps from the start value of the
+  // first period's bracket search to the lower end of the bracket, and that lower end
+  int ffwd;
+  int *ff_m;           // [ncol]  0: no information
+  double *ff_c;        // [ncol]
 };
 
 __device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
@@ -309,7 +314,125 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
   rho = 1.6612f * p - 0.4721f * p2 + 0.0671f * p3 - 0.0043f * p4 + 0.000106f * p5;
 }
 
-enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_DONE };
+enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_GV, P_DONE };
+
+// start-up of surfdisp96 (:134-216): extremal velocities of the layer stack and the start value of the first period's search
+template <int RDEN>
+__device__ __forceinline__ void startup(const Knots &K, const Layer *lay, int mmax, int nz, bool fast, float &betmx, float &cc1) {
+  float betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
+  betmx = -1.e20f;
+  int jsol = 1;
+  for (int m = 1; m <= mmax; m++) {
+    float fa, fb, fr, fd;
+    layer_model<RDEN>(K, lay, m, nz, fast, fa, fb, fr, fd);
+    if (fb > 0.01f && fb < betmn) {
+      betmn = fb;
+      a_mn = fa;
+      b_mn = fb;
+      jsol = 1;
+    } else if (fb <= 0.01f && fa < betmn) {
+      betmn = fa;
+      a_mn = fa;
+      b_mn = fb;
+      jsol = 0;
+    }
+    if (fb > betmx) betmx = fb;
+  }
+  cc1 = jsol == 0 ? betmn : gtsolh(a_mn, b_mn);
+  cc1 = .95f * cc1;
+  cc1 = .90f * cc1;
+}
+
+// The bracket search of the FIRST period starts far below the root (0.855 x the Rayleigh velocity of the slowest layer) and walks
+// up in steps of dc = 0.005 km/s: ~100 secular evaluations against ~9 for each later period, 40 % of all the work of an item with
+// 16 periods -- and a strictly sequential chain only in its stopping rule: the grid points c_j = c_{j-1} + dc do not depend on
+// the function values.  This kernel evaluates them 64 at a time for the column's own model (one wavefront per column, lane j =
+// point j), exactly as the reference would one after the other, and records where the first sign change is: m = j* - 1 steps
+// from the start to the lower end of the bracket, and that lower end.  disp_kernel then starts an item's first period by
+// evaluating the start point (del1st), jumping m steps ahead by the same sequence of additions, evaluating there, and going on
+// as the reference does from that point:
+//   * for the column's own model nothing is assumed -- every skipped point was evaluated here, with the same function;
+//   * the 6*nz perturbed copies (one knot changed by +-0.5 %) jump to 0.02 km/s (four steps) below the column's bracket and
+//     check that the sign there is still the start point's.  A perturbed root lies within ~0.003 km/s of the column's (at most
+//     0.015 if one knot carried all the sensitivity), so the jump stays below it; if the sign has changed, the item goes back to
+//     the start point and searches step by step.  What is NOT checked is an even number of sign changes inside the skipped
+//     interval -- two roots of the perturbed model where the column's model, evaluated at every point of the same grid, has
+//     none.  That takes a double root appearing under a 0.5 % change of one knot; option disp.ffwd = 0 turns the jump off, and
+//     tests/test_disp_gpu.py compares both settings bit for bit.
+constexpr int FF_BLOCKS = 8;          // 8 x 64 grid points = 2.56 km/s above the start value
+constexpr double FF_MARGIN = 0.02;    // km/s below the column's bracket for the perturbed copies
+template <int RDEN>
+__global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
+  __shared__ Layer s_lay[NL];
+  __shared__ float s_knot[3 * NZMAX];
+  const int lane = threadIdx.x, col = blockIdx.x;
+  const int nz = A.nz, mmax = A.mmax;
+  for (int i = lane; i < mmax; i += 64) s_lay[i] = A.lay[i];
+  for (int k = lane; k < nz; k += 64) {
+    const float vs = A.vel[(size_t)k * A.ncol + col];
+    float vp, rho;
+    brocher(vs, vp, rho);
+    s_knot[k] = vs;
+    s_knot[nz + k] = vp;
+    s_knot[2 * nz + k] = rho;
+  }
+  __syncthreads();
+  Knots K;
+  K.vs = s_knot;
+  K.vp = s_knot + nz;
+  K.rho = s_knot + 2 * nz;
+  K.pi = 0;
+  K.pq = -1;
+  K.pv = 0.0f;
+  bool fast = false;
+  if (RDEN == 2) {
+    bool ok = true;
+    for (int i = 1; i < nz; i++)
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const float ad = fabsf(K.get(q, i + 1) - K.get(q, i));
+        ok = ok && (ad == 0.0f || (ad >= 1.0e-30f && ad <= 1.0e28f));
+      }
+    fast = __all(ok);
+  }
+  float betmx, cc1;
+  startup<RDEN>(K, s_lay, mmax, nz, fast, betmx, cc1);
+  const double dc = fabs((double)0.005f), TWOPI = 2.0 * 3.141592653589793;
+  const double omega = TWOPI / A.t[0];
+  const double climit = (double)betmx + dc;      // a visited point at or above it ends the reference's search (:470)
+  double cblk = (double)cc1;                     // grid point 64 * blk
+  unsigned long long prev_last = 0;
+  int found = 0;
+  double cfound = 0.0, clast_prev = 0.0;           // clast_prev: grid point 64 * blk - 1
+  for (int blk = 0; blk < FF_BLOCKS; blk++) {
+    double c = cblk;
+    for (int i = 0; i < lane; i++) c = c + dc;   // the reference's c2 = c1 + dc, one step after the other
+    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / c, omega);
+    const unsigned long long neg = __ballot(sgn(del) < 0.0);
+    const unsigned long long before = (neg << 1) | (blk > 0 ? prev_last : (neg & 1ull));
+    const unsigned long long chg = neg ^ before;                     // bit j: the sign changes between points j-1 and j
+    const unsigned long long over = __ballot(c >= climit);           // points the reference would not go beyond
+    const int jl = over ? __builtin_ctzll(over) : 64;
+    const double clast = __shfl(c, 63);
+    if (chg != 0) {
+      const int j = __builtin_ctzll(chg);
+      const double cl = __shfl(c, j > 0 ? j - 1 : 0);
+      if (j <= jl) {
+        found = 64 * blk + j;
+        cfound = j > 0 ? cl : clast_prev;                          // lower end of the bracket = point j-1
+      }
+      break;
+    }
+    if (over != 0) break;
+    prev_last = neg >> 63;
+    clast_prev = clast;
+    cblk = clast + dc;
+  }
+  if (lane == 0) {
+    A.ff_m[col] = found > 0 ? found - 1 : 0;
+    A.ff_c[col] = cfound;
+  }
+}
 
 // Scheduling.  A work item's periods chain (the root of period k seeds the search of period k+1, :262-266), so an item is a
 // long serial job: ~15 secular evaluations x layers x periods, and a launch whose workgroups do not fill a whole number of
@@ -399,29 +522,10 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     }
     // ---- start-up of surfdisp96 (:134-216): extremal velocities, half-space start value (recomputed per chunk: one pass
     // over the layers, the cost of a fraction of one secular evaluation) ----
-    float betmx = -1.e20f, betmn = 1.e20f, a_mn = 1.0f, b_mn = 1.0f;
-    int jsol = 1;
-    for (int m = 1; m <= mmax; m++) {
-      float fa, fb, fr, fd;
-      layer_model<RDEN>(K, s_lay, m, nz, fast, fa, fb, fr, fd);
-      if (fb > 0.01f && fb < betmn) {
-        betmn = fb;
-        a_mn = fa;
-        b_mn = fb;
-        jsol = 1;
-      } else if (fb <= 0.01f && fa < betmn) {
-        betmn = fa;
-        a_mn = fa;
-        b_mn = fb;
-        jsol = 0;
-      }
-      if (fb > betmx) betmx = fb;
-    }
+    float betmx, cc1;
+    startup<RDEN>(K, s_lay, mmax, nz, fast, betmx, cc1);
     const float ddc = 0.005f, sone = 1.5f;
     const double onea = (double)sone, TWOPI = 2.0 * 3.141592653589793;
-    float cc1 = jsol == 0 ? betmn : gtsolh(a_mn, b_mn);
-    cc1 = .95f * cc1;
-    cc1 = .90f * cc1;
     const double cc = (double)cc1, dc = fabs((double)ddc), cm = cc;
     const size_t wi = (size_t)(active ? w : 0);
     float *cg = A.cg + wi * kmax;
@@ -453,6 +557,27 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
           del1 = del;
           if (ifirst == 1) del1st = del1;
           idir = (ifirst == 1) ? 1 : (sgn(del1st) * sgn(del1) >= 0.0 ? 1 : -1);
+          advance_bracket = true;
+          if (A.ffwd && ifirst == 1 && chunk == 0) {   // first period: jump ahead to the bracket found by disp_bracket_kernel
+            int m = A.ff_m[col];
+            if (m > 0 && var > 0) {
+              const double steps = floor((A.ff_c[col] - FF_MARGIN - c1) / dc);
+              m = steps > 0.0 ? (steps < (double)m + 8.0 ? (int)steps : m + 8) : 0;
+            }
+            if (m >= 2) {
+              s_x[0][tid] = c1;                        // (the Neville table is idle during the bracket search)
+              for (int i = 0; i < m; i++) c1 = c1 + dc;   // the same additions the step-by-step search would have made
+              ceval = c1;
+              phase = P_GV;
+              advance_bracket = false;
+            }
+          }
+          break;
+        case P_GV:   // arrival point of the jump: same sign as the start point -> go on from here, else back to the start
+          if (sgn(del) == sgn(del1))
+            del1 = del;
+          else
+            c1 = s_x[0][tid];
           advance_bracket = true;
           break;
         case P_G2:
@@ -754,7 +879,22 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, DT, dyn_lds) != hipSuccess || occ < 1) occ = 1;
     long nwg = (long)ctx->num_cu * occ;
     if (nwg > (long)ntask) nwg = (long)ntask;
+    // first-period fast-forward (disp_bracket_kernel); off with option disp.ffwd = 0 and when the periods are handed from task to task
+    A.ffwd = (A.nchunk == 1 && !(ctx->opts.count("disp.ffwd") && !ctx->opts["disp.ffwd"])) ? 1 : 0;
+    if ((rc = dz_scratch(ctx, "disp.ff_m", (size_t)ncol * 4 + 16, &p))) return rc;
+    A.ff_m = (int *)p;
+    if ((rc = dz_scratch(ctx, "disp.ff_c", (size_t)ncol * 8 + 16, &p))) return rc;
+    A.ff_c = (double *)p;
     DzTimer t(ctx, "disp");
+    if (A.ffwd) {
+      if (rden == 1)
+        hipLaunchKernelGGL(disp_bracket_kernel<1>, dim3((unsigned)ncol), dim3(64), 0, ctx->stream, A);
+      else if (rden == 2)
+        hipLaunchKernelGGL(disp_bracket_kernel<2>, dim3((unsigned)ncol), dim3(64), 0, ctx->stream, A);
+      else
+        hipLaunchKernelGGL(disp_bracket_kernel<0>, dim3((unsigned)ncol), dim3(64), 0, ctx->stream, A);
+      DZ_HIP(hipGetLastError());
+    }
     if (rden == 1)
       hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
     else if (rden == 2)

@@ -129,3 +129,37 @@ def test_period_chunked_task_queue_is_bit_identical(orc):
             assert nf == base[2] and np.array_equal(pv, base[0])
             for a, b in zip(sen, base[1]):
                 assert np.array_equal(a, b)
+
+
+def test_first_period_fast_forward_is_bit_identical(ctx):
+    """The first period's bracket search jumps to the bracket that disp_bracket_kernel found for the column's own model by
+    evaluating every grid point (exact for the column; the perturbed copies land 0.02 km/s below it, check the sign and fall
+    back to the step-by-step search if it changed).  Results must equal those of the step-by-step search (option disp.ffwd = 0)
+    bit for bit: ordinary columns, a deep model, a low-velocity zone with reversed dispersion, and a column without a root."""
+    cases = []
+    depz = np.arange(12, dtype=np.float32) * 5.0
+    cases.append((model(9, 7, depz, 5), depz, np.arange(5, 37, 2, dtype=np.float64), 3.0))
+    depz = np.array([0, 3, 6, 9, 12, 16, 20, 25, 30, 35, 40, 50, 60, 70, 80, 100, 120, 150], np.float32)
+    cases.append((model(4, 3, depz, 6), depz, np.arange(5, 41, dtype=np.float64), 4.0))
+    depz = np.array([0.0, 5.0, 10.0, 20.0, 35.0, 60.0], np.float32)
+    vel = np.zeros((6, 2, 3), np.float32)
+    vel[:] = np.array([3.4, 3.6, 2.9, 3.2, 3.9, 4.4], np.float32)[:, None, None]
+    vel[:, 1, :] *= np.float32(1.03)
+    cases.append((vel, depz, np.arange(4, 44, 2, dtype=np.float64), 3.0))
+    depz = np.array([0.0, 10.0, 20.0, 40.0], np.float32)
+    vel = np.zeros((4, 1, 2), np.float32)
+    vel[:, 0, 0] = [3.0, 3.5, 3.9, 4.3]
+    vel[:, 0, 1] = [4.6, 4.4, 3.0, 2.6]
+    cases.append((vel, depz, np.array([5.0, 10.0, 20.0, 40.0, 60.0]), 2.0))
+    for vel, depz, t, minthk in cases:
+        for kernels in (True, False):
+            pv1, sen1, nf1 = ctx.depthkernel(vel, depz, t, minthk, kernels=kernels)
+            ctx.set_option("disp.ffwd", 0)
+            try:
+                pv0, sen0, nf0 = ctx.depthkernel(vel, depz, t, minthk, kernels=kernels)
+            finally:
+                ctx.set_option("disp.ffwd", 1)
+            assert nf0 == nf1 and np.array_equal(pv0, pv1)
+            if kernels:
+                for a, b in zip(sen0, sen1):
+                    assert np.array_equal(a, b)

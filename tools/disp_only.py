@@ -7,6 +7,7 @@ import dazimsurftomo_amd as dz
 ctx = dz.Context(0)
 import os
 if os.environ.get("DISP_PCHUNK"): ctx.set_option("disp.pchunk", int(os.environ["DISP_PCHUNK"]))
+if os.environ.get("DISP_FFWD"): ctx.set_option("disp.ffwd", int(os.environ["DISP_FFWD"]))
 dev = torch.device("cuda:0")
 for nx in [int(a) for a in sys.argv[1:]] or [54]:
     bench.NX = bench.NY = nx
