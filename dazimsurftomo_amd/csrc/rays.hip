@@ -180,7 +180,10 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // moves to another B-spline cell (every ~10 steps), so every cell still sees its contributions in the
 // reference's order (fdm = r1 + fdm).
 template <bool EMIT, bool AZIM>
-__global__ __launch_bounds__(64, AZIM ? 2 : 4) void rays_kernel(RayArgs A) {
+#ifndef DZ_RAYS_MINW
+#define DZ_RAYS_MINW 4
+#endif
+__global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayArgs A) {
   constexpr int GP = EMIT ? GP_EMIT : GP_COUNT;   // lanes per ray
   constexpr int RPW = 64 / GP;                    // rays per wavefront
   constexpr int LPR = 16 / GP;                    // cells of the 4x4 B-spline block per lane

@@ -86,6 +86,12 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
         ctx.set_option("fmm.no_hybrid", 0)
 
 
+def test_fmm_701(ctx, orc):
+    """a grid above 682 nodes a side (143x143 -> 701x701): past the hybrid heap's 2047 slots, the all-LDS 2048-slot heap with
+    32-bit node ids and three 4-level sift-down steps"""
+    _run_case(ctx, orc, 143, 143, 1, 3, seed=17, shrink=12.0)
+
+
 def test_fmm_source_outside(ctx):
     import dazimsurftomo_amd as dz
     pv = synth.phase_velocity_maps(17, 17, 1)
