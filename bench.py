@@ -408,6 +408,7 @@ def main():
             stats["lsmr_s"] = time.perf_counter() - t_l
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
         stats["spmv_kind"], stats["spmvt_kind"] = ctx.kernel_seconds("spmv.kind"), ctx.kernel_seconds("spmvt.kind")
+        stats["ax_idx_bytes"], stats["aty_idx_bytes"] = ctx.kernel_seconds("spmv.idx_bytes"), ctx.kernel_seconds("spmvt.idx_bytes")
         stats["lsmr_itn"] = info["itn"]
         stats["nfail"] = nfail
         lap("lsmr")
@@ -445,6 +446,13 @@ def main():
         kind_aty = {0: "spmv_rows (CSC gather)", 1: "spmvT_scatter + k_scatter_combine"}
         b_ax = nnz * 8 + (m + 1) * 8 + n * 4 + 2 * m * 4      # A*x : CSR stream + rowptr + x + u read/write
         b_aty = nnz * 8 + (n + 1) * 8 + m * 4 + 2 * n * 4
+        # `achieved` / `frac` follow SURVEY 8(d): fp32 value + int32 column = 8 B per stored entry, the reference's representation
+        # (comparable from round to round).  Where the library streams 16-bit column indices (n <= 65536) the bytes it really
+        # moves are 6 B per entry: `stored_*` quote the same time against those.
+        ib_ax = int(stats.get("ax_idx_bytes", 4) or 4)
+        ib_aty = int(stats.get("aty_idx_bytes", 4) or 4)
+        s_ax = b_ax - nnz * (4 - ib_ax)
+        s_aty = b_aty - nnz * (4 - ib_aty)
         out = {
             "metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s",
             "value": total_fields / (dt / a.steps), "unit": "fields/s",
@@ -470,9 +478,13 @@ def main():
                                  "ATy": kind_aty.get(int(stats.get("spmvt_kind", -1)), "?")}, "bound": "hbm",
                      "unit": "GB/s", "peak": HBM_PEAK_GBS,
                      "Ax": {"us": stats["spmv_s"] * 1e6, "achieved": b_ax / stats["spmv_s"] / 1e9,
-                            "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["ax"]},
+                            "frac": b_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["ax"],
+                            "stored_bytes_per_entry": 4 + ib_ax, "stored_achieved": s_ax / stats["spmv_s"] / 1e9,
+                            "stored_frac": s_ax / stats["spmv_s"] / 1e9 / HBM_PEAK_GBS},
                      "ATy": {"us": stats["spmvt_s"] * 1e6, "achieved": b_aty / stats["spmvt_s"] / 1e9,
-                             "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["aty"]},
+                             "frac": b_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS, "traffic": traffic["aty"],
+                             "stored_bytes_per_entry": 4 + ib_aty, "stored_achieved": s_aty / stats["spmvt_s"] / 1e9,
+                             "stored_frac": s_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS},
                      "m": m, "n": n, "nnz": nnz},
             "lsmr": {"driver": ("in-library RCCL (dazim_comm_init)" if native else "torch.distributed (backend nccl = RCCL)") if use_dist
                                else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,

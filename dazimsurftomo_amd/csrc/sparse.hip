@@ -23,6 +23,9 @@ struct dazim_csr {
   int ncb = 0, cbw = 0;                          // number of column blocks, block width
   int64_t *cbptr = nullptr;
   float vmax = 0.0f;                             // max |val|, sets the fixed-point scale
+  // the same column indices in 16 bits when n <= 65536 (the S-256 matrix): the two products of an LSMR iteration stream
+  // 6 instead of 8 bytes per stored entry.  Built with the column blocks; nullptr otherwise.
+  unsigned short *col16 = nullptr;
 };
 
 namespace {
@@ -92,8 +95,16 @@ __global__ __launch_bounds__(64 * WPB) void spmv_rows(int64_t nrows, const int64
 // One workgroup of 16 wavefronts per CU, each wavefront a row at a time, two 16-byte loads of
 // values and of indices in flight per lane.
 constexpr int LWPB = 16;
+#ifndef DZ_LDSX_UNROLL4
+#define DZ_LDSX_UNROLL4 1
+#endif
+// four consecutive column indices with one load: int4 (16 bytes) or ushort4 (8 bytes)
+template <class IT> struct Idx4;
+template <> struct Idx4<int> { using type = int4; };
+template <> struct Idx4<unsigned short> { using type = ushort4; };
+template <class IT>
 __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64_t nx, const int64_t *__restrict__ ptr,
-                                                           const int *__restrict__ idx, const float *__restrict__ val,
+                                                           const IT *__restrict__ idx, const float *__restrict__ val,
                                                            const float *__restrict__ x, float *__restrict__ out,
                                                            const float *__restrict__ beta_p, float beta_sign,
                                                            double *__restrict__ sumsq, const int *__restrict__ guard) {
@@ -117,11 +128,31 @@ __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64
     for (int64_t i = s + lane; i < s4; i += 64) acc += val[i] * xs[idx[i]];
     const int64_t e4 = s4 + ((e - s4) & ~(int64_t)3);
     int64_t i = s4 + 4 * lane;
+#if DZ_LDSX_UNROLL4
+    for (; i + 768 < e4; i += 1024) {   // four groups in flight (16-bit indices leave 24 instead of 32 bytes per lane and group)
+      using I4 = typename Idx4<IT>::type;
+      float4 v[4];
+      I4 c[4];
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        v[g] = *reinterpret_cast<const float4 *>(val + i + 256 * g);
+        c[g] = *reinterpret_cast<const I4 *>(idx + i + 256 * g);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        acc += v[g].x * xs[c[g].x];
+        acc += v[g].y * xs[c[g].y];
+        acc += v[g].z * xs[c[g].z];
+        acc += v[g].w * xs[c[g].w];
+      }
+    }
+#endif
     for (; i + 256 < e4; i += 512) {
+      using I4 = typename Idx4<IT>::type;
       const float4 v0 = *reinterpret_cast<const float4 *>(val + i);
-      const int4 c0 = *reinterpret_cast<const int4 *>(idx + i);
+      const I4 c0 = *reinterpret_cast<const I4 *>(idx + i);
       const float4 v1 = *reinterpret_cast<const float4 *>(val + i + 256);
-      const int4 c1 = *reinterpret_cast<const int4 *>(idx + i + 256);
+      const I4 c1 = *reinterpret_cast<const I4 *>(idx + i + 256);
       acc += v0.x * xs[c0.x];
       acc += v0.y * xs[c0.y];
       acc += v0.z * xs[c0.z];
@@ -132,8 +163,9 @@ __global__ __launch_bounds__(64 * LWPB) void spmv_rows_ldsx(int64_t nrows, int64
       acc += v1.w * xs[c1.w];
     }
     for (; i < e4; i += 256) {
+      using I4 = typename Idx4<IT>::type;
       const float4 v = *reinterpret_cast<const float4 *>(val + i);
-      const int4 c = *reinterpret_cast<const int4 *>(idx + i);
+      const I4 c = *reinterpret_cast<const I4 *>(idx + i);
       acc += v.x * xs[c.x];
       acc += v.y * xs[c.y];
       acc += v.z * xs[c.z];
@@ -501,6 +533,17 @@ __global__ void k_colblock_ptr(int64_t nrows, int ncb, int cbw, const int64_t *_
   cbptr[t] = lo;
 }
 constexpr int APART = 2048;   // partial maxima (enough workgroups to stream at HBM rate)
+// 32-bit -> 16-bit column indices, four per thread step
+__global__ void k_narrow_cols(int64_t n, const int *__restrict__ col, unsigned short *__restrict__ col16) {
+  for (int64_t i = ((int64_t)blockIdx.x * VB + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * VB * 4) {
+    if (i + 3 < n) {
+      const int4 c = *reinterpret_cast<const int4 *>(col + i);
+      *reinterpret_cast<ushort4 *>(col16 + i) = make_ushort4((unsigned short)c.x, (unsigned short)c.y, (unsigned short)c.z, (unsigned short)c.w);
+    } else {
+      for (int64_t j = i; j < n; j++) col16[j] = (unsigned short)col[j];
+    }
+  }
+}
 __global__ void k_absmax(int64_t n, const float *x, float *part) {
   float v = 0.0f;
   const int64_t n4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) ? n / 4 : 0;   // 16-byte loads when the array allows
@@ -538,10 +581,11 @@ __global__ void k_absmax_finish(const float *part, int np, float *res) {
 // elemf(column, value, aux) is called for every entry (head, aligned groups, tail: the order of a plain loop over this lane's
 // entries), endf(r, aux) once per row.
 struct RowPtr { int64_t s, e; float aux; };
-template <int GL, int NG, class PtrF, class ElemF, class EndF>
-__device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64_t nrows, int lane, const int *__restrict__ col,
+template <int GL, int NG, class IT, class PtrF, class ElemF, class EndF>
+__device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64_t nrows, int lane, const IT *__restrict__ col,
                                           const float *__restrict__ val, PtrF ptrf, ElemF elemf, EndF endf) {
-  struct Ent { int64_t r, s4, e4; float aux; float4 v[NG]; int4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
+  using I4 = typename Idx4<IT>::type;
+  struct Ent { int64_t r, s4, e4; float aux; float4 v[NG]; I4 k[NG]; float hv, tv; int hk, tk; bool hh, ht; };
   auto load_ptr = [&](int64_t r) {
     RowPtr p = ptrf(r < nrows ? r : 0);                // (a dummy read past the end)
     if (r >= nrows) p.e = p.s;                         // nothing to do
@@ -559,15 +603,15 @@ __device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64
       const int64_t i = t.s4 + 4 * lane + (int64_t)g * 4 * GL;
       const int64_t j = i < t.e4 ? i : 0;
       t.v[g] = *reinterpret_cast<const float4 *>(val + j);
-      t.k[g] = *reinterpret_cast<const int4 *>(col + j);
+      t.k[g] = *reinterpret_cast<const I4 *>(col + j);
     }
     const int64_t ih = p.s + lane, it = t.e4 + lane;   // <= 3 unaligned entries at either end
     t.hh = ih < t.s4;
     t.ht = it < p.e;
     t.hv = val[t.hh ? ih : 0];
-    t.hk = col[t.hh ? ih : 0];
+    t.hk = (int)col[t.hh ? ih : 0];
     t.tv = val[t.ht ? it : 0];
-    t.tk = col[t.ht ? it : 0];
+    t.tk = (int)col[t.ht ? it : 0];
     return t;
   };
   auto consume = [&](const Ent &t) {
@@ -576,14 +620,14 @@ __device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64
     for (int g = 0; g < NG; g++) {
       const int64_t i = t.s4 + 4 * lane + (int64_t)g * 4 * GL;
       if (i < t.e4) {
-        elemf(t.k[g].x, t.v[g].x, t.aux); elemf(t.k[g].y, t.v[g].y, t.aux);
-        elemf(t.k[g].z, t.v[g].z, t.aux); elemf(t.k[g].w, t.v[g].w, t.aux);
+        elemf((int)t.k[g].x, t.v[g].x, t.aux); elemf((int)t.k[g].y, t.v[g].y, t.aux);
+        elemf((int)t.k[g].z, t.v[g].z, t.aux); elemf((int)t.k[g].w, t.v[g].w, t.aux);
       }
     }
     for (int64_t i = t.s4 + 4 * lane + (int64_t)NG * 4 * GL; i < t.e4; i += 4 * GL) {   // long rows
       const float4 v = *reinterpret_cast<const float4 *>(val + i);
-      const int4 k = *reinterpret_cast<const int4 *>(col + i);
-      elemf(k.x, v.x, t.aux); elemf(k.y, v.y, t.aux); elemf(k.z, v.z, t.aux); elemf(k.w, v.w, t.aux);
+      const I4 k = *reinterpret_cast<const I4 *>(col + i);
+      elemf((int)k.x, v.x, t.aux); elemf((int)k.y, v.y, t.aux); elemf((int)k.z, v.z, t.aux); elemf((int)k.w, v.w, t.aux);
     }
     if (t.ht) elemf(t.tk, t.tv, t.aux);
     endf(t.r, t.aux);
@@ -606,9 +650,9 @@ __device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64
 // idle, while a counter that hands rows out dynamically costs more in same-address atomics than it saves (both measured).
 // (The same pipeline applied to the LDS-staged A*x kernel made it 2 % slower -- that kernel streams whole rows and is bandwidth
 // bound already -- and pipelining fixed-size segments instead of rows made this one 6 % slower; same-box A/B runs.)
-template <int GL, int NG>
+template <int GL, int NG, class IT>
 __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
-                                                          const int64_t *__restrict__ cbptr, const int *__restrict__ col,
+                                                          const int64_t *__restrict__ cbptr, const IT *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
                                                           double scale, long long *__restrict__ part, const int *__restrict__ guard) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];
@@ -623,7 +667,7 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
   // fixed point by the magic-number trick: for |t| < 2^51, the low mantissa bits of t + 1.5*2^52 hold round-to-nearest-even(t);
   // scale is a power of two, so the fused multiply-add rounds exactly like (v*y*scale) + magic would
   constexpr double MAGIC = 6755399441055744.0;
-  walk_rows<GL, NG>(
+  walk_rows<GL, NG, IT>(
       ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nchunk * SCW * RPWV, nrows, lane, col, val,
       [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb], cbptr[r * (ncb + 1) + cb + 1], y[r]}; },
       [&](int c, float v, float yr) {
@@ -679,7 +723,7 @@ __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int
   const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
   float acc = 0.0f;
   float *dst = part + (size_t)pr * nrows;
-  walk_rows<GL, NG>(
+  walk_rows<GL, NG, int>(
       ((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nset * SCW * RPWV, nrows, lane, col, val,
       [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb0], cbptr[r * (ncb + 1) + cb1], 0.0f}; },
       [&](int c, float v, float) { acc += v * xblk[c - c0]; },
@@ -730,12 +774,18 @@ int spmv_blocks(dazim_ctx *ctx, int64_t nrows, int64_t nx = -1) {
 // nx = length of the gathered vector; nblocks must come from spmv_blocks(ctx, nrows, nx)
 int launch_spmv(dazim_ctx *ctx, int64_t nrows, int64_t nx, const int64_t *ptr, const int *idx, const float *val,
                 const float *x, float *out, const float *beta_p, float beta_sign, double *sumsq,
-                int nblocks, const int *guard = nullptr) {
+                int nblocks, const int *guard = nullptr, const unsigned short *idx16 = nullptr) {
   if (use_ldsx(ctx, nrows, nx)) {
     const size_t lds = (size_t)((nx + 3) & ~(int64_t)3) * 4;
-    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(spmv_rows_ldsx, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x, out,
-                       beta_p, beta_sign, sumsq, guard);
+    if (idx16) {   // 16-bit column indices: 6 bytes per stored entry
+      DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(spmv_rows_ldsx<unsigned short>, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx16, val,
+                         x, out, beta_p, beta_sign, sumsq, guard);
+    } else {
+      DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_ldsx<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(spmv_rows_ldsx<int>, dim3(nblocks), dim3(64 * LWPB), lds, ctx->stream, nrows, nx, ptr, idx, val, x, out,
+                         beta_p, beta_sign, sumsq, guard);
+    }
   } else {
     hipLaunchKernelGGL(spmv_rows, dim3(nblocks), dim3(64 * WPB), 0, ctx->stream, nrows, ptr, idx, val, x, out,
                        beta_p, beta_sign, sumsq, guard);
@@ -805,8 +855,15 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
 }
 
 // column-block pointers + max|val| for the scatter form of A^T*y (needs canonical CSR)
-int build_colblocks(dazim_ctx *ctx, dazim_csr *A) {
+// cols_changed = false: only the values changed (row scaling) -- the 16-bit copy of the column indices is kept
+int build_colblocks(dazim_ctx *ctx, dazim_csr *A, bool cols_changed = true) {
   if (A->cbptr) { (void)hipFree(A->cbptr); A->cbptr = nullptr; }
+  if (cols_changed && A->col16) { (void)hipFree(A->col16); A->col16 = nullptr; }
+  if (!A->col16 && A->n <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"])) {
+    DZ_HIP(hipMalloc((void **)&A->col16, (size_t)((A->nnz + 3) & ~(int64_t)3) * 2));
+    hipLaunchKernelGGL(k_narrow_cols, dim3(nblk((A->nnz + 3) / 4)), dim3(VB), 0, ctx->stream, A->nnz, A->col, A->col16);
+    DZ_HIP(hipGetLastError());
+  }
   A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
   A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
   const int64_t np = A->m * (A->ncb + 1);
@@ -839,6 +896,7 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
                  float beta_sign, double *sumsq, int *npart, const int *guard = nullptr) {
   const double pm = (double)A->vmax * (double)ymax;
   ctx->ksec["spmvt.kind"] = (use_scatter(ctx, A) && std::isfinite(pm)) ? 1 : 0;
+  ctx->ksec["spmvt.idx_bytes"] = (A->col16 && use_scatter(ctx, A) && std::isfinite(pm)) ? 2 : 4;
   // non-finite values (NaN / Inf in G or y) cannot be put on the fixed-point grid: the gather form propagates them like
   // the reference's plain loop would
   if (!use_scatter(ctx, A) || !std::isfinite(pm)) {
@@ -868,15 +926,19 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
   bool shortseg = A->nnz < (int64_t)400 * A->m * A->ncb;   // measured: 16 lanes win at 141 and 296 entries per segment, 64 at 553
   if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
-  if (shortseg) {
-    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((spmvT_scatter<16, 2>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part, guard);
+  const dim3 sgrid(nchunk * A->ncb), sblock(64 * SCW);
+#define DZ_SCATTER(GL_, NG_, IT_, COLP_)                                                                                        \
+  do {                                                                                                                          \
+    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<GL_, NG_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((spmvT_scatter<GL_, NG_, IT_>), sgrid, sblock, lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw, A->n,       \
+                       A->cbptr, COLP_, A->val, y, scale, part, guard);                                                         \
+  } while (0)
+  if (A->col16) {   // 16-bit column indices: 6 bytes per stored entry
+    if (shortseg) DZ_SCATTER(16, 2, unsigned short, A->col16); else DZ_SCATTER(64, 4, unsigned short, A->col16);
   } else {
-    DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((spmvT_scatter<64, 4>), dim3(nchunk * A->ncb), dim3(64 * SCW), lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw,
-                       A->n, A->cbptr, A->col, A->val, y, scale, part, guard);
+    if (shortseg) DZ_SCATTER(16, 2, int, A->col); else DZ_SCATTER(64, 4, int, A->col);
   }
+#undef DZ_SCATTER
   const int nb = nblk(A->n, NPART);
   hipLaunchKernelGGL(k_scatter_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->n, nchunk, part, 1.0 / scale, out, beta_p,
                      beta_sign, sumsq, guard);
@@ -893,10 +955,11 @@ bool use_blocked(dazim_ctx *ctx, const dazim_csr *A) {
 int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out, const float *beta_p, float beta_sign,
                  double *sumsq, int *npart, const int *guard = nullptr) {
   ctx->ksec["spmv.kind"] = use_blocked(ctx, A) ? 2 : (use_ldsx(ctx, A->m, A->n) ? 1 : 0);
+  ctx->ksec["spmv.idx_bytes"] = (A->col16 && !use_blocked(ctx, A) && use_ldsx(ctx, A->m, A->n)) ? 2 : 4;   // index bytes streamed per entry
   if (!use_blocked(ctx, A)) {
     const int gm = spmv_blocks(ctx, A->m, A->n);
     if (npart) *npart = gm;
-    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm, guard);
+    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm, guard, A->col16);
   }
   const int npair = (A->ncb + 1) / 2;
   int nset = ctx->num_cu / npair;
@@ -1099,7 +1162,7 @@ int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
   if (!A) return 0;
   if (ctx) DZ_HIP(hipStreamSynchronize(ctx->stream));   // (a matrix may outlive its context: the arrays are still freed)
   else (void)hipDeviceSynchronize();
-  void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr};
+  void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr, A->col16};
   for (void *p : ps)
     if (p) (void)hipFree(p);
   delete A;
@@ -1286,7 +1349,7 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   if (A->tperm) hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  return build_colblocks(ctx, A);
+  return build_colblocks(ctx, A, false);
 }
 
 int dazim_csr_col_abs_sums(dazim_ctx *ctx, const dazim_csr *A, float *out_u) {
@@ -1771,7 +1834,7 @@ int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *o
     DZ_HIP(hipGetLastError());
   }
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  if (G && (rc = build_colblocks(ctx, G))) return rc;
+  if (G && (rc = build_colblocks(ctx, G, false))) return rc;
   if (stats) {
     double a[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < nb; b++)
