@@ -554,6 +554,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
 }  // namespace
 
 struct dazim_csr;  // sparse.hip
+extern "C" void dz_csr_set_capacity(dazim_csr *A, int64_t cap_m, int64_t cap_nnz);
 extern "C" int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
                                float *val, dazim_csr **out);
 
@@ -646,7 +647,11 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = dz_scratch(ctx, "rays.lval", nr1 * A.LK * 4 * (joint ? 3 : 1), &p))) return rc;
   A.lval = (float *)p;
   int64_t *rowptr = nullptr;
-  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + 1) * 8));
+  // the caller may announce rows it is going to append (regularisation): the CSR arrays then get that much slack and
+  // dazim_csr_append_coo writes behind the ray rows instead of reallocating and copying the matrix
+  const int64_t res_rows = ctx->opts.count("csr.reserve_rows") && ctx->opts["csr.reserve_rows"] > 0 ? ctx->opts["csr.reserve_rows"] : 0;
+  const int64_t res_nnz = ctx->opts.count("csr.reserve_nnz") && ctx->opts["csr.reserve_nnz"] > 0 ? ctx->opts["csr.reserve_nnz"] : 0;
+  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + res_rows + 1) * 8));
   A.dsurf = dsurf.dev;
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
@@ -692,8 +697,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   }
   float *val = nullptr;
   int *col = nullptr;
-  DZ_HIP(hipMalloc((void **)&val, (size_t)(nnz > 0 ? nnz : 1) * 4));
-  DZ_HIP(hipMalloc((void **)&col, (size_t)(nnz > 0 ? nnz : 1) * 4));
+  const int64_t cap_nnz = nnz + res_nnz;   // (options csr.reserve_rows / csr.reserve_nnz: room for rows appended later)
+  DZ_HIP(hipMalloc((void **)&val, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4));
+  DZ_HIP(hipMalloc((void **)&col, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4));
   A.val = val;
   A.col = col;
   if (nray > 0) {
@@ -727,7 +733,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     return err;
   }
   const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1);
-  return dazim_csr_adopt(ctx, m, n, nnz, rowptr, col, val, G);
+  int rca = dazim_csr_adopt(ctx, m, n, nnz, rowptr, col, val, G);
+  if (!rca && (res_rows > 0 || res_nnz > 0)) dz_csr_set_capacity(*G, m + res_rows, cap_nnz);
+  return rca;
 }
 
 // = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields

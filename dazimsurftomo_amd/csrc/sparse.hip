@@ -26,6 +26,11 @@ struct dazim_csr {
   // the same column indices in 16 bits when n <= 65536 (the S-256 matrix): the two products of an LSMR iteration stream
   // 6 instead of 8 bytes per stored entry.  Built with the column blocks; nullptr otherwise.
   unsigned short *col16 = nullptr;
+  int64_t col16_cap = 0;                         // entries col16 can hold
+  // rows / entries the arrays rowptr (cap_m + 1), col and val (cap_nnz) can hold: rays_build_G allocates them with the slack
+  // the options csr.reserve_rows / csr.reserve_nnz ask for, so that the regularisation rows are appended in place
+  // (0: exactly m / nnz)
+  int64_t cap_m = 0, cap_nnz = 0;
 };
 
 namespace {
@@ -855,13 +860,26 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
 }
 
 // column-block pointers + max|val| for the scatter form of A^T*y (needs canonical CSR)
-// cols_changed = false: only the values changed (row scaling) -- the 16-bit copy of the column indices is kept
-int build_colblocks(dazim_ctx *ctx, dazim_csr *A, bool cols_changed = true) {
+// changed_from: first entry whose column index is new (0: all of them; < 0: only values changed, e.g. row scaling) -- the
+// 16-bit copy of the column indices is extended / kept accordingly
+int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
   if (A->cbptr) { (void)hipFree(A->cbptr); A->cbptr = nullptr; }
-  if (cols_changed && A->col16) { (void)hipFree(A->col16); A->col16 = nullptr; }
-  if (!A->col16 && A->n <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"])) {
-    DZ_HIP(hipMalloc((void **)&A->col16, (size_t)((A->nnz + 3) & ~(int64_t)3) * 2));
-    hipLaunchKernelGGL(k_narrow_cols, dim3(nblk((A->nnz + 3) / 4)), dim3(VB), 0, ctx->stream, A->nnz, A->col, A->col16);
+  const bool want16 = A->n <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"]);
+  if (A->col16 && (!want16 || A->col16_cap < A->nnz || changed_from == 0)) {
+    (void)hipFree(A->col16);
+    A->col16 = nullptr;
+    A->col16_cap = 0;
+  }
+  if (want16 && (!A->col16 || changed_from >= 0)) {
+    int64_t from = 0;
+    if (!A->col16) {
+      A->col16_cap = ((A->cap_nnz > A->nnz ? A->cap_nnz : A->nnz) + 3) & ~(int64_t)3;
+      DZ_HIP(hipMalloc((void **)&A->col16, (size_t)A->col16_cap * 2));
+    } else {
+      from = changed_from & ~(int64_t)3;
+    }
+    const int64_t cnt = A->nnz - from;
+    if (cnt > 0) hipLaunchKernelGGL(k_narrow_cols, dim3(nblk((cnt + 3) / 4)), dim3(VB), 0, ctx->stream, cnt, A->col + from, A->col16 + from);
     DZ_HIP(hipGetLastError());
   }
   A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
@@ -1289,6 +1307,21 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   dazim_csr *B = nullptr;
   if ((rc = dazim_csr_from_coo(ctx, extra_m > 0 ? extra_m : 1, A->n, nnz2, shifted, icol_u, rw_u, &B))) return rc;
   const int64_t m2 = A->m + extra_m, nz2 = A->nnz + nnz2;
+  if (A->cap_m >= m2 && A->cap_nnz >= nz2) {   // the arrays were allocated with room for these rows: append in place
+    const int64_t nnz1 = A->nnz;
+    if (extra_m > 0)
+      hipLaunchKernelGGL(k_offset_ptr, dim3(nblk(extra_m + 1)), dim3(VB), 0, ctx->stream, extra_m + 1, B->rowptr, A->nnz, A->rowptr + A->m);
+    DZ_HIP(hipMemcpyAsync(A->col + nnz1, B->col, (size_t)nnz2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(A->val + nnz1, B->val, (size_t)nnz2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    dazim_csr_free(ctx, B);
+    A->m = m2;
+    A->nnz = nz2;
+    if ((rc = build_colblocks(ctx, A, nnz1 > 0 ? nnz1 : 0))) return rc;
+    if ((rc = invalidate_transpose(A))) return rc;
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
   int64_t *rowptr;
   int *col;
   float *val;
@@ -1309,10 +1342,18 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   (void)hipFree(A->val);
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
+  A->cap_m = A->cap_nnz = 0;
   if ((rc = build_colblocks(ctx, A))) return rc;
   if ((rc = invalidate_transpose(A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+// (library-internal) the arrays a matrix has adopted are larger than m / nnz: see dazim_csr::cap_m
+extern "C" void dz_csr_set_capacity(dazim_csr *A, int64_t cap_m, int64_t cap_nnz) {
+  if (!A) return;
+  A->cap_m = cap_m;
+  A->cap_nnz = cap_nnz;
 }
 
 // copy the matrix out as the reference's COO triplets (1-based), rows ascending
@@ -1349,7 +1390,7 @@ int dazim_csr_scale_rows(dazim_ctx *ctx, dazim_csr *A, const float *w_u) {
   if (A->tperm) hipLaunchKernelGGL(k_gather_f, dim3(nblk(A->nnz)), dim3(VB), 0, ctx->stream, A->nnz, A->tperm, A->val, A->tval);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  return build_colblocks(ctx, A, false);
+  return build_colblocks(ctx, A, -1);
 }
 
 int dazim_csr_col_abs_sums(dazim_ctx *ctx, const dazim_csr *A, float *out_u) {
@@ -1790,6 +1831,7 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   (void)hipFree(A->val);
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
+  A->cap_m = A->cap_nnz = 0;
   if ((rc = build_colblocks(ctx, A))) return rc;
   if ((rc = invalidate_transpose(A))) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1834,7 +1876,7 @@ int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *o
     DZ_HIP(hipGetLastError());
   }
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  if (G && (rc = build_colblocks(ctx, G, false))) return rc;
+  if (G && (rc = build_colblocks(ctx, G, -1))) return rc;
   if (stats) {
     double a[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < nb; b++)

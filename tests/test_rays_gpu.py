@@ -102,7 +102,24 @@ def test_G_matches_oracle(ctx, orc, nx, ny, depz, kmax, minthk):
     y = np.zeros(m + c3, np.float32); yo = y.copy()
     ctx.aprod(1, G, x, y); orc.aprod(1, m + c3, n, x.copy(), yo, irT, icT, rwT)
     assert np.linalg.norm(y - yo) <= 1e-4 * np.linalg.norm(yo)
+    # the same matrix with the regularisation rows announced beforehand (options csr.reserve_*): they are appended in place,
+    # behind the ray rows, instead of by reallocating and copying G -- identical triplets and products
+    coo = G.to_coo()
     G.free()
+    try:
+        ctx.set_option("csr.reserve_rows", int(c3))
+        ctx.set_option("csr.reserve_nnz", int(len(rwT) - len(rw_o)))
+        G2, _, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    finally:
+        ctx.set_option("csr.reserve_rows", 0)
+        ctx.set_option("csr.reserve_nnz", 0)
+    G2.append_coo(c3, irT[len(rw_o):], icT[len(rw_o):], rwT[len(rw_o):])
+    coo2 = G2.to_coo()
+    assert all(np.array_equal(a, b) for a, b in zip(coo, coo2))
+    y2 = np.zeros(m + c3, np.float32)
+    ctx.aprod(1, G2, x, y2)
+    assert np.array_equal(y, y2)
+    G2.free()
 
 
 def test_receiver_outside_is_an_error(ctx, orc):
