@@ -75,7 +75,15 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * applying the inversion's second threshold |row| > ftol (inv/CalSurfG.f90:1353).  "rays.lcap": capacity of the per-ray LDS
  * cell list (default min(cells, 1024)); small values exercise the full-grid-sweep and retrace fallbacks.
  * "spmv.ldsx", "spmv.blocked", "spmv.scatter": 0 = do not use the LDS-staged A*x (whole x / per column-block pair) or
- * the fixed-point scatter A^T*y, i.e. fall back to the plain wavefront-per-row gather kernels (tests compare the two). */
+ * the fixed-point scatter A^T*y, i.e. fall back to the plain wavefront-per-row gather kernels (tests compare the two).
+ * "spmv.col16": 0 = keep 32-bit column indices in the products (default: a 16-bit copy is streamed when n <= 65536).
+ * "csr.reserve_rows" / "csr.reserve_nnz": rows / entries the caller is going to append to the next matrix that
+ * dazim_rays_build_G* returns (regularisation rows): its arrays get that much room and dazim_csr_append_coo appends in place.
+ * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
+ * "fmm.wg_per_cu": resident eikonal workgroups per CU (measurement).  "disp.ffwd": 0 = the first period's bracket search goes
+ * step by step from its start value like the reference's (default: it jumps to the bracket that a parallel evaluation of the
+ * same grid points found for the column's model; identical results).  "disp.pchunk": periods per
+ * task of the dispersion kernel (default: all).  "disp.rden": 0 = keep the divisions of the sub-layer interpolation. */
 int dazim_set_option(dazim_ctx *ctx, const char *name, int value);
 
 /* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */

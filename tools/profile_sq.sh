@@ -1,0 +1,14 @@
+#!/bin/bash
+# Issue / wait counters per kernel (one rocprofv3 --pmc pass of a 1-step bench run; counters only): tools/profile_sq.sh <tag>
+#   -> gpurun_out/sq_<tag>.md (copy to profiles/<round>_sq_counters.md)
+tag=${1:-x}
+root=$PWD
+out=$root/gpurun_out
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+  --output-format csv -d $out/pmc_sq_$tag -- python $root/bench.py --no-cpu --steps 1 --warmup 0 > $out/pmc_sq_$tag.log 2>&1
+cd $root
+python tools/sq_summary.py $out/pmc_sq_$tag > $out/sq_$tag.md
+rm -rf $out/pmc_sq_$tag
+head -12 $out/sq_$tag.md
