@@ -23,10 +23,13 @@ struct dazim_csr {
   int ncb = 0, cbw = 0;                          // number of column blocks, block width
   int64_t *cbptr = nullptr;
   float vmax = 0.0f;                             // max |val|, sets the fixed-point scale
-  // the same column indices in 16 bits when n <= 65536 (the S-256 matrix): the two products of an LSMR iteration stream
-  // 6 instead of 8 bytes per stored entry.  Built with the column blocks; nullptr otherwise.
+  // the same column indices in 16 bits: the two products of an LSMR iteration stream 6 instead of 8 bytes per stored entry.
+  // col16_mod = 0: the column itself (n <= 65536, the S-256 matrix); col16_mod = 2*cbw > 0: the column relative to the first
+  // column of its PAIR of column blocks (larger n: the scatter kernel works on one block, the blocked A*x on a pair).
+  // Built with the column blocks; nullptr when not used.
   unsigned short *col16 = nullptr;
   int64_t col16_cap = 0;                         // entries col16 can hold
+  int col16_mod = 0;
   // rows / entries the arrays rowptr (cap_m + 1), col and val (cap_nnz) can hold: rays_build_G allocates them with the slack
   // the options csr.reserve_rows / csr.reserve_nnz ask for, so that the regularisation rows are appended in place
   // (0: exactly m / nnz)
@@ -538,14 +541,15 @@ __global__ void k_colblock_ptr(int64_t nrows, int ncb, int cbw, const int64_t *_
   cbptr[t] = lo;
 }
 constexpr int APART = 2048;   // partial maxima (enough workgroups to stream at HBM rate)
-// 32-bit -> 16-bit column indices, four per thread step
-__global__ void k_narrow_cols(int64_t n, const int *__restrict__ col, unsigned short *__restrict__ col16) {
+// 32-bit -> 16-bit column indices, four per thread step; mod > 0: relative to the pair of column blocks (column mod 2*cbw)
+__global__ void k_narrow_cols(int64_t n, const int *__restrict__ col, unsigned short *__restrict__ col16, int mod) {
   for (int64_t i = ((int64_t)blockIdx.x * VB + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * VB * 4) {
     if (i + 3 < n) {
-      const int4 c = *reinterpret_cast<const int4 *>(col + i);
+      int4 c = *reinterpret_cast<const int4 *>(col + i);
+      if (mod > 0) { c.x %= mod; c.y %= mod; c.z %= mod; c.w %= mod; }
       *reinterpret_cast<ushort4 *>(col16 + i) = make_ushort4((unsigned short)c.x, (unsigned short)c.y, (unsigned short)c.z, (unsigned short)c.w);
     } else {
-      for (int64_t j = i; j < n; j++) col16[j] = (unsigned short)col[j];
+      for (int64_t j = i; j < n; j++) col16[j] = (unsigned short)(mod > 0 ? col[j] % mod : col[j]);
     }
   }
 }
@@ -659,11 +663,13 @@ template <int GL, int NG, class IT>
 __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
                                                           const int64_t *__restrict__ cbptr, const IT *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
-                                                          double scale, long long *__restrict__ part, const int *__restrict__ guard) {
+                                                          double scale, long long *__restrict__ part, const int *__restrict__ guard,
+                                                          int pairlocal) {
   extern __shared__ __attribute__((aligned(16))) long long acc[];
   if (guard && *guard) return;
   const int chunk = blockIdx.x / ncb, cb = blockIdx.x - chunk * ncb;
   const int c0 = cb * cbw;
+  const int csub = pairlocal ? (cb & 1) * cbw : c0;    // what to take off a stored index to get the accumulator
   const int width = (int)((ncols - c0) < cbw ? (ncols - c0) : cbw);
   for (int i = threadIdx.x; i < width; i += 64 * SCW) acc[i] = 0;
   __syncthreads();
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
       ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nchunk * SCW * RPWV, nrows, lane, col, val,
       [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb], cbptr[r * (ncb + 1) + cb + 1], y[r]}; },
       [&](int c, float v, float yr) {
-        atomicAdd((unsigned long long *)&acc[c - c0],
+        atomicAdd((unsigned long long *)&acc[c - csub],
                   (unsigned long long)(__double_as_longlong(fma((double)(v * yr), scale, MAGIC)) - __double_as_longlong(MAGIC)));
       },
       [](int64_t, float) {});
@@ -711,16 +717,17 @@ __global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__
 // pointers as the scatter kernel, two scatter blocks (<= 38 K floats of x) per workgroup, which removes the per-entry
 // cache-line gather that bounds the plain kernel.  A workgroup owns (row set x column-block pair) and writes the partial
 // dot product of each of its rows to part[pair][row]; k_rows_combine adds the pairs in a fixed order.
-template <int GL, int NG>
+template <int GL, int NG, class IT>
 __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int nset, int npair, int ncb, int cbw, int64_t ncols,
-                                                              const int64_t *__restrict__ cbptr, const int *__restrict__ col,
+                                                              const int64_t *__restrict__ cbptr, const IT *__restrict__ col,
                                                               const float *__restrict__ val, const float *__restrict__ x,
-                                                              float *__restrict__ part, const int *__restrict__ guard) {
+                                                              float *__restrict__ part, const int *__restrict__ guard, int pairlocal) {
   extern __shared__ __attribute__((aligned(16))) float xblk[];
   if (guard && *guard) return;
   const int set = blockIdx.x / npair, pr = blockIdx.x - set * npair;
   const int cb0 = 2 * pr, cb1 = (cb0 + 2 < ncb) ? cb0 + 2 : ncb;
   const int c0 = cb0 * cbw;
+  const int csub = pairlocal ? 0 : c0;                 // (16-bit indices of large matrices are already relative to the pair)
   const int width = (int)((ncols - c0) < 2 * (int64_t)cbw ? (ncols - c0) : 2 * (int64_t)cbw);
   for (int i = threadIdx.x; i < width; i += 64 * SCW) xblk[i] = x[c0 + i];
   __syncthreads();
@@ -728,10 +735,10 @@ __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int
   const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
   float acc = 0.0f;
   float *dst = part + (size_t)pr * nrows;
-  walk_rows<GL, NG, int>(
+  walk_rows<GL, NG, IT>(
       ((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nset * SCW * RPWV, nrows, lane, col, val,
       [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb0], cbptr[r * (ncb + 1) + cb1], 0.0f}; },
-      [&](int c, float v, float) { acc += v * xblk[c - c0]; },
+      [&](int c, float v, float) { acc += v * xblk[c - csub]; },
       [&](int64_t r, float) {
         float a = acc;
 #pragma unroll
@@ -864,8 +871,11 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
 // 16-bit copy of the column indices is extended / kept accordingly
 int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
   if (A->cbptr) { (void)hipFree(A->cbptr); A->cbptr = nullptr; }
-  const bool want16 = A->n <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"]);
-  if (A->col16 && (!want16 || A->col16_cap < A->nnz || changed_from == 0)) {
+  A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
+  A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
+  const int mod16 = A->n <= 65536 ? 0 : 2 * A->cbw;       // 16-bit indices: the column, or the column within its block pair
+  const bool want16 = mod16 <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"]);
+  if (A->col16 && (!want16 || A->col16_cap < A->nnz || changed_from == 0 || A->col16_mod != mod16)) {
     (void)hipFree(A->col16);
     A->col16 = nullptr;
     A->col16_cap = 0;
@@ -875,15 +885,15 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
     if (!A->col16) {
       A->col16_cap = ((A->cap_nnz > A->nnz ? A->cap_nnz : A->nnz) + 3) & ~(int64_t)3;
       DZ_HIP(hipMalloc((void **)&A->col16, (size_t)A->col16_cap * 2));
+      A->col16_mod = mod16;
     } else {
       from = changed_from & ~(int64_t)3;
     }
     const int64_t cnt = A->nnz - from;
-    if (cnt > 0) hipLaunchKernelGGL(k_narrow_cols, dim3(nblk((cnt + 3) / 4)), dim3(VB), 0, ctx->stream, cnt, A->col + from, A->col16 + from);
+    if (cnt > 0)
+      hipLaunchKernelGGL(k_narrow_cols, dim3(nblk((cnt + 3) / 4)), dim3(VB), 0, ctx->stream, cnt, A->col + from, A->col16 + from, mod16);
     DZ_HIP(hipGetLastError());
   }
-  A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
-  A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
   const int64_t np = A->m * (A->ncb + 1);
   if (np > 0) {   // a matrix without rows (an empty ray batch) has no block pointers
     DZ_HIP(hipMalloc((void **)&A->cbptr, (size_t)np * 8));
@@ -949,7 +959,7 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   do {                                                                                                                          \
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<GL_, NG_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((spmvT_scatter<GL_, NG_, IT_>), sgrid, sblock, lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw, A->n,       \
-                       A->cbptr, COLP_, A->val, y, scale, part, guard);                                                         \
+                       A->cbptr, COLP_, A->val, y, scale, part, guard, (sizeof(IT_) == 2 && A->col16_mod > 0) ? 1 : 0);                               \
   } while (0)
   if (A->col16) {   // 16-bit column indices: 6 bytes per stored entry
     if (shortseg) DZ_SCATTER(16, 2, unsigned short, A->col16); else DZ_SCATTER(64, 4, unsigned short, A->col16);
@@ -973,11 +983,13 @@ bool use_blocked(dazim_ctx *ctx, const dazim_csr *A) {
 int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out, const float *beta_p, float beta_sign,
                  double *sumsq, int *npart, const int *guard = nullptr) {
   ctx->ksec["spmv.kind"] = use_blocked(ctx, A) ? 2 : (use_ldsx(ctx, A->m, A->n) ? 1 : 0);
-  ctx->ksec["spmv.idx_bytes"] = (A->col16 && !use_blocked(ctx, A) && use_ldsx(ctx, A->m, A->n)) ? 2 : 4;   // index bytes streamed per entry
+  // index bytes streamed per entry (the whole-x LDS kernel needs the column itself, the blocked one takes either form)
+  ctx->ksec["spmv.idx_bytes"] = (A->col16 && (use_blocked(ctx, A) || (use_ldsx(ctx, A->m, A->n) && A->col16_mod == 0))) ? 2 : 4;
   if (!use_blocked(ctx, A)) {
     const int gm = spmv_blocks(ctx, A->m, A->n);
     if (npart) *npart = gm;
-    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm, guard, A->col16);
+    return launch_spmv(ctx, A->m, A->n, A->rowptr, A->col, A->val, x, out, beta_p, beta_sign, sumsq, gm, guard,
+                       A->col16_mod == 0 ? A->col16 : nullptr);
   }
   const int npair = (A->ncb + 1) / 2;
   int nset = ctx->num_cu / npair;
@@ -989,15 +1001,19 @@ int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out,
   const size_t lds = (size_t)A->cbw * 2 * 4;
   bool shortseg = A->nnz < (int64_t)600 * A->m * npair;    // measured: 16 lanes win at 282 and 519 entries per segment
   if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
-  if (shortseg) {
-    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((spmv_rows_blocked<16, 2>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
-                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part, guard);
+  const dim3 bgrid(nset * npair), bblock(64 * SCW);
+#define DZ_BLOCKED(GL_, NG_, IT_, COLP_)                                                                                        \
+  do {                                                                                                                          \
+    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<GL_, NG_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((spmv_rows_blocked<GL_, NG_, IT_>), bgrid, bblock, lds, ctx->stream, A->m, nset, npair, A->ncb, A->cbw, A->n, \
+                       A->cbptr, COLP_, A->val, x, part, guard, (sizeof(IT_) == 2 && A->col16_mod > 0) ? 1 : 0);                 \
+  } while (0)
+  if (A->col16) {   // 16-bit column indices: 6 bytes per stored entry
+    if (shortseg) DZ_BLOCKED(16, 2, unsigned short, A->col16); else DZ_BLOCKED(64, 4, unsigned short, A->col16);
   } else {
-    DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((spmv_rows_blocked<64, 4>), dim3(nset * npair), dim3(64 * SCW), lds, ctx->stream, A->m, nset, npair, A->ncb,
-                       A->cbw, A->n, A->cbptr, A->col, A->val, x, part, guard);
+    if (shortseg) DZ_BLOCKED(16, 2, int, A->col); else DZ_BLOCKED(64, 4, int, A->col);
   }
+#undef DZ_BLOCKED
   const int nb = nblk(A->m, NPART);
   hipLaunchKernelGGL(k_rows_combine, dim3(nb), dim3(VB), 0, ctx->stream, A->m, npair, part, out, beta_p, beta_sign, sumsq, guard);
   DZ_HIP(hipGetLastError());

@@ -76,7 +76,8 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * cell list (default min(cells, 1024)); small values exercise the full-grid-sweep and retrace fallbacks.
  * "spmv.ldsx", "spmv.blocked", "spmv.scatter": 0 = do not use the LDS-staged A*x (whole x / per column-block pair) or
  * the fixed-point scatter A^T*y, i.e. fall back to the plain wavefront-per-row gather kernels (tests compare the two).
- * "spmv.col16": 0 = keep 32-bit column indices in the products (default: a 16-bit copy is streamed when n <= 65536).
+ * "spmv.col16": 0 = keep 32-bit column indices in the products (default: a 16-bit copy is streamed -- the column itself
+ * when n <= 65536, else the column relative to its pair of column blocks).
  * "csr.reserve_rows" / "csr.reserve_nnz": rows / entries the caller is going to append to the next matrix that
  * dazim_rays_build_G* returns (regularisation rows): its arrays get that much room and dazim_csr_append_coo appends in place.
  * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
