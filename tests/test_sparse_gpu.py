@@ -197,3 +197,14 @@ def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n, m, per_row):
     ref = S.T @ y.astype(np.float64)
     assert np.linalg.norm(outs["fast"][1] - ref) <= np.linalg.norm(outs["gather"][1] - ref) * 1.5 + 1e-9
     A.free()
+    # the products stream a 16-bit copy of the column indices (the column itself up to n = 65536, above that the column
+    # relative to its pair of column blocks): same arithmetic in the same order as with the 32-bit indices -> identical bits
+    ctx.set_option("spmv.col16", 0)
+    try:
+        A32 = ctx.csr_from_coo(m, n, irow, icol, rw)
+    finally:
+        ctx.set_option("spmv.col16", 1)
+    y32 = np.zeros(m, np.float32); ctx.aprod(1, A32, x, y32)
+    x32 = np.zeros(n, np.float32); ctx.aprod(2, A32, x32, y)
+    assert np.array_equal(y32, outs["fast"][0]) and np.array_equal(x32, outs["fast"][1])
+    A32.free()
