@@ -388,8 +388,6 @@ def main():
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
         lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
-        ctx.set_option("csr.reserve_rows", int(c3))          # the regularisation rows appended below: no realloc + copy of G
-        ctx.set_option("csr.reserve_nnz", int(len(t_ir)))
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, d_sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")

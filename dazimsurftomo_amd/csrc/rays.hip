@@ -649,8 +649,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   int64_t *rowptr = nullptr;
   // the caller may announce rows it is going to append (regularisation): the CSR arrays then get that much slack and
   // dazim_csr_append_coo writes behind the ray rows instead of reallocating and copying the matrix
-  const int64_t res_rows = ctx->opts.count("csr.reserve_rows") && ctx->opts["csr.reserve_rows"] > 0 ? ctx->opts["csr.reserve_rows"] : 0;
-  const int64_t res_nnz = ctx->opts.count("csr.reserve_nnz") && ctx->opts["csr.reserve_nnz"] > 0 ? ctx->opts["csr.reserve_nnz"] : 0;
+  // By default: one regularisation row per model parameter with the 7-point stencil of inv/TikhRegul.f90 (a few MB).
+  int64_t res_rows = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1), res_nnz = 7 * res_rows;
+  if (ctx->opts.count("csr.reserve_rows") && ctx->opts["csr.reserve_rows"] > res_rows) res_rows = ctx->opts["csr.reserve_rows"];
+  if (ctx->opts.count("csr.reserve_nnz") && ctx->opts["csr.reserve_nnz"] > res_nnz) res_nnz = ctx->opts["csr.reserve_nnz"];
   DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + res_rows + 1) * 8));
   A.dsurf = dsurf.dev;
   A.rowptr = (const long *)rowptr;

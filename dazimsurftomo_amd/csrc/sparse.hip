@@ -1829,6 +1829,18 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   const int64_t m2 = A->m + nrow, nz2 = A->nnz + nnz2;
   if (nz2 > 0xfffffff0ll) return dz_fail(ctx, DAZIM_E_NNZ_OVERFLOW, "too many stored entries");
+  if (A->cap_m >= m2 && A->cap_nnz >= nz2) {   // dazim_rays_build_G left room for these rows: generate them behind the ray rows
+    const int64_t nnz1 = A->nnz;
+    hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
+                       A->rowptr + A->m, A->col, A->val);
+    DZ_HIP(hipGetLastError());
+    A->m = m2;
+    A->nnz = nz2;
+    if ((rc = build_colblocks(ctx, A, nnz1 > 0 ? nnz1 : 0))) return rc;
+    if ((rc = invalidate_transpose(A))) return rc;
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
   int64_t *rowptr;
   int *col;
   float *val;
