@@ -41,6 +41,8 @@ struct RayArgs {
   const float *vels;       // [nz][ny][nx]
   const double *svs, *svp, *srho;  // [nz][kmax][nx*ny]
   const float *lsen;       // joint mode: Lsen_Gsc [nz-1][kmax][nx*ny] (fp32, inv/CalSurfGAniso_Joint.f90:337)
+  // double-precision reciprocals RN(1/d) of the loop-invariant fp32 divisors (grid spacings and 2*EARTH*spacing): see divr()
+  double r_dnx, r_dnz, r_dnxr, r_dnzr, r_dvx, r_dvz, r_e2dnx, r_e2dnxr;
   float dplh;              // min cell size (before the 0.5 factor), host libm
   float *dsurf;            // [nray]
   int *status;             // [nray]
@@ -106,6 +108,15 @@ __device__ __forceinline__ void step_azimuth(float x0, float z0, float x1, float
   s2psi = (float)sin((double)(2.0f * rgpsi));
 }
 
+// x / d, correctly rounded, for a divisor whose double-precision reciprocal rd = RN(1/d) is at hand: three instructions
+// (convert, multiply, convert) instead of the ~11 of the IEEE fp32 division sequence -- a fifth to a third of this kernel was
+// divisions by grid spacings.  Exact for EVERY x: the double product is within 2^-52 (relative) of x/d, and the quotient of two
+// 24-bit numbers X/D is either a 24-bit number itself or at least 1/(D*M) >= 2^-49 (relative) away from every rounding
+// boundary M of the 24-bit format (|X*2^k - D*M| is a non-zero integer; a quotient cannot sit exactly on a boundary, because
+// X = D'*M with an odd 25-bit M would need more than 24 bits), so rounding the double to fp32 rounds where the exact quotient
+// rounds.  Infinities, NaNs and zeros come out as the division's.
+__device__ __forceinline__ float divr(float x, double rd) { return (float)((double)x * rd); }
+
 __device__ __forceinline__ void basis(float v, float b[4]) {  // inv/CalSurfG.f90:2145-2148
   const float om = 1.0f - v;
   b[0] = om * om * om / 6.0f;
@@ -114,18 +125,8 @@ __device__ __forceinline__ void basis(float v, float b[4]) {  // inv/CalSurfG.f9
   b[3] = v * v * v / 6.0f;
 }
 
-// x / 6.0f, correctly rounded, in three instructions instead of the ~10 of the IEEE division sequence: q = x*r, then one fused
-// correction step, r = RN(1/6).  Equal to RN(x/6) for every float with 3.9e-31 <= |x| <= 2.5e30 (tools/check_fastdiv.c 6 1:
-// 0 mismatches of 1 694 498 816) and for 0; anything else takes the division.
-__device__ __forceinline__ float div6(float x) {
-  const float ax = fabsf(x);
-  if (ax == 0.0f || (ax >= 1.0e-30f && ax <= 1.0e30f)) {
-    const float r = 1.0f / 6.0f;
-    const float q = x * r;
-    return __builtin_fmaf(__builtin_fmaf(-6.0f, q, x), r, q);
-  }
-  return x / 6.0f;
-}
+// x / 6.0f through divr (the reciprocal is a compile-time constant)
+__device__ __forceinline__ float div6(float x) { return divr(x, 1.0 / 6.0); }
 // element i (0..3) of the cubic B-spline basis at v, inv/CalSurfG.f90:2145-2148: only the selected numerator is divided
 // (the kernel is bound by instruction issue; the four divisions of the plain form were a fifth of a step)
 __device__ __forceinline__ float basis1(float v, int i) {
@@ -138,14 +139,15 @@ __device__ __forceinline__ float basis1(float v, int i) {
 }
 
 // bilinear velocity inside coarse cell (ipx,ipz), inv/CalSurfG.f90:2129-2137
-__device__ __forceinline__ float vel_at(const dazim_geom &g, const float *veln, int ipx, int ipz, float drx, float drz) {
+__device__ __forceinline__ float vel_at(const dazim_geom &g, const float *veln, int ipx, int ipz, float drx, float drz,
+                                        double rdnx, double rdnz) {
   float vel = 0.0f;
 #pragma unroll
   for (int l = 1; l <= 2; l++)
 #pragma unroll
     for (int m = 1; m <= 2; m++) {
-      float produ = (1.0f - fabsf(((float)(m - 1) * g.dnz - drz) / g.dnz));
-      produ = produ * (1.0f - fabsf(((float)(l - 1) * g.dnx - drx) / g.dnx));
+      float produ = (1.0f - fabsf(divr((float)(m - 1) * g.dnz - drz, rdnz)));
+      produ = produ * (1.0f - fabsf(divr((float)(l - 1) * g.dnx - drx, rdnx)));
       if (ipz - 1 + m <= g.nnz && ipx - 1 + l <= g.nnx && ipz - 1 + m >= 1 && ipx - 1 + l >= 1)
         vel = vel + veln[(size_t)(ipx - 2 + l) * g.nnz + (ipz - 2 + m)] * produ;
     }
@@ -153,7 +155,8 @@ __device__ __forceinline__ float vel_at(const dazim_geom &g, const float *veln, 
 }
 
 // bilinear(nv,dsx,dsz), inv/CalSurfG.f90:2293 -- velocity at a point of cell (cx,cz)
-__device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *veln, int cx, int cz, float px, float pz) {
+__device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *veln, int cx, int cz, float px, float pz,
+                                            double rdnx, double rdnz) {
   const float drx = (px - g.gox) - (float)(cx - 1) * g.dnx;
   const float drz = (pz - g.goz) - (float)(cz - 1) * g.dnz;
   float biv = 0.0f;
@@ -161,8 +164,8 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   for (int i = 1; i <= 2; i++)
 #pragma unroll
     for (int j = 1; j <= 2; j++) {
-      const float produ = (1.0f - fabsf(((float)(i - 1) * g.dnx - drx) / g.dnx)) *
-                          (1.0f - fabsf(((float)(j - 1) * g.dnz - drz) / g.dnz));
+      const float produ = (1.0f - fabsf(divr((float)(i - 1) * g.dnx - drx, rdnx))) *
+                          (1.0f - fabsf(divr((float)(j - 1) * g.dnz - drz, rdnz)));
       biv = biv + veln[(size_t)(cx - 2 + i) * g.nnz + (cz - 2 + j)] * produ;
     }
   return biv;
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
   float *gfdm = A.fdm_scratch + ((size_t)blockIdx.x * RPW + grp) * nf * NG;
   float *gfdmc = gfdm + nf, *gfdms = gfdm + 2 * nf;
   const float gox = g.gox, goz = g.goz, dnx = g.dnx, dnz = g.dnz, dvx = g.dvx, dvz = g.dvz;
+  const double rdnx = A.r_dnx, rdnz = A.r_dnz, rdnxr = A.r_dnxr, rdnzr = A.r_dnzr, rdvx = A.r_dvx, rdvz = A.r_dvz;
   const unsigned gmask_shift = grp * GP;
   // XCD-aware order (speed only): workgroup b runs on XCD b % 8, and the rays of one field read the
   // same traveltime grids, so each XCD gets one contiguous eighth of the ray quads
@@ -224,12 +228,12 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     int status = 0, rb = 0;
     // ---------------- srtimes, inv/CalSurfG.f90:1644-1711 ----------------
     if (!EMIT) {
-      int irx = (int)((rcx - gox) / dnx) + 1, irz = (int)((rcz - goz) / dnz) + 1;
+      int irx = (int)divr(rcx - gox, rdnx) + 1, irz = (int)divr(rcz - goz, rdnz) + 1;
       if (irx < 1 || irx > nnx || irz < 1 || irz > nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
       if (!status) {
         if (irx == nnx) irx--;
         if (irz == nnz) irz--;
-        const int isx = (int)((scx - gox) / dnx) + 1, isz = (int)((scz - goz) / dnz) + 1;
+        const int isx = (int)divr(scx - gox, rdnx) + 1, isz = (int)divr(scz - goz, rdnz) + 1;
         float sred = ((scx - rcx) * EARTH) * ((scx - rcx) * EARTH);
         const float e2 = (scz - rcz) * EARTH * dz_sinf(rcx);
         sred = sqrtf(sred + e2 * e2);
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         if (isx == irx && isz == irz) sw = true;
         float trr;
         if (sw) {
-          const float vs = bilin_cell(g, veln, isx, isz, scx, scz);
-          const float vr = bilin_cell(g, veln, irx, irz, rcx, rcz);
+          const float vs = bilin_cell(g, veln, isx, isz, scx, scz, rdnx, rdnz);
+          const float vr = bilin_cell(g, veln, irx, irz, rcx, rcz, rdnx, rdnz);
           trr = 2.0f * sred / (vs + vr);
         } else {
           const float drx = (rcx - gox) - (float)(irx - 1) * dnx;
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           for (int k = 1; k <= 2; k++)
 #pragma unroll
             for (int l = 1; l <= 2; l++) {
-              const float produ = (1.0f - fabsf(((float)(l - 1) * dnz - drz) / dnz)) *
-                                  (1.0f - fabsf(((float)(k - 1) * dnx - drx) / dnx));
+              const float produ = (1.0f - fabsf(divr((float)(l - 1) * dnz - drz, rdnz))) *
+                                  (1.0f - fabsf(divr((float)(k - 1) * dnx - drx, rdnx)));
               trr = trr + ttn[(size_t)(irx - 2 + k) * nnz + (irz - 2 + l)] * produ;
             }
         }
@@ -259,9 +263,9 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     // ---------------- rpaths, inv/CalSurfG.f90:1818-2236 ----------------
     const float goxr = bx.goxr, gozr = bx.gozr, dnxr = bx.dnxr, dnzr = bx.dnzr;
     const int nnxr = bx.nnxr, nnzr = bx.nnzr;
-    const int isx = (int)((scx - goxr) / dnxr) + 1, isz = (int)((scz - gozr) / dnzr) + 1;
+    const int isx = (int)divr(scx - goxr, rdnxr) + 1, isz = (int)divr(scz - gozr, rdnzr) + 1;
     const float dpl = 0.5f * A.dplh;
-    int ipx = (int)((rcx - gox) / dnx) + 1, ipz = (int)((rcz - goz) / dnz) + 1;
+    int ipx = (int)divr(rcx - gox, rdnx) + 1, ipz = (int)divr(rcz - goz, rdnz) + 1;
     if (ipx < 1 || ipx >= nnx || ipz < 1 || ipz >= nnz) status = DAZIM_E_RECEIVER_OUTSIDE;
     if (!status && saved < 0) {
       float x0 = rcx, z0 = rcz;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       float e2 = (scz - z0) * EARTH * sinx0;
       sred = sqrtf(sred + e2 * e2);
       if (sred < 2.0f * dpl) sw = 1;
-      int ipxr = (int)((rcx - goxr) / dnxr) + 1, ipzr = (int)((rcz - gozr) / dnzr) + 1;
+      int ipxr = (int)divr(rcx - goxr, rdnxr) + 1, ipzr = (int)divr(rcz - gozr, rdnzr) + 1;
       auto in_refined = [&](int px, int pz) -> int {
         if (px < 1 || px >= nnxr || pz < 1 || pz >= nnzr) return 0;
         const int *sp = nstsr + (size_t)(px - 1) * RM + (pz - 1);
@@ -316,14 +320,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         if (igref == 1) {
           dtx = tr10 - tr00;
           dtx = dtx + tr11 - tr01;
-          dtx = dtx / (2.0f * EARTH * dnxr);
+          dtx = divr(dtx, A.r_e2dnxr);
           dtz = tr01 - tr00;
           dtz = dtz + tr11 - tr10;
           dtz = dtz / (2.0f * EARTH * sinx0 * dnzr);
         } else {
           dtx = tc10 - tc00;
           dtx = dtx + tc11 - tc01;
-          dtx = dtx / (2.0f * EARTH * dnx);
+          dtx = divr(dtx, A.r_e2dnx);
           dtz = tc01 - tc00;
           dtz = dtz + tc11 - tc10;
           dtz = dtz / (2.0f * EARTH * sinx0 * dnz);
@@ -332,11 +336,11 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         float x1 = x0 - dpl * dtx / (EARTH * rd1);
         float z1 = z0 - dpl * dtz / (EARTH * sinx0 * rd1);
         const int ipxo = ipx, ipzo = ipz;
-        ipxr = (int)((x1 - goxr) / dnxr) + 1;
-        ipzr = (int)((z1 - gozr) / dnzr) + 1;
+        ipxr = (int)divr(x1 - goxr, rdnxr) + 1;
+        ipzr = (int)divr(z1 - gozr, rdnzr) + 1;
         igref = in_refined(ipxr, ipzr);
-        ipx = (int)((x1 - gox) / dnx) + 1;
-        ipz = (int)((z1 - goz) / dnz) + 1;
+        ipx = (int)divr(x1 - gox, rdnx) + 1;
+        ipz = (int)divr(z1 - goz, rdnz) + 1;
         float sinx1 = dz_sinf(x1);
         sred = ((scx - x1) * EARTH) * ((scx - x1) * EARTH);
         e2 = (scz - z1) * EARTH * sinx1;
@@ -386,12 +390,12 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         if (nhp == 2) vr1 = 1.0f;
         float drx = (x0 - gox) - (float)(ipxo - 1) * dnx;
         float drz = (z0 - goz) - (float)(ipzo - 1) * dnz;
-        float vel = vel_at(g, veln, ipxo, ipzo, drx, drz);
+        float vel = vel_at(g, veln, ipxo, ipzo, drx, drz, rdnx, rdnz);
         drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
         drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
-        float vi = basis1(drx / dvx, lm), wi[LPR];  // this lane's vi(m), wi(l)
+        float vi = basis1(divr(drx, rdvx), lm), wi[LPR];  // this lane's vi(m), wi(l)
 #pragma unroll
-        for (int q = 0; q < LPR; q++) wi[q] = basis1(drz / dvz, l0 + q * LSTEP);
+        for (int q = 0; q < LPR; q++) wi[q] = basis1(divr(drz, rdvz), l0 + q * LSTEP);
         int ivxt = ivxo, ivzt = ivzo;
         for (int k = 1; k <= nhp; k++) {
           const float velo = vel, vio = vi;
@@ -407,15 +411,15 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           const float vrp = (k == 2) ? vr0 : vr1;
           const float rigz = z0 + vrk * (z1 - z0);
           const float rigx = x0 + vrk * (x1 - x0);
-          const int ipxt = (int)((rigx - gox) / dnx) + 1, ipzt = (int)((rigz - goz) / dnz) + 1;
+          const int ipxt = (int)divr(rigx - gox, rdnx) + 1, ipzt = (int)divr(rigz - goz, rdnz) + 1;
           drx = (rigx - gox) - (float)(ipxt - 1) * dnx;
           drz = (rigz - goz) - (float)(ipzt - 1) * dnz;
-          vel = vel_at(g, veln, ipxt, ipzt, drx, drz);
+          vel = vel_at(g, veln, ipxt, ipzt, drx, drz, rdnx, rdnz);
           drx = (rigx - gox) - (float)(ivxt - 1) * dvx;
           drz = (rigz - goz) - (float)(ivzt - 1) * dvz;
-          vi = basis1(drx / dvx, lm);
+          vi = basis1(divr(drx, rdvx), lm);
 #pragma unroll
-          for (int q = 0; q < LPR; q++) wi[q] = basis1(drz / dvz, l0 + q * LSTEP);
+          for (int q = 0; q < LPR; q++) wi[q] = basis1(divr(drz, rdvz), l0 + q * LSTEP);
           const float dinc = (k == 1) ? vrk * dpl : (vrk - vrp) * dpl;
           // block of this sub-segment: cells (ivzt-2+l, ivxt-2+m), l,m = 1..4
           const int nbx = ivxt - 1, nbz = ivzt - 1;
@@ -622,6 +626,14 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     rd1 = g.dnz * EARTH * sinf(g.gox + (float)(g.nnx - 1) * g.dnx);
     if (rd1 < dpl) dpl = rd1;
     A.dplh = dpl;
+  }
+  {  // reciprocals of the loop-invariant divisors of the ray kernel (divr): the divisors as fp32 values the kernel would divide by
+    const float dnxr = g.dvx / (float)(GDX * 8), dnzr = g.dvz / (float)(GDZ * 8);   // = dazim_refbox::dnxr/dnzr (sgdl = 8, fmm.hip)
+    const float e2dnx = 2.0f * EARTH * g.dnx, e2dnxr = 2.0f * EARTH * dnxr;
+    A.r_dnx = 1.0 / (double)g.dnx;   A.r_dnz = 1.0 / (double)g.dnz;
+    A.r_dnxr = 1.0 / (double)dnxr;   A.r_dnzr = 1.0 / (double)dnzr;
+    A.r_dvx = 1.0 / (double)g.dvx;   A.r_dvz = 1.0 / (double)g.dvz;
+    A.r_e2dnx = 1.0 / (double)e2dnx; A.r_e2dnxr = 1.0 / (double)e2dnxr;
   }
   void *p;
   const int64_t m = nray;
