@@ -77,6 +77,47 @@ void dz_stage_put(dazim_ctx *ctx, void *p) {
   (void)hipFree(p);   // not from the cache
 }
 
+// Matrix-array cache: best fit among the free blocks if it is not more than half again as large, else a new allocation; at
+// most 12 free blocks / 24 GiB are kept.
+int dz_big_get(dazim_ctx *ctx, size_t bytes, void **out) {
+  if (bytes == 0) bytes = 16;
+  int best = -1;
+  for (size_t i = 0; i < ctx->big.size(); i++) {
+    auto &b = ctx->big[i];
+    if (!b.busy && b.bytes >= bytes && (best < 0 || b.bytes < ctx->big[best].bytes)) best = (int)i;
+  }
+  if (best >= 0 && ctx->big[best].bytes <= bytes + bytes / 2 + (1 << 20)) {
+    ctx->big[best].busy = true;
+    *out = ctx->big[best].p;
+    return 0;
+  }
+  void *p = nullptr;
+  DZ_HIP(hipMalloc(&p, bytes));
+  ctx->big.push_back({p, bytes, true});
+  *out = p;
+  return 0;
+}
+void dz_big_put(dazim_ctx *ctx, void *p) {
+  if (!p) return;
+  if (ctx) {
+    size_t kept = 0, nfree = 0;
+    for (auto &b : ctx->big)
+      if (!b.busy) { kept += b.bytes; nfree++; }
+    for (size_t i = 0; i < ctx->big.size(); i++) {
+      auto &b = ctx->big[i];
+      if (b.p != p) continue;
+      if (nfree >= 12 || kept + b.bytes > ((size_t)24 << 30)) {
+        (void)hipFree(b.p);
+        ctx->big.erase(ctx->big.begin() + i);
+      } else {
+        b.busy = false;
+      }
+      return;
+    }
+  }
+  (void)hipFree(p);   // not from the cache (or no context left)
+}
+
 namespace {
 __global__ void k_range_flag(int64_t n, const int *a, int lo, int hi, int *bad) {
   bool b = false;
@@ -134,6 +175,9 @@ void dazim_destroy(dazim_ctx *ctx) {
   if (ctx->comm && ctx->comm_release) ctx->comm_release(ctx);
   for (auto &b : ctx->stage) (void)hipFree(b.p);
   ctx->stage.clear();
+  for (auto &b : ctx->big)
+    if (!b.busy) (void)hipFree(b.p);   // (arrays of matrices that outlive the context stay theirs: dazim_csr_free(NULL, A) frees them)
+  ctx->big.clear();
   for (auto &kv : ctx->scratch)
     if (kv.second.first) (void)hipFree(kv.second.first);
   (void)hipEventDestroy(ctx->ev0);

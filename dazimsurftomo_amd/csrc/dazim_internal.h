@@ -26,6 +26,10 @@ struct dazim_ctx {
   // hipMalloc + hipFree pair per staged array costs milliseconds in a program that calls the library once per outer iteration
   struct StageBlock { void *p; size_t bytes; bool busy; };
   std::vector<StageBlock> stage;
+  // matrix arrays (CSR values / columns / row pointers of G, hundreds of MB to GB each): a program builds and frees one G per
+  // outer iteration, and a hipMalloc + hipFree pair of that size costs about a millisecond each -- freed arrays are kept
+  // (a few, best fit) and handed out again
+  std::vector<StageBlock> big;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
@@ -47,6 +51,8 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
 bool dz_is_device_ptr(const void *p);
 int dz_stage_get(dazim_ctx *ctx, size_t bytes, void **out);   // a device block of >= bytes from the context's staging cache
 void dz_stage_put(dazim_ctx *ctx, void *p);                   // give it back (kept for reuse; freed by dazim_destroy)
+int dz_big_get(dazim_ctx *ctx, size_t bytes, void **out);     // a device array for a matrix (see dazim_ctx::big)
+void dz_big_put(dazim_ctx *ctx, void *p);                     // return it (any hipMalloc'ed pointer is accepted; ctx may be null)
 
 // every a[i] of a DEVICE array inside lo..hi?  Returns 0, or DAZIM_E_BAD_ARG with "<what> outside lo..hi" as the message.
 int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what);

@@ -665,7 +665,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   int64_t res_rows = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1), res_nnz = 7 * res_rows;
   if (ctx->opts.count("csr.reserve_rows") && ctx->opts["csr.reserve_rows"] > res_rows) res_rows = ctx->opts["csr.reserve_rows"];
   if (ctx->opts.count("csr.reserve_nnz") && ctx->opts["csr.reserve_nnz"] > res_nnz) res_nnz = ctx->opts["csr.reserve_nnz"];
-  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m + res_rows + 1) * 8));
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m + res_rows + 1) * 8, &pp))) return rc; rowptr = (int64_t *)pp; }
   A.dsurf = dsurf.dev;
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
@@ -712,8 +712,8 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   float *val = nullptr;
   int *col = nullptr;
   const int64_t cap_nnz = nnz + res_nnz;   // (options csr.reserve_rows / csr.reserve_nnz: room for rows appended later)
-  DZ_HIP(hipMalloc((void **)&val, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4));
-  DZ_HIP(hipMalloc((void **)&col, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4));
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4, &pp))) return rc; val = (float *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4, &pp))) return rc; col = (int *)pp; }
   A.val = val;
   A.col = col;
   if (nray > 0) {
@@ -741,9 +741,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = dsurf.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   if (err) {
-    (void)hipFree(rowptr);
-    (void)hipFree(val);
-    (void)hipFree(col);
+    dz_big_put(ctx, rowptr);
+    dz_big_put(ctx, val);
+    dz_big_put(ctx, col);
     return err;
   }
   const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1);

@@ -870,13 +870,13 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
 // changed_from: first entry whose column index is new (0: all of them; < 0: only values changed, e.g. row scaling) -- the
 // 16-bit copy of the column indices is extended / kept accordingly
 int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
-  if (A->cbptr) { (void)hipFree(A->cbptr); A->cbptr = nullptr; }
+  if (A->cbptr) { dz_big_put(ctx, A->cbptr); A->cbptr = nullptr; }
   A->ncb = (int)((A->n + CBW_MAX - 1) / CBW_MAX);
   A->cbw = (int)(((A->n + A->ncb - 1) / A->ncb + 3) & ~3ll);
   const int mod16 = A->n <= 65536 ? 0 : 2 * A->cbw;       // 16-bit indices: the column, or the column within its block pair
   const bool want16 = mod16 <= 65536 && A->nnz > 0 && !(ctx->opts.count("spmv.col16") && !ctx->opts["spmv.col16"]);
   if (A->col16 && (!want16 || A->col16_cap < A->nnz || changed_from == 0 || A->col16_mod != mod16)) {
-    (void)hipFree(A->col16);
+    dz_big_put(ctx, A->col16);
     A->col16 = nullptr;
     A->col16_cap = 0;
   }
@@ -884,7 +884,7 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
     int64_t from = 0;
     if (!A->col16) {
       A->col16_cap = ((A->cap_nnz > A->nnz ? A->cap_nnz : A->nnz) + 3) & ~(int64_t)3;
-      DZ_HIP(hipMalloc((void **)&A->col16, (size_t)A->col16_cap * 2));
+      { void *pp; int rcp = dz_big_get(ctx, (size_t)A->col16_cap * 2, &pp); if (rcp) return rcp; A->col16 = (unsigned short *)pp; }
       A->col16_mod = mod16;
     } else {
       from = changed_from & ~(int64_t)3;
@@ -896,7 +896,7 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
   }
   const int64_t np = A->m * (A->ncb + 1);
   if (np > 0) {   // a matrix without rows (an empty ray batch) has no block pointers
-    DZ_HIP(hipMalloc((void **)&A->cbptr, (size_t)np * 8));
+    { void *pp; int rcp = dz_big_get(ctx, (size_t)np * 8, &pp); if (rcp) return rcp; A->cbptr = (int64_t *)pp; }
     hipLaunchKernelGGL(k_colblock_ptr, dim3((unsigned)((np + VB - 1) / VB)), dim3(VB), 0, ctx->stream, A->m, A->ncb, A->cbw,
                        A->rowptr, A->col, A->cbptr);
     DZ_HIP(hipGetLastError());
@@ -1198,7 +1198,7 @@ int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
   else (void)hipDeviceSynchronize();
   void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr, A->col16};
   for (void *p : ps)
-    if (p) (void)hipFree(p);
+    if (p) dz_big_put(ctx, p);
   delete A;
   return 0;
 }
@@ -1228,9 +1228,9 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
   A->n = n;
   A->nnz = nnz;
   const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
-  DZ_HIP(hipMalloc((void **)&A->rowptr, (m + 1) * 8));
-  DZ_HIP(hipMalloc((void **)&A->col, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->val, nz * 4));
+  { void *pp; if ((rc = dz_big_get(ctx, (m + 1) * 8, &pp))) return fail(rc); A->rowptr = (int64_t *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, nz * 4, &pp))) return fail(rc); A->col = (int *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, nz * 4, &pp))) return fail(rc); A->val = (float *)pp; }
   unsigned *k0, *k1, *v0, *perm;
   int *bad;
   void *p;
@@ -1341,9 +1341,9 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   int64_t *rowptr;
   int *col;
   float *val;
-  DZ_HIP(hipMalloc((void **)&rowptr, (m2 + 1) * 8));
-  DZ_HIP(hipMalloc((void **)&col, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
-  DZ_HIP(hipMalloc((void **)&val, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m2 + 1) * 8, &pp))) return rc; rowptr = (int64_t *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nz2 > 0 ? nz2 : 1) * 4, &pp))) return rc; col = (int *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nz2 > 0 ? nz2 : 1) * 4, &pp))) return rc; val = (float *)pp; }
   DZ_HIP(hipMemcpyAsync(rowptr, A->rowptr, (A->m + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
   if (extra_m > 0)
     hipLaunchKernelGGL(k_offset_ptr, dim3(nblk(extra_m + 1)), dim3(VB), 0, ctx->stream, extra_m + 1, B->rowptr, A->nnz, rowptr + A->m);
@@ -1353,9 +1353,9 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   DZ_HIP(hipMemcpyAsync(val + A->nnz, B->val, (size_t)nnz2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   dazim_csr_free(ctx, B);
-  (void)hipFree(A->rowptr);
-  (void)hipFree(A->col);
-  (void)hipFree(A->val);
+  dz_big_put(ctx, A->rowptr);
+  dz_big_put(ctx, A->col);
+  dz_big_put(ctx, A->val);
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
   A->cap_m = A->cap_nnz = 0;
@@ -1844,9 +1844,9 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   int64_t *rowptr;
   int *col;
   float *val;
-  DZ_HIP(hipMalloc((void **)&rowptr, (size_t)(m2 + 1) * 8));
-  DZ_HIP(hipMalloc((void **)&col, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
-  DZ_HIP(hipMalloc((void **)&val, (size_t)(nz2 > 0 ? nz2 : 1) * 4));
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m2 + 1) * 8, &pp))) return rc; rowptr = (int64_t *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nz2 > 0 ? nz2 : 1) * 4, &pp))) return rc; col = (int *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nz2 > 0 ? nz2 : 1) * 4, &pp))) return rc; val = (float *)pp; }
   DZ_HIP(hipMemcpyAsync(rowptr, A->rowptr, (size_t)A->m * 8, hipMemcpyDeviceToDevice, ctx->stream));
   DZ_HIP(hipMemcpyAsync(col, A->col, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
   DZ_HIP(hipMemcpyAsync(val, A->val, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1854,9 +1854,9 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
                      rowptr + A->m, col, val);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  (void)hipFree(A->rowptr);
-  (void)hipFree(A->col);
-  (void)hipFree(A->val);
+  dz_big_put(ctx, A->rowptr);
+  dz_big_put(ctx, A->col);
+  dz_big_put(ctx, A->val);
   A->rowptr = rowptr; A->col = col; A->val = val;
   A->m = m2; A->nnz = nz2;
   A->cap_m = A->cap_nnz = 0;
