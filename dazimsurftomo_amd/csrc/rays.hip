@@ -54,6 +54,7 @@ struct RayArgs {
   float *fdm_scratch;      // [nwg*4][(nvx+2)*(nvz+2)] (x3 in joint mode): one Frechet grid slot per 16-lane group
   int LK;
   int lcap;                // LDS cell-list capacity per ray
+  unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD)
   int keep_small;          // 1: keep every non-zero row entry of the |fdm| >= ftol cells (the forward program's dense GGc/GGs,
                            // fwd/FwdTraveltimeCPS.f90:694-712); 0: the inversion's second |row| > ftol threshold
   const long *rowptr;      // [nray+1] (emit pass in)
@@ -206,12 +207,29 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
   const double rdnx = A.r_dnx, rdnz = A.r_dnz, rdnxr = A.r_dnxr, rdnzr = A.r_dnzr, rdvx = A.r_dvx, rdvz = A.r_dvz;
   const unsigned gmask_shift = grp * GP;
   // XCD-aware order (speed only): workgroup b runs on XCD b % 8, and the rays of one field read the
-  // same traveltime grids, so each XCD gets one contiguous eighth of the ray quads
+  // same traveltime grids, so each XCD gets one contiguous eighth of the ray quads.  Within its eighth a workgroup takes
+  // the next quad from a counter (rays differ in length by an order of magnitude: equal shares of quads are not equal
+  // shares of work); a workgroup whose eighth is drained helps with the next ones.
   const long nquad = (A.nray + RPW - 1) / RPW;
   const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
-  const long xcd = blockIdx.x % nxcd, wg_in_xcd = blockIdx.x / nxcd, wgs_per_xcd = gridDim.x / nxcd;
-  const long q_lo = nquad * xcd / nxcd, q_hi = nquad * (xcd + 1) / nxcd;
-  for (long quad = q_lo + wg_in_xcd; quad < q_hi; quad += wgs_per_xcd) {
+  unsigned *qcnt = A.qcount + (EMIT ? 8 : 0);
+  int chunk = (int)(blockIdx.x % nxcd);
+  for (;;) {
+    long quad = -1;
+    if (lane == 0) {
+      for (int tried = 0; tried < nxcd; tried++) {
+        const long lo = nquad * chunk / nxcd, hi = nquad * (chunk + 1) / nxcd;
+        const long b = lo < hi ? (long)atomicAdd(&qcnt[chunk], 1u) : hi;
+        if (lo + b < hi) {
+          quad = lo + b;
+          break;
+        }
+        chunk = (chunk + 1) % nxcd;
+      }
+    }
+    quad = ((long)__shfl((int)(quad >> 32), 0) << 32) | (unsigned)__shfl((int)quad, 0);
+    chunk = __shfl(chunk, 0);
+    if (quad < 0) break;
     const long ray = quad * RPW + grp;
     if (ray >= A.nray) continue;
     const int f = A.field[ray];
@@ -691,6 +709,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (nwg < 1) nwg = 1;
   if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * RPW_MAX * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
   A.fdm_scratch = (float *)p;
+  if ((rc = dz_scratch(ctx, "rays.qcount", 64, &p))) return rc;
+  A.qcount = (unsigned *)p;
+  DZ_HIP(hipMemsetAsync(A.qcount, 0, 64, ctx->stream));
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
