@@ -16,6 +16,7 @@
 #include "dazim_internal.h"
 
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -54,6 +55,9 @@ struct RayArgs {
   float *fdm_scratch;      // [nwg*4][(nvx+2)*(nvz+2)] (x3 in joint mode): one Frechet grid slot per 16-lane group
   int LK;
   int lcap;                // LDS cell-list capacity per ray
+  const unsigned *perm;    // [nray] order in which the rays are dealt to the lane groups: by field, then by source-receiver
+                           // distance, so that the rays marching in lockstep in one wavefront have similar lengths (speed only:
+                           // everything a ray produces is stored under its own index)
   unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD)
   int keep_small;          // 1: keep every non-zero row entry of the |fdm| >= ftol cells (the forward program's dense GGc/GGs,
                            // fwd/FwdTraveltimeCPS.f90:694-712); 0: the inversion's second |row| > ftol threshold
@@ -172,6 +176,22 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
   return biv;
 }
 
+// sort key of a ray for the order in which rays are dealt to the wavefronts: field in the high bits, quantised source-receiver
+// distance (a proxy for the number of steps of the ray) in the low `dbits`
+__global__ void k_ray_keys(long nray, const int *__restrict__ field, const float *__restrict__ scx, const float *__restrict__ scz,
+                           const float *__restrict__ rcx, const float *__restrict__ rcz, float inv_dmax, int dbits,
+                           unsigned *__restrict__ keys, unsigned *__restrict__ iota) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nray) return;
+  const int f = field[i];
+  const float dx = scx[f] - rcx[i], dz = (scz[f] - rcz[i]) * __sinf(rcx[i]);
+  const float d = sqrtf(dx * dx + dz * dz) * inv_dmax;
+  const unsigned dmaxq = (1u << dbits) - 1u;
+  unsigned q = d >= 1.0f ? dmaxq : (unsigned)(d * (float)dmaxq);
+  keys[i] = ((unsigned)f << dbits) | (dmaxq - q);          // longest rays of a field first
+  iota[i] = (unsigned)i;
+}
+
 // lanes per ray: 8 in the count pass, which traces every ray (measured: 16 lanes 94 ms, 8 lanes 73 ms, 4 lanes 84 ms on the S-256
 // batch); 16 in the emit pass, which only walks the saved cell lists (lane-parallel work: 8.2 ms with 16 lanes, 12.5 with 8)
 constexpr int GP_COUNT = 8, GP_EMIT = 16;
@@ -230,8 +250,9 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     quad = ((long)__shfl((int)(quad >> 32), 0) << 32) | (unsigned)__shfl((int)quad, 0);
     chunk = __shfl(chunk, 0);
     if (quad < 0) break;
-    const long ray = quad * RPW + grp;
-    if (ray >= A.nray) continue;
+    const long slot = quad * RPW + grp;
+    if (slot >= A.nray) continue;
+    const long ray = A.perm ? (long)A.perm[slot] : slot;
     const int f = A.field[ray];
     const float scx = A.scx[f], scz = A.scz[f], rcx = A.rcx[ray], rcz = A.rcz[ray];
     const float *veln = A.veln + (size_t)(A.period[f] - 1) * nnx * nnz;
@@ -709,6 +730,27 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (nwg < 1) nwg = 1;
   if ((rc = dz_scratch(ctx, "rays.fdm", (size_t)nwg * RPW_MAX * (g.nvx + 2) * (g.nvz + 2) * 4 * (joint ? 3 : 1), &p))) return rc;
   A.fdm_scratch = (float *)p;
+  A.perm = nullptr;
+  if (nray >= 64 && nray < (1ll << 32) && !(ctx->opts.count("rays.sort") && !ctx->opts["rays.sort"])) {
+    int fbits = 1;
+    while ((1ll << fbits) < nfield) fbits++;
+    const int dbits = 32 - fbits > 12 ? 12 : 32 - fbits;
+    if (dbits >= 4) {
+      unsigned *k0, *k1, *v0, *v1;
+      if ((rc = dz_scratch(ctx, "rays.sortbuf", (size_t)nray * 16 + 64, &p))) return rc;
+      k0 = (unsigned *)p; k1 = k0 + nray; v0 = k1 + nray; v1 = v0 + nray;
+      const float ex = (float)g.nnx * g.dnx, ez = (float)g.nnz * g.dnz;
+      const float inv_dmax = 1.0f / sqrtf(ex * ex + ez * ez);
+      hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((nray + 255) / 256)), dim3(256), 0, ctx->stream, (long)nray, field.dev, scx.dev,
+                         scz.dev, rcx.dev, rcz.dev, inv_dmax, dbits, k0, v0);
+      size_t tb = 0;
+      DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, v1, (size_t)nray, 0, fbits + dbits, ctx->stream));
+      void *tmp;
+      if ((rc = dz_scratch(ctx, "rays.sorttmp", tb + 256, &tmp))) return rc;
+      DZ_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, v1, (size_t)nray, 0, fbits + dbits, ctx->stream));
+      A.perm = v1;
+    }
+  }
   if ((rc = dz_scratch(ctx, "rays.qcount", 64, &p))) return rc;
   A.qcount = (unsigned *)p;
   DZ_HIP(hipMemsetAsync(A.qcount, 0, 64, ctx->stream));
