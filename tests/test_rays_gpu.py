@@ -196,3 +196,12 @@ def test_cell_list_fallbacks_give_the_same_G(ctx, orc, joint):
         ctx.set_option("rays.lcap", 0)
     assert np.array_equal(t0, t1)
     assert len(a0[2]) > 1000 and all(np.array_equal(x, y) for x, y in zip(a0, a1))
+    # the order in which rays are dealt to the wavefronts (default: by field and source-receiver distance) is a matter of speed
+    try:
+        ctx.set_option("rays.sort", 0)
+        G2, t2, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+        a2 = G2.to_coo()
+        G2.free()
+    finally:
+        ctx.set_option("rays.sort", 1)
+    assert np.array_equal(t0, t2) and all(np.array_equal(x, y) for x, y in zip(a0, a2))
