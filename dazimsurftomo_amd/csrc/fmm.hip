@@ -18,6 +18,7 @@
 // field four-fold compared with one field per wavefront -- the kernel is issue-bound, not HBM-bound.
 // fp32 without FMA contraction (this file is built with -ffp-contract=off); sin() of the colatitude
 // comes from host tables so that it is the same libm value the CPU reference uses.
+#include <algorithm>
 #include <cmath>
 
 #include "dazim_internal.h"
@@ -1067,6 +1068,28 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     int run = 0;
     for (size_t k = 0; k < cnt.size(); k++) { const int c = cnt[k]; cnt[k] = run; run += c; }
     for (int i = 0; i < nfield; i++) order[cnt[key(i)]++] = i;
+    // Within a period: by the distance of the source from the middle of the grid.  The four fields of a wavefront march in
+    // lockstep and the sift-down runs as many 4-level steps as the largest of their bands needs (three from 512 entries on,
+    // else two); the band of a field grows with the room the front has, i.e. with how central the source is, so fields with
+    // similar bands are put together.  (Speed only: which fields share a wavefront has no influence on any field.)
+    if (!(ctx->opts.count("fmm.sort") && !ctx->opts["fmm.sort"])) {
+      std::vector<float> hx(nfield), hz(nfield);
+      DZ_HIP(hipMemcpyAsync(hx.data(), A.scx, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipMemcpyAsync(hz.data(), A.scz, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      const float cx = A.g.gox + 0.5f * (float)(A.g.nnx - 1) * A.g.dnx, cz = A.g.goz + 0.5f * (float)(A.g.nnz - 1) * A.g.dnz;
+      const float wx = 1.0f / ((float)A.g.nnx * A.g.dnx), wz = 1.0f / ((float)A.g.nnz * A.g.dnz);
+      auto dist = [&](int i) {   // Chebyshev distance from the centre in units of the grid size: the nearest edge decides the band
+        const float ax = fabsf(hx[i] - cx) * wx, az = fabsf(hz[i] - cz) * wz;
+        return ax > az ? ax : az;
+      };
+      int b0 = 0;
+      for (int i = 1; i <= nfield; i++)
+        if (i == nfield || hper[order[i]] != hper[order[b0]]) {
+          std::stable_sort(order.begin() + b0, order.begin() + i, [&](int a, int b) { return dist(a) < dist(b); });
+          b0 = i;
+        }
+    }
     if ((rc = dz_scratch(ctx, "fmm.order", (size_t)nfield * 4 + 16, &p))) return rc;
     DZ_HIP(hipMemcpyAsync(p, order.data(), (size_t)nfield * 4, hipMemcpyHostToDevice, ctx->stream));
     A.flist = (const int *)p;

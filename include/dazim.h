@@ -83,6 +83,7 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * get that much room and dazim_csr_append_coo / dazim_csr_append_tikhonov append in place instead of copying the matrix.
  * "rays.sort": 0 = deal the rays to the wavefronts in input order (default: by field, then by source-receiver distance, so
  * that the rays a wavefront traces in lockstep have similar lengths; results do not depend on it).
+ * "fmm.sort": 0 = fields of a period marched in input order (default: by how central the source is; speed only).
  * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
  * "fmm.wg_per_cu": resident eikonal workgroups per CU (measurement).  "disp.ffwd": 0 = the first period's bracket search goes
  * step by step from its start value like the reference's (default: it jumps to the bracket that a parallel evaluation of the
