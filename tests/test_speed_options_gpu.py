@@ -5,6 +5,7 @@ switched off:
   disp.ffwd = 0     first period's bracket search step by step (no jump to the bracket found by disp_bracket_kernel)
   rays.sort = 0     rays dealt to the wavefronts in input order
   spmv.col16 = 0    32-bit column indices in the products
+  fmm.sort = 0      fields of a period marched in input order
 
 Everything that crosses the ABI must be IDENTICAL bit for bit -- phase velocities, depth kernels, eikonal fields, predicted
 traveltimes, the triplets of G, the LSMR iterates -- because none of these devices changes the arithmetic or its order
@@ -46,11 +47,11 @@ def _step(ctx, nsrc=24, nrcv=12, kmax=4):
 def test_speed_options_do_not_change_any_result(ctx):
     fast = _step(ctx)
     try:
-        for name in ("disp.ffwd", "rays.sort", "spmv.col16"):
+        for name in ("disp.ffwd", "rays.sort", "spmv.col16", "fmm.sort"):
             ctx.set_option(name, 0)
         plain = _step(ctx)
     finally:
-        for name in ("disp.ffwd", "rays.sort", "spmv.col16"):
+        for name in ("disp.ffwd", "rays.sort", "spmv.col16", "fmm.sort"):
             ctx.set_option(name, 1)
     assert fast["nfail"] == plain["nfail"] and np.array_equal(fast["pv"], plain["pv"])
     for a, b in zip(fast["sen"], plain["sen"]):
