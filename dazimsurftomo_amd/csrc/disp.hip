@@ -50,6 +50,7 @@ struct DispArgs {
   int ffwd;
   int *ff_m;           // [ncol]  0: no information
   double *ff_c;        // [ncol]
+  int *ff_v;           // [ncol]  steps the perturbed copies may jump at most (see disp_bracket_kernel: a dip of |del| before the bracket)
 };
 
 __device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
@@ -355,12 +356,24 @@ __device__ __forceinline__ void startup(const Knots &K, const Layer *lay, int mm
 //   * the 6*nz perturbed copies (one knot changed by +-0.5 %) jump to 0.02 km/s (four steps) below the column's bracket and
 //     check that the sign there is still the start point's.  A perturbed root lies within ~0.003 km/s of the column's (at most
 //     0.015 if one knot carried all the sensitivity), so the jump stays below it; if the sign has changed, the item goes back to
-//     the start point and searches step by step.  What is NOT checked is an even number of sign changes inside the skipped
-//     interval -- two roots of the perturbed model where the column's model, evaluated at every point of the same grid, has
-//     none.  That takes a double root appearing under a 0.5 % change of one knot; option disp.ffwd = 0 turns the jump off, and
-//     tests/test_disp_gpu.py compares both settings bit for bit.
+//     the start point and searches step by step.  What the sign check cannot see is an even number of sign changes inside the
+//     skipped interval: two roots of the perturbed model where the column's model has none.  That happens where the column's
+//     secular function touches zero without crossing it (a double root about to be born: 4 of 1 200 columns whose knots are
+//     drawn at random, none in layered models with any smoothness), and it shows in the samples this kernel has anyway: the
+//     normalised |del| sits on a plateau and falls monotonically into the bracket, except in those columns, where it dips and
+//     comes back.  So the kernel also records where |del| first decreases and whether it ever increases again before the
+//     bracket; if it does, the perturbed copies jump only to eight steps before that first decrease and walk through the dip
+//     step by step like the reference (ff_v).  What remains after that are features of the perturbed copy's function narrower
+//     than the grid step that the column's own samples miss: 2 of 28 800 columns whose ten knots are drawn independently from
+//     2.6 .. 4.7 km/s, both with a knot more than 36 % slower than a shallower one (stacks of trapped-wave channels); none in
+//     57 600 columns of a gradient with independent knot perturbations of up to +-30 %.  The perturbed copies of a column
+//     therefore jump only if no knot is more than FF_MAXDROP = 25 % slower than the fastest knot above it; rougher columns
+//     are searched step by step.  tests/test_disp_gpu.py compares the jump with the step-by-step search bit for bit on
+//     ordinary models, on graded random columns (jump active) and on thousands of such rough columns (gate and dip guard);
+//     option disp.ffwd = 0 turns the jump off.
 constexpr int FF_BLOCKS = 8;          // 8 x 64 grid points = 2.56 km/s above the start value
 constexpr double FF_MARGIN = 0.02;    // km/s below the column's bracket for the perturbed copies
+constexpr float FF_MAXDROP = 0.25f;   // largest relative decrease of Vs below a shallower knot for which the perturbed copies jump
 template <int RDEN>
 __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
@@ -404,6 +417,9 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
   unsigned long long prev_last = 0;
   int found = 0;
   double cfound = 0.0, clast_prev = 0.0;           // clast_prev: grid point 64 * blk - 1
+  double alast_prev = 0.0;                         // |del| at grid point 64 * blk - 1
+  int jfirst = -1;                                 // first grid point at which |del| is smaller than at the point before
+  bool wiggle = false;                             // ... and it grew again somewhere between there and the bracket
   for (int blk = 0; blk < FF_BLOCKS; blk++) {
     double c = cblk;
     for (int i = 0; i < lane; i++) c = c + dc;   // the reference's c2 = c1 + dc, one step after the other
@@ -414,6 +430,25 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
     const unsigned long long over = __ballot(c >= climit);           // points the reference would not go beyond
     const int jl = over ? __builtin_ctzll(over) : 64;
     const double clast = __shfl(c, 63);
+    {   // monotonicity of |del| up to the bracket (points of this block below the sign change, or all 64)
+      const double a = fabs(del);
+      double ap = __shfl_up(a, 1);
+      if (lane == 0) ap = blk > 0 ? alast_prev : a;
+      const int jend = (chg != 0 && __builtin_ctzll(chg) <= jl) ? __builtin_ctzll(chg) : 64;   // points < jend are below the bracket
+      const unsigned long long below = jend >= 64 ? ~0ull : ((1ull << jend) - 1ull);
+      const unsigned long long dec = __ballot(a < ap * (1.0 - 1.0e-6)) & below;
+      const unsigned long long inc = __ballot(a > ap * (1.0 + 1.0e-6)) & below;
+      unsigned long long after = ~0ull;             // points after the first decrease
+      if (jfirst < 0 && dec != 0) {
+        const int jd = __builtin_ctzll(dec);
+        jfirst = 64 * blk + jd;
+        after = jd >= 63 ? 0ull : ~((2ull << jd) - 1ull);
+      } else if (jfirst < 0) {
+        after = 0ull;
+      }
+      if ((inc & after) != 0) wiggle = true;
+      alast_prev = __shfl(a, 63);
+    }
     if (chg != 0) {
       const int j = __builtin_ctzll(chg);
       const double cl = __shfl(c, j > 0 ? j - 1 : 0);
@@ -431,6 +466,15 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
   if (lane == 0) {
     A.ff_m[col] = found > 0 ? found - 1 : 0;
     A.ff_c[col] = cfound;
+    float vtop = s_knot[0], drop = 0.0f;             // roughness gate: how much slower than the fastest knot above is any knot?
+    for (int k = 1; k < nz; k++) {
+      const float v = s_knot[k];
+      drop = fmaxf(drop, (vtop - v) / vtop);
+      vtop = fmaxf(vtop, v);
+    }
+    int lim = wiggle ? (jfirst - 8 > 0 ? jfirst - 8 : 0) : 0x3fffffff;   // (no dip: no extra limit)
+    if (drop > FF_MAXDROP) lim = 0;
+    A.ff_v[col] = lim;
   }
 }
 
@@ -563,6 +607,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
             if (m > 0 && var > 0) {
               const double steps = floor((A.ff_c[col] - FF_MARGIN - c1) / dc);
               m = steps > 0.0 ? (steps < (double)m + 8.0 ? (int)steps : m + 8) : 0;
+              const int lim = A.ff_v[col] - 4;      // (a dip of the column's |del| before its bracket: stay in front of it)
+              if (m > lim) m = lim > 0 ? lim : 0;
             }
             if (m >= 2) {
               s_x[0][tid] = c1;                        // (the Neville table is idle during the bracket search)
@@ -885,6 +931,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     A.ff_m = (int *)p;
     if ((rc = dz_scratch(ctx, "disp.ff_c", (size_t)ncol * 8 + 16, &p))) return rc;
     A.ff_c = (double *)p;
+    if ((rc = dz_scratch(ctx, "disp.ff_v", (size_t)ncol * 4 + 16, &p))) return rc;
+    A.ff_v = (int *)p;
     DzTimer t(ctx, "disp");
     if (A.ffwd) {
       if (rden == 1)
