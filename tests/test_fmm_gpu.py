@@ -12,8 +12,10 @@ from tests import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run_case(ctx, orc, nx, ny, kmax, nsrc, seed, goxd=30.0, gozd=100.0, dv=0.25, edge_sources=False, shrink=0.3):
+def _run_case(ctx, orc, nx, ny, kmax, nsrc, seed, goxd=30.0, gozd=100.0, dv=0.25, edge_sources=False, shrink=0.3, rough=False):
     pv = synth.phase_velocity_maps(nx, ny, kmax, seed)
+    if rough:   # every inversion cell drawn independently: strong, short-wavelength contrasts (caustics, many ties broken)
+        pv = np.random.default_rng(seed).uniform(2.0, 4.8, pv.shape).astype(np.float32).astype(np.float64)
     lat, lon = synth.stations(nx, ny, goxd, gozd, dv, dv, nsrc, seed + 1, shrink=0.02 if edge_sources else shrink)
     if edge_sources:  # corners and exact node positions exercise the clipped refined boxes
         lat[:4] = [goxd, goxd, goxd - (nx - 3) * dv, goxd - (nx - 3) * dv]
@@ -90,6 +92,14 @@ def test_fmm_701(ctx, orc):
     """a grid above 682 nodes a side (143x143 -> 701x701): past the hybrid heap's 2047 slots, the all-LDS 2048-slot heap with
     32-bit node ids and three 4-level sift-down steps"""
     _run_case(ctx, orc, 143, 143, 1, 3, seed=17, shrink=12.0)
+
+
+def test_fmm_rough_random_velocity_maps(ctx, orc):
+    """phase-velocity maps whose cells are drawn independently from 2.0 .. 4.8 km/s (nothing like a tomographic model: fronts
+    fold, bands grow ragged): the acceptance order, ties included, must still be the reference's -- bit-exact fields on a 71 x 71
+    and a 126 x 126 grid"""
+    _run_case(ctx, orc, 17, 17, 3, 10, seed=77, goxd=26.5, gozd=101.25, edge_sources=True, rough=True)
+    _run_case(ctx, orc, 28, 28, 2, 6, seed=78, rough=True)
 
 
 def test_fmm_source_outside(ctx):
