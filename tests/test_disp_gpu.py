@@ -209,3 +209,15 @@ def test_first_period_fast_forward_on_graded_random_models(ctx, p):
     base = (3.0 + 0.02 * ROUGH_DEPZ)[:, None, None]
     vel = (base * (1 + rng.uniform(-p, p, (len(ROUGH_DEPZ), ny, nx)))).astype(np.float32)
     _same_with_and_without_jump(ctx, vel, ROUGH_DEPZ, ROUGH_T, 3.0)
+
+
+def test_phase_velocities_on_rough_random_columns(ctx, orc):
+    """600 of the rough random columns (knots drawn independently from 2.6 .. 4.7 km/s) against the oracle, phase velocities only:
+    the usual bars (4e-6 km/s, >= 99.5 % bit-equal) and the same root failures"""
+    rng = np.random.default_rng(5)
+    vel = rng.uniform(2.6, 4.7, (len(ROUGH_DEPZ), 20, 30)).astype(np.float32)
+    vel[-1] = np.maximum(vel[-1], 4.2)
+    pv, _, nf = ctx.depthkernel(vel, ROUGH_DEPZ, ROUGH_T, 3.0, kernels=False)
+    pvo, _ = orc.depthkernel(vel, ROUGH_DEPZ, ROUGH_T, 3.0, kernels=False)
+    assert np.array_equal(pv == 0, pvo == 0) and nf == int((pvo == 0).sum())
+    assert np.abs(pv - pvo).max() <= 4e-6 and (pv == pvo).mean() >= 0.995
