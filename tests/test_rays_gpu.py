@@ -122,6 +122,33 @@ def test_G_matches_oracle(ctx, orc, nx, ny, depz, kmax, minthk):
     G2.free()
 
 
+def test_G_matches_oracle_on_a_rough_model(ctx, orc):
+    """+-12 % checkerboard and 6 % independent noise per cell (phase-velocity maps with 15-20 % contrasts over one cell: rays
+    bend hard, some hug caustics): predicted traveltimes and G against the oracle with the usual bars"""
+    nx, ny, kmax, minthk = 17, 17, 3, 2.0
+    depz = np.asarray([0.0, 10.0, 35.0, 60.0], np.float32)
+    goxd, gozd, dv = 30.0, 100.0, 0.25
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 10, 6, seed=91)
+    rng = np.random.default_rng(92)
+    vel = (vel * (1.0 + 0.06 * np.sign(vel - vel.mean(axis=(1, 2), keepdims=True)) + 0.06 * rng.standard_normal(vel.shape))).astype(np.float32)
+    vel = np.clip(vel, 2.4, 4.9).astype(np.float32)
+    t = np.array([6.0, 14.0, 30.0])
+    rc, rw_o, ir_o, ic_o, ds_o, nb_o = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
+                                                    nrc1, nsrc1, periods, 4_000_000)
+    assert rc == 0
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
+    ir, ic, rw = G.to_coo()
+    m, n = len(ds_o), (nx - 2) * (ny - 2) * (len(depz) - 1)
+    D, Do = dense(m, n, ir, ic, rw), dense(m, n, ir_o, ic_o, rw_o)
+    assert np.abs(D - Do).max() <= 2e-4
+    assert np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
+    G.free()
+
+
 def test_receiver_outside_is_an_error(ctx, orc):
     import dazimsurftomo_amd as dz
     nx = ny = 10
