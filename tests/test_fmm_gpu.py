@@ -96,10 +96,11 @@ def test_fmm_701(ctx, orc):
 
 def test_fmm_rough_random_velocity_maps(ctx, orc):
     """phase-velocity maps whose cells are drawn independently from 2.0 .. 4.8 km/s (nothing like a tomographic model: fronts
-    fold, bands grow ragged): the acceptance order, ties included, must still be the reference's -- bit-exact fields on a 71 x 71
-    and a 126 x 126 grid"""
+    fold, bands grow ragged): the acceptance order, ties included, must still be the reference's -- bit-exact fields on 71 x 71,
+    126 x 126 and 511 x 511 grids"""
     _run_case(ctx, orc, 17, 17, 3, 10, seed=77, goxd=26.5, gozd=101.25, edge_sources=True, rough=True)
     _run_case(ctx, orc, 28, 28, 2, 6, seed=78, rough=True)
+    _run_case(ctx, orc, 105, 105, 1, 3, seed=79, shrink=10.0, rough=True)   # 511 x 511, central sources: the hybrid heap's HBM level
 
 
 def test_fmm_source_outside(ctx):
