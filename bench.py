@@ -2,6 +2,7 @@
 """bench.py -- the DAzimSurfTomo hot path on MI355X (BASELINE.json metric).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--sources S] [--receivers R] [--no-cpu] [--workload s128|s256|s512]
+                    [--scaling weak|strong] [--dry-launch]
 
 One "step" = one pass of the hot path over the S-256 synthetic batch: dispersion +
 depth kernels for every model column, 16 periods x S sources eikonal fields on the 256x256 grid,
@@ -17,9 +18,14 @@ its HBM fraction is reported for transparency, not as a target), `spmv` (the HBM
 40 % target applies to) and `cpu_baseline` (the oracle = plain-C port of the reference, 1 thread, on
 a bounded sample of the same workload on this box's host cores).
 
-Multi-GPU (`--gpus N` under torch.distributed.run): the default workload stays S-256 per rank (weak scaling, so that the N = 1
-point of a scaling curve equals the single-GPU bench); BASELINE's 8-GPU configuration is `--gpus 8 --workload s512 --sources 1000`
-(511 x 511 nodes, 32 periods, 8 x 1000 sources).  The row-sharded LSMR runs inside the library over its own RCCL communicator
+Multi-GPU: `python bench.py --gpus N` with no WORLD_SIZE in the environment launches itself as N ranks under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU); started by
+torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.  The default workload stays S-256 per rank
+(weak scaling, so that the N = 1 point of a scaling curve equals the single-GPU bench).  `--scaling strong` makes `--sources` the
+TOTAL number of sources: one fixed (period x source) field list, cut into N contiguous shards balanced by rays
+(dazimsurftomo_amd.distributed.shard_fields); BASELINE's 8-GPU configuration is literally
+`--gpus 8 --workload s512 --sources 8000 --scaling strong` (511 x 511 nodes, 32 periods, 8000 sources).  `--dry-launch` spawns the
+ranks, shards the work and prints the JSON skeleton without touching a GPU (gloo): the launch path's CPU test.  The row-sharded LSMR runs inside the library over its own RCCL communicator
 (dazim_comm_init; one n-float all-reduce + one scalar per iteration); if that communicator cannot be set up on every rank the
 run falls back to the torch.distributed driver (dazimsurftomo_amd/distributed.py) and says so in the JSON line (`lsmr.driver`).
 
@@ -131,6 +137,45 @@ def workload(nsrc, nrcv, rank):
     field_of_ray = np.repeat(np.arange(kmax * nsrc, dtype=np.int32), nr)
     ridx = np.tile(rcv, (kmax, 1)).reshape(-1)
     return scx, scz, per, field_of_ray, sx[ridx].copy(), sz[ridx].copy()
+
+
+def rank_workload(a, rank, world):
+    """this rank's fields and rays.  weak: its own a.sources stations (seeded by rank); strong: shard `rank` of the one field list
+    of a.sources stations x periods (period-major, as the reference orders its data), balanced by rays per field"""
+    if a.scaling == "weak" or world == 1:
+        scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, rank if a.scaling == "weak" else 0)
+        return scx, scz, per, field_of_ray, rcx, rcz, len(scx) * (world if a.scaling == "weak" else 1)
+    from dazimsurftomo_amd.distributed import shard_fields
+    scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, 0)
+    nfield = len(scx)
+    f0, f1 = shard_fields(nfield, world, rank, np.bincount(field_of_ray, minlength=nfield))
+    r0, r1 = np.searchsorted(field_of_ray, [f0, f1])
+    return (scx[f0:f1].copy(), scz[f0:f1].copy(), per[f0:f1].copy(), (field_of_ray[r0:r1] - f0).astype(np.int32),
+            rcx[r0:r1].copy(), rcz[r0:r1].copy(), nfield)
+
+
+def dry_launch(a, rank, world):
+    """--dry-launch: every rank joins a gloo group, takes its shard, and rank 0 prints the JSON skeleton (no GPU anywhere)"""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    scx, scz, per, field_of_ray, rcx, rcz, nfield_all = rank_workload(a, rank, world)
+    mine = torch.tensor([rank, len(scx), len(rcx), os.getpid()], dtype=torch.int64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        rows = [mine]
+    if rank == 0:
+        shards = [[int(v) for v in r] for r in rows]
+        print(json.dumps({"metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s", "dry_launch": True,
+                          "n_gpus": world, "scaling": a.scaling, "value": None, "unit": "fields/s",
+                          "ranks": [{"rank": r[0], "fields": r[1], "rays": r[2], "pid": r[3]} for r in shards],
+                          "total_fields": sum(r[1] for r in shards), "fields_in_list": int(nfield_all)}), flush=True)
 
 
 def tikhonov_rows(nx, ny, nz, dall, w):
@@ -270,6 +315,9 @@ def main():
     ap.add_argument("--lsmr-iters", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s256")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --sources per GPU; strong: --sources in total, one field list sharded over the ranks")
+    ap.add_argument("--dry-launch", action="store_true", help="spawn the ranks and shard the work, no GPU (CPU test of the launch path)")
     a = ap.parse_args()
     if a.sources is None:
         a.sources = 200 if a.workload == "s128" else 1000
@@ -277,10 +325,26 @@ def main():
         a.receivers = 16 if a.workload == "s128" else 32
     nnodes = set_workload(a.workload)
 
-    import torch
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: become N ranks, one per GPU (the driver's other form starts torch.distributed.run itself)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and "WORLD_SIZE" in os.environ and rank == 0:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE = {world}; the launcher's world size is used", file=sys.stderr)
+    if a.dry_launch:
+        return dry_launch(a, rank, world)
+
+    import torch
     # DAZIM_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, row-partitioned LSMR with
     # all-reduce) even with a single rank, so that it can be exercised on a 1-GPU box
     force_dist = os.environ.get("DAZIM_BENCH_FORCE_DIST") == "1"
@@ -327,21 +391,21 @@ def main():
                 ctx.comm_init(world, rank, box[0])
             except Exception as e:
                 ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
-        if want == "1" and not ok:
-            raise RuntimeError(lsmr_note or "in-library RCCL set-up failed")
         vote = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)     # (vote first, raise afterwards: no rank is left waiting in the collective)
         if int(vote.item()) == 0:
             if ok:
                 ctx.comm_free()
             native = False
             lsmr_note = lsmr_note or "in-library RCCL set-up failed on another rank"
+            if want == "1":
+                raise RuntimeError(lsmr_note)
 
     kmax = len(PERIODS)
     vel = s256_model()
-    scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, rank)
+    scx, scz, per, field_of_ray, rcx, rcz, nfield_all = rank_workload(a, rank, world)
     nfield, nray = len(scx), len(rcx)
-    rays_per_field = nray // nfield
+    rays_per_field = nray // max(nfield, 1)
     g = dz.geometry(NX, NY, GOXD, GOZD, DV, DV)
     T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     d_vel, d_scx, d_scz, d_per = T(vel), T(scx), T(scz), T(per)
@@ -401,11 +465,13 @@ def main():
             stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
             stats["nranks"] = ctx.kernel_seconds("lsmr.nranks")
+            stats["host_syncs"] = ctx.kernel_seconds("lsmr.host_syncs")      # counted by the library around the iteration loop
         else:           # row-partitioned G, one RCCL all-reduce of G^T u (n floats) + one scalar per iteration
             t_l = time.perf_counter()
             x, info = lsmr_distributed(GpuLocalOps(ctx, G), d_b, n_model, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10)
             torch.cuda.synchronize()
             stats["lsmr_s"] = time.perf_counter() - t_l
+            stats["host_syncs"] = info.get("host_syncs", -1)
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
         stats["spmv_kind"], stats["spmvt_kind"] = ctx.kernel_seconds("spmv.kind"), ctx.kernel_seconds("spmvt.kind")
         stats["ax_idx_bytes"], stats["aty_idx_bytes"] = ctx.kernel_seconds("spmv.idx_bytes"), ctx.kernel_seconds("spmvt.idx_bytes")
@@ -428,16 +494,19 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    total_fields = nfield
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        cnt = torch.tensor([nfield], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)                       # fields all ranks processed per step
+        total_fields = int(cnt.item())
 
     if rank == 0 and os.environ.get("DAZIM_BENCH_WALL") == "1":
         print("host wall ms per step:", {k: round(v / (a.steps + a.warmup) * 1e3, 2) for k, v in wall.items()}, file=sys.stderr)
     if rank == 0:
         ms = dt / a.steps * 1e3
-        total_fields = nfield * world
         fmm_gbs = BYTES_PER_FIELD * nfield / stats["fmm_s"] / 1e9
         m, n, nnz = stats["m"], stats["n"], stats["nnz"]
         traffic, traffic_src = profiled_traffic(a.workload, nfield, nnz)
@@ -457,10 +526,11 @@ def main():
             "metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s",
             "value": total_fields / (dt / a.steps), "unit": "fields/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-{ {'s128': 128, 's256': 256, 's512': 512}[a.workload] }: {NX}x{NY}x12 model -> {nnodes}x{nnodes} nodes, "
-                                   f"{len(PERIODS)} periods {PERIODS[0]:g}..{PERIODS[-1]:g} s, {a.sources} sources x "
-                                   f"{rays_per_field} receivers per GPU ({nfield} fields, {nray} rays), "
+                                   f"{len(PERIODS)} periods {PERIODS[0]:g}..{PERIODS[-1]:g} s, {a.sources} sources "
+                                   f"{'per GPU' if a.scaling == 'weak' else 'in total, sharded'} x "
+                                   f"{rays_per_field} receivers (rank 0: {nfield} fields, {nray} rays), "
                                    f"{a.lsmr_iters} LSMR iterations", "fields_per_gpu": nfield, "rays_per_gpu": nray},
             # the dominant kernel.  It is bound by the serial heap order of fast marching (instruction issue + small random record
             # accesses), not by HBM bandwidth: `bound` says so; the HBM fraction of its algorithmic bytes is still reported
@@ -488,7 +558,8 @@ def main():
                      "m": m, "n": n, "nnz": nnz},
             "lsmr": {"driver": ("in-library RCCL (dazim_comm_init)" if native else "torch.distributed (backend nccl = RCCL)") if use_dist
                                else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
-                     "host_syncs_per_iteration": 0.125 if (not use_dist or native) else 3},
+                     "host_syncs_per_iteration": (stats["host_syncs"] / max(stats["lsmr_itn"], 1)) if stats.get("host_syncs", -1) >= 0 else None,
+                     "host_syncs_note": "host waits on the device counted by the solver during its iteration loop / iterations"},
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],

@@ -22,16 +22,36 @@ def sources():
 
 
 def build(force=False):
-    """Compile every HIP source for gfx950 into lib/libdazim_hip.so (cross-compiles without a GPU)."""
+    """Compile every HIP source for gfx950 into lib/libdazim_hip.so (cross-compiles without a GPU): one object per source file,
+    compiled in parallel and only when the file, a header or the flags changed, then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     srcs = sources()
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    deps.append(os.path.join(ROOT, "include", "dazim.h"))
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(ROOT, "include", "dazim.h")]
     if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in srcs + hdrs):
             return LIB_PATH
-    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    libdir = os.path.dirname(LIB_PATH)
+    objdir = os.path.join(libdir, "obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + HIPCC_FLAGS + os.environ.get("DAZIM_HIPCC_EXTRA", "").split() + ["-o", LIB_PATH] + srcs
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("DAZIM_HIPCC_EXTRA", "").split()
+    stamp = " ".join([hipcc] + flags)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    tag = os.path.splitext(os.path.basename(LIB_PATH))[0]     # (DAZIM_LIB builds keep their own objects)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, f"{tag}.{os.path.basename(src)}.o")
+        cmdfile = obj + ".cmd"
+        fresh = (not force and os.path.exists(obj) and os.path.exists(cmdfile) and open(cmdfile).read() == stamp
+                 and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time))
+        if not fresh:
+            subprocess.check_call([hipcc] + flags + ["-c", "-o", obj, src])
+            with open(cmdfile, "w") as f:
+                f.write(stamp)
+        return obj
+    with ThreadPoolExecutor(max(1, min(len(srcs), os.cpu_count() or 1))) as ex:
+        objs = list(ex.map(compile_one, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if any(open(s).read().find("rccl.h") >= 0 for s in srcs):
         cmd += ["-lrccl"]
     subprocess.check_call(cmd)

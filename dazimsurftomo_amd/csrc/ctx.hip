@@ -22,6 +22,29 @@ bool dz_is_device_ptr(const void *p) {
   return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// Free every cached block nobody is using (staging blocks and matrix arrays).  Returns the bytes released.
+size_t dz_trim_caches(dazim_ctx *ctx) {
+  if (!ctx) return 0;
+  size_t freed = 0;
+  (void)hipStreamSynchronize(ctx->stream);
+  for (size_t i = ctx->stage.size(); i-- > 0;)
+    if (!ctx->stage[i].busy) { freed += ctx->stage[i].bytes; (void)hipFree(ctx->stage[i].p); ctx->stage.erase(ctx->stage.begin() + i); }
+  for (size_t i = ctx->big.size(); i-- > 0;)
+    if (!ctx->big[i].busy) { freed += ctx->big[i].bytes; (void)hipFree(ctx->big[i].p); ctx->big.erase(ctx->big.begin() + i); }
+  return freed;
+}
+
+// hipMalloc that gives the caches' idle memory back to the device before it reports out-of-memory: up to 24 GiB of freed
+// matrix arrays and 2 GiB of staging blocks may be parked there, which a failing allocation must be able to use.
+hipError_t dz_malloc_retry(dazim_ctx *ctx, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory && dz_trim_caches(ctx) > 0) {
+    (void)hipGetLastError();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
+
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
   auto &s = ctx->scratch[name];
   if (s.second < bytes) {
@@ -32,7 +55,7 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
     s.first = nullptr;
     s.second = 0;
     size_t want = bytes + bytes / 8;  // a little slack so slowly growing batches do not thrash
-    DZ_HIP(hipMalloc(&s.first, want));
+    DZ_HIP(dz_malloc_retry(ctx, &s.first, want));
     s.second = want;
   }
   *out = s.first;
@@ -54,7 +77,7 @@ int dz_stage_get(dazim_ctx *ctx, size_t bytes, void **out) {
     return 0;
   }
   void *p = nullptr;
-  DZ_HIP(hipMalloc(&p, bytes));
+  DZ_HIP(dz_malloc_retry(ctx, &p, bytes));
   ctx->stage.push_back({p, bytes, true});
   *out = p;
   return 0;
@@ -92,7 +115,7 @@ int dz_big_get(dazim_ctx *ctx, size_t bytes, void **out) {
     return 0;
   }
   void *p = nullptr;
-  DZ_HIP(hipMalloc(&p, bytes));
+  DZ_HIP(dz_malloc_retry(ctx, &p, bytes));
   ctx->big.push_back({p, bytes, true});
   *out = p;
   return 0;
@@ -190,7 +213,7 @@ const char *dazim_last_error(const dazim_ctx *ctx) { return ctx ? ctx->err.c_str
 
 int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes) {
   DZ_HIP(hipSetDevice(ctx->device));
-  DZ_HIP(hipMalloc(dptr, bytes));
+  DZ_HIP(dz_malloc_retry(ctx, dptr, bytes));
   return 0;
 }
 int dazim_free(dazim_ctx *ctx, void *dptr) {

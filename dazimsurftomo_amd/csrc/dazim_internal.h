@@ -48,11 +48,17 @@ int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
 // named scratch buffer of at least `bytes` bytes
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
 
+size_t dz_trim_caches(dazim_ctx *ctx);                                // free all idle cached blocks; bytes released
+hipError_t dz_malloc_retry(dazim_ctx *ctx, void **p, size_t bytes);   // hipMalloc; on out-of-memory trim the caches and retry once
 bool dz_is_device_ptr(const void *p);
 int dz_stage_get(dazim_ctx *ctx, size_t bytes, void **out);   // a device block of >= bytes from the context's staging cache
 void dz_stage_put(dazim_ctx *ctx, void *p);                   // give it back (kept for reuse; freed by dazim_destroy)
 int dz_big_get(dazim_ctx *ctx, size_t bytes, void **out);     // a device array for a matrix (see dazim_ctx::big)
 void dz_big_put(dazim_ctx *ctx, void *p);                     // return it (any hipMalloc'ed pointer is accepted; ctx may be null)
+
+// take ownership of device CSR arrays whose allocations hold cap_m rows / cap_nnz entries (0 = exactly m / nnz); sparse.hip
+extern "C" int dz_csr_adopt_cap(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col, float *val,
+                                int64_t cap_m, int64_t cap_nnz, dazim_csr **out);
 
 // every a[i] of a DEVICE array inside lo..hi?  Returns 0, or DAZIM_E_BAD_ARG with "<what> outside lo..hi" as the message.
 int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what);

@@ -597,7 +597,6 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
 }  // namespace
 
 struct dazim_csr;  // sparse.hip
-extern "C" void dz_csr_set_capacity(dazim_csr *A, int64_t cap_m, int64_t cap_nnz);
 extern "C" int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col,
                                float *val, dazim_csr **out);
 
@@ -698,6 +697,8 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = dz_scratch(ctx, "rays.lval", nr1 * A.LK * 4 * (joint ? 3 : 1), &p))) return rc;
   A.lval = (float *)p;
   int64_t *rowptr = nullptr;
+  float *val = nullptr;
+  int *col = nullptr;
   // the caller may announce rows it is going to append (regularisation): the CSR arrays then get that much slack and
   // dazim_csr_append_coo writes behind the ray rows instead of reallocating and copying the matrix
   // By default: one regularisation row per model parameter with the 7-point stencil of inv/TikhRegul.f90 (a few MB).
@@ -705,6 +706,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (ctx->opts.count("csr.reserve_rows") && ctx->opts["csr.reserve_rows"] > res_rows) res_rows = ctx->opts["csr.reserve_rows"];
   if (ctx->opts.count("csr.reserve_nnz") && ctx->opts["csr.reserve_nnz"] > res_nnz) res_nnz = ctx->opts["csr.reserve_nnz"];
   { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m + res_rows + 1) * 8, &pp))) return rc; rowptr = (int64_t *)pp; }
+  struct Arrays {   // the matrix arrays go back to the cache on every early return (until the matrix has adopted them)
+    dazim_ctx *c; int64_t *&rp; float *&v; int *&cl; bool keep = false;
+    ~Arrays() { if (!keep) { dz_big_put(c, rp); dz_big_put(c, v); dz_big_put(c, cl); } }
+  } arrays{ctx, rowptr, val, col};
   A.dsurf = dsurf.dev;
   A.rowptr = (const long *)rowptr;
   A.val = nullptr;
@@ -772,8 +777,6 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     DZ_HIP(hipMemcpyAsync(&nnz, rowptr + m, 8, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
-  float *val = nullptr;
-  int *col = nullptr;
   const int64_t cap_nnz = nnz + res_nnz;   // (options csr.reserve_rows / csr.reserve_nnz: room for rows appended later)
   { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4, &pp))) return rc; val = (float *)pp; }
   { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4, &pp))) return rc; col = (int *)pp; }
@@ -803,16 +806,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (nnz_out) *nnz_out = nnz;
   if ((rc = dsurf.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  if (err) {
-    dz_big_put(ctx, rowptr);
-    dz_big_put(ctx, val);
-    dz_big_put(ctx, col);
-    return err;
-  }
+  if (err) return err;
   const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1);
-  int rca = dazim_csr_adopt(ctx, m, n, nnz, rowptr, col, val, G);
-  if (!rca && (res_rows > 0 || res_nnz > 0)) dz_csr_set_capacity(*G, m + res_rows, cap_nnz);
-  return rca;
+  arrays.keep = true;   // adopted (dz_csr_adopt_cap frees them itself if it fails)
+  return dz_csr_adopt_cap(ctx, m, n, nnz, rowptr, col, val, m + res_rows, cap_nnz, G);
 }
 
 // = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields

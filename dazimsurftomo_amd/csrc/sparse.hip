@@ -828,10 +828,10 @@ int build_transpose(dazim_ctx *ctx, dazim_csr *A) {
   const size_t nz = (size_t)(nnz > 0 ? nnz : 1);
   for (void **pp : {(void **)&A->colptr, (void **)&A->row, (void **)&A->tval, (void **)&A->tperm})
     if (*pp) { (void)hipFree(*pp); *pp = nullptr; }
-  DZ_HIP(hipMalloc((void **)&A->colptr, (n + 1) * 8));
-  DZ_HIP(hipMalloc((void **)&A->row, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->tval, nz * 4));
-  DZ_HIP(hipMalloc((void **)&A->tperm, nz * 4));
+  DZ_HIP(dz_malloc_retry(ctx, (void **)&A->colptr, (n + 1) * 8));
+  DZ_HIP(dz_malloc_retry(ctx, (void **)&A->row, nz * 4));
+  DZ_HIP(dz_malloc_retry(ctx, (void **)&A->tval, nz * 4));
+  DZ_HIP(dz_malloc_retry(ctx, (void **)&A->tperm, nz * 4));
   if (nnz == 0) {
     DZ_HIP(hipMemsetAsync(A->colptr, 0, (n + 1) * 8, ctx->stream));
     return 0;
@@ -1291,10 +1291,20 @@ int dazim_csr_from_coo(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const 
 // take ownership of device CSR arrays (hipMalloc'ed: rowptr[m+1], col[nnz] 0-based, val[nnz])
 int dazim_csr_adopt(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col, float *val,
                     dazim_csr **out) {
+  return dz_csr_adopt_cap(ctx, m, n, nnz, rowptr, col, val, 0, 0, out);
+}
+
+// (library-internal) the same for arrays that are larger than m / nnz (room for rows appended later, dazim_csr::cap_m): the
+// capacities are known BEFORE the column blocks are built, so the 16-bit column copy is sized for the reserved entries once
+// and an append only narrows its own tail
+int dz_csr_adopt_cap(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col, float *val,
+                     int64_t cap_m, int64_t cap_nnz, dazim_csr **out) {
   if (!ctx || !out || !rowptr) return DAZIM_E_BAD_ARG;
   dazim_csr *A = new dazim_csr;
   A->m = m; A->n = n; A->nnz = nnz;
   A->rowptr = rowptr; A->col = col; A->val = val;
+  if (cap_m > m) A->cap_m = cap_m;
+  if (cap_nnz > nnz) A->cap_nnz = cap_nnz;
   int rc;
   if ((rc = build_colblocks(ctx, A)) || (rc = invalidate_transpose(A))) {
     dazim_csr_free(ctx, A);   // ownership was taken: the arrays go with it
@@ -1365,12 +1375,6 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
   return 0;
 }
 
-// (library-internal) the arrays a matrix has adopted are larger than m / nnz: see dazim_csr::cap_m
-extern "C" void dz_csr_set_capacity(dazim_csr *A, int64_t cap_m, int64_t cap_nnz) {
-  if (!A) return;
-  A->cap_m = cap_m;
-  A->cap_nnz = cap_nnz;
-}
 
 // copy the matrix out as the reference's COO triplets (1-based), rows ascending
 int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow_u, int *icol_u, float *rw_u) {
@@ -1519,6 +1523,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   ncclComm_t comm = (ncclComm_t)ctx->comm;   // non-null: A, b are this rank's rows of one global system
   void *p;
   double *d_sum = nullptr;
+  long long *d_cons = nullptr;
   float *wbuf = nullptr;
   int64_t m_glob = m;
   int localVecs = 0;
@@ -1534,6 +1539,8 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     if ((r = b.init(ctx, b_u, m, true, false))) return r;
     if ((r = x.init(ctx, x_u, n, false, true))) return r;
     if (comm) {
+      if ((r = dz_scratch(ctx, "lsmr.cons", 64, &p))) return r;   // consensus words: from the scratch pool, inside the voted set-up
+      d_cons = (long long *)p;
       if ((r = dz_scratch(ctx, "lsmr.sum", 64, &p))) return r;
       d_sum = (double *)p;
       if ((r = dz_scratch(ctx, "lsmr.w", n * 4, &p))) return r;
@@ -1563,14 +1570,32 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
       d_trace = (dazim_lsmr_rec *)p;
     }
     if (!use_scatter(ctx, A) && !A->colptr && (r = build_transpose(ctx, const_cast<dazim_csr *>(A)))) return r;
+    // the reorthogonalisation window, sized by its upper bound min(localSize, n) (the global row count, known after the
+    // consensus, can only make it smaller): allocated here so that its failure is part of the vote
+    const int64_t lv = localSize < 0 ? 0 : (localSize < n ? localSize : n);
+    if (lv > 0) {
+      if ((r = dz_scratch(ctx, "lsmr.localV", (size_t)n * lv * 4, &p))) return r;
+      localV = (float *)p;
+    }
     return 0;
+  };
+  // after the consensus a rank that fails on its own must not leave the others waiting in a collective: abort the communicator
+  // (every pending and future collective on it returns an error on every rank) and detach it
+  auto leave = [&](int code) -> int {
+    if (comm) {
+      (void)ncclCommAbort(comm);
+      ctx->comm = nullptr;
+      ctx->nranks = 1;
+      ctx->rank = 0;
+      comm = nullptr;
+    }
+    return code;
   };
   rc = setup();
   if (comm) {   // agree on (failure, n, m_total): every rank leaves together or none does
-    long long hv[4] = {rc != 0 ? 1 : 0, (long long)n, -(long long)n, 0}, *dv = nullptr;
+    long long hv[4] = {rc != 0 ? 1 : 0, (long long)n, -(long long)n, 0}, *dv = d_cons;
     double hm = (double)m;
-    bool ok = rc == 0 || d_sum != nullptr;
-    if (hipMalloc((void **)&dv, sizeof hv + 8) != hipSuccess) return dz_fail(ctx, -3, "row-sharded LSMR: no memory for the consensus buffer");
+    if (!dv) return leave(rc ? rc : dz_fail(ctx, -3, "row-sharded LSMR: no memory for the consensus buffer"));
     (void)hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(dv + 4, &hm, 8, hipMemcpyHostToDevice, ctx->stream);
     ncclResult_t r1 = ncclAllReduce(dv, dv, 3, ncclInt64, ncclMax, comm, ctx->stream);
@@ -1578,8 +1603,6 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     (void)hipMemcpyAsync(hv, dv, sizeof hv, hipMemcpyDeviceToHost, ctx->stream);
     (void)hipMemcpyAsync(&hm, dv + 4, 8, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dv);
-    (void)ok;
     if (rc) return rc;
     if (r1 != ncclSuccess || r2 != ncclSuccess || e != hipSuccess) return dz_fail(ctx, -2000, "row-sharded LSMR: consensus all-reduce failed");
     if (hv[0]) return dz_fail(ctx, -2001, "row-sharded LSMR: another rank failed during set-up");
@@ -1588,13 +1611,11 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   } else if (rc) {
     return rc;
   }
+  // ---- from here on a local failure (a launch, a copy, a collective) aborts the communicator: see `leave` ----
+  auto solve = [&]() -> int {
   localVecs = localSize < 0 ? 0 : localSize;
   if (m_glob < localVecs) localVecs = (int)m_glob;
   if (n < localVecs) localVecs = (int)n;
-  if (localVecs > 0) {   // (after the consensus: sized by the global row count)
-    if ((rc = dz_scratch(ctx, "lsmr.localV", (size_t)n * localVecs * 4, &p))) return rc;
-    localV = (float *)p;
-  }
   constexpr int CHECK = 8, NSLOT = 2;
   struct Guard {   // pinned state copies + events, released on every exit path
     LsmrState *h = nullptr;
@@ -1653,6 +1674,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   int ntrace = 0;
   double t_spmv = 0, t_spmvt = 0;
   int n_spmv = 0, n_spmvt = 0;
+  int host_syncs = 0;   // host waits on the device inside the iteration loop (one per examined batch of CHECK iterations)
   // u = b ; beta = ||u|| ; u /= beta ; v = A^T u ; alpha = ||v|| ; v /= alpha   (:355-372)
   hipLaunchKernelGGL(k_copy, dim3(bm), dim3(VB), 0, ctx->stream, m, b.dev, u);
   DZ_HIP(hipMemsetAsync(v, 0, n * 4, ctx->stream));
@@ -1745,6 +1767,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
       while (examined < nbatch - keep && !stopped) {
         const int ls = examined % NSLOT;
         DZ_HIP(hipEventSynchronize(guard.done[ls]));
+        host_syncs++;
         float ms = 0;
         if (hipEventElapsedTime(&ms, guard.ta[ls][0], guard.ta[ls][1]) == hipSuccess) { t_spmv += ms * 1e-3; n_spmv++; }
         if (hipEventElapsedTime(&ms, guard.ta[ls][2], guard.ta[ls][3]) == hipSuccess) { t_spmvt += ms * 1e-3; n_spmvt++; }
@@ -1774,6 +1797,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   ctx->ksec["spmv"] = n_spmv ? t_spmv / n_spmv : -1.0;
   ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
   ctx->ksec["lsmr.normb"] = normb;
+  ctx->ksec["lsmr.host_syncs"] = host_syncs;
   {
     int nr = 1;
     if (comm) (void)ncclCommCount(comm, &nr);
@@ -1790,6 +1814,9 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   if ((rc = x.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+  };
+  rc = solve();
+  return rc ? leave(rc) : 0;
 }
 
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp, float atol, float btol,

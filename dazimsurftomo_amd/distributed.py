@@ -86,9 +86,15 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return t
 
+    syncs = [0]                  # device -> host scalar reads (each one waits for the device)
+
+    def host(t):
+        syncs[0] += 1
+        return float(t.item())
+
     def gnorm_u(u):              # ||u|| over all ranks: local sum of squares in fp64, one scalar all-reduce
         s = allsum_((u.double() ** 2).sum().reshape(1))
-        return _f32(np.sqrt(float(s.item())))
+        return _f32(np.sqrt(host(s)))
 
     damp, atol, btol, conlim = map(_f32, (damp, atol, btol, conlim))
     m_local = b_local.shape[0]
@@ -105,7 +111,7 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
         u.mul_(float(_f32(1) / beta))
         ops.aprod2(v, u)
         allsum_(v)                                   # the one n-vector all-reduce of this half-step
-        alpha = _f32(np.sqrt(float((v.double() ** 2).sum().item())))
+        alpha = _f32(np.sqrt(host((v.double() ** 2).sum())))
     if alpha > 0:
         v.mul_(float(_f32(1) / alpha))
     normAr = _f32(alpha * beta)
@@ -127,6 +133,7 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
     itn = istop = 0
     normA = condA = normx = _f32(0)
     w = torch.empty(n, dtype=f32, device=dev)
+    syncs[0] = 0                                      # counted over the iteration loop only
     while True:
         itn += 1
         u.mul_(float(-alpha))
@@ -149,7 +156,7 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
                 for q in range(lim):
                     dq = torch.dot(v, localV[q])
                     v.sub_(localV[q] * dq)
-            alpha = _f32(np.sqrt(float((v.double() ** 2).sum().item())))
+            alpha = _f32(np.sqrt(host((v.double() ** 2).sum())))
             if alpha > 0:
                 v.mul_(float(_f32(1) / alpha))
         alphahat = _d2norm(alphabar, damp)
@@ -193,7 +200,7 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
             minrbar = min(minrbar, rhobarold)
         condA = _f32(max(maxrbar, rhotemp) / min(minrbar, rhotemp))
         normAr = _f32(abs(zetabar))
-        normx = _f32(np.sqrt(float((x.double() ** 2).sum().item())))
+        normx = _f32(np.sqrt(host((x.double() ** 2).sum())))
         test1 = _f32(normr / normb)
         test2 = _f32(normAr / _f32(normA * normr))
         test3 = _f32(_f32(1) / condA)
@@ -211,5 +218,5 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
     if damp > 0 and istop == 2:
         istop = 3
     info.update(istop=int(istop), itn=itn, normA=float(normA), condA=float(condA), normr=float(normr),
-                normAr=float(normAr), normx=float(normx))
+                normAr=float(normAr), normx=float(normx), host_syncs=syncs[0])
     return x, info

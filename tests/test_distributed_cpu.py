@@ -104,3 +104,36 @@ def test_lsmr_distributed_single_process_equals_oracle(orc):
     xo, io = orc.lsmr(m, 200, irow, icol, rw, b, *cfg)
     assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3
     assert np.linalg.norm(x.numpy() - xo) <= 1e-3 * np.linalg.norm(xo)
+
+
+def _bench(*args, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's command form) must become two ranks under
+    torch.distributed.run: two distinct processes, every field of the two weak-scaling batches accounted for."""
+    d = _bench("--gpus", "2", "--dry-launch", "--workload", "s128", "--sources", "12", "--receivers", "4")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["dry_launch"] is True
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["ranks"][0]["pid"] != d["ranks"][1]["pid"]
+    assert [r["fields"] for r in d["ranks"]] == [8 * 12, 8 * 12] and d["total_fields"] == 2 * 8 * 12
+    assert [r["rays"] for r in d["ranks"]] == [8 * 12 * 4] * 2
+
+
+def test_bench_strong_scaling_shards_one_field_list():
+    """--scaling strong: --sources is the total; the ranks' shards are contiguous, disjoint and cover the one list (BASELINE's
+    configuration 5 is this with --gpus 8 --workload s512 --sources 8000)"""
+    one = _bench("--gpus", "1", "--dry-launch", "--workload", "s128", "--sources", "15", "--receivers", "4", "--scaling", "strong")
+    two = _bench("--gpus", "2", "--dry-launch", "--workload", "s128", "--sources", "15", "--receivers", "4", "--scaling", "strong")
+    assert one["n_gpus"] == 1 and one["total_fields"] == 8 * 15
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["total_fields"] == 8 * 15 == two["fields_in_list"]
+    f = [r["fields"] for r in two["ranks"]]
+    assert abs(f[0] - f[1]) <= 1 and sum(r["rays"] for r in two["ranks"]) == 8 * 15 * 4
