@@ -328,6 +328,26 @@ class SparseMatrix:
         self.ctx._check(self.ctx.lib.dazim_csr_dims(self._h, C.byref(m0), None, C.byref(z0)))
         self.m, self.nnz = m0.value, z0.value
 
+    def take_twin(self):
+        """the dense twin (the reference's GVs | GGc | GGs) of a matrix built with option rays.dense_twin = 1, or None"""
+        h = C.c_void_p()
+        self.ctx._check(self.ctx.lib.dazim_csr_take_twin(self.ctx._h, self._h, C.byref(h)))
+        if not h.value:
+            return None
+        m0, z0 = C.c_int64(0), C.c_int64(0)
+        self.ctx._check(self.ctx.lib.dazim_csr_dims(h, C.byref(m0), None, C.byref(z0)))
+        return SparseMatrix(self.ctx, h, m0.value, self.n, z0.value)
+
+    def threshold(self, tol, reserve_rows=0, reserve_nnz=0):
+        """a new matrix holding the entries with |value| > tol (dazim_csr_threshold): the solver's triplets (inv/CalSurfG.f90:1358)
+        from a matrix built with option rays.keep_small (the entries of the reference's dense GVs/GGc/GGs, :1369-1378)"""
+        h = C.c_void_p()
+        self.ctx._check(self.ctx.lib.dazim_csr_threshold(self.ctx._h, self._h, C.c_float(tol), C.c_int64(reserve_rows),
+                                                         C.c_int64(reserve_nnz), C.byref(h)))
+        m0, z0 = C.c_int64(0), C.c_int64(0)
+        self.ctx._check(self.ctx.lib.dazim_csr_dims(h, C.byref(m0), None, C.byref(z0)))
+        return SparseMatrix(self.ctx, h, m0.value, self.n, z0.value)
+
     def to_coo(self):
         irow = np.zeros(self.nnz, np.int32); icol = np.zeros(self.nnz, np.int32); rw = np.zeros(self.nnz, np.float32)
         self.ctx._check(self.ctx.lib.dazim_csr_to_coo(self.ctx._h, self._h, _ptr(irow), _ptr(icol), _ptr(rw)))

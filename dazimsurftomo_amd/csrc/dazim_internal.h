@@ -60,6 +60,9 @@ void dz_big_put(dazim_ctx *ctx, void *p);                     // return it (any 
 extern "C" int dz_csr_adopt_cap(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t *rowptr, int *col, float *val,
                                 int64_t cap_m, int64_t cap_nnz, dazim_csr **out);
 
+// attach B as the "dense twin" of A (A owns it until dazim_csr_take_twin hands it out; dazim_csr_free(A) frees an attached twin)
+extern "C" int dz_csr_set_twin(dazim_ctx *ctx, dazim_csr *A, dazim_csr *B);
+
 // every a[i] of a DEVICE array inside lo..hi?  Returns 0, or DAZIM_E_BAD_ARG with "<what> outside lo..hi" as the message.
 int dz_check_range(dazim_ctx *ctx, const int *a_dev, int64_t n, int lo, int hi, const char *what);
 

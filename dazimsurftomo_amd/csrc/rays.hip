@@ -58,7 +58,14 @@ struct RayArgs {
   const unsigned *perm;    // [nray] order in which the rays are dealt to the lane groups: by field, then by source-receiver
                            // distance, so that the rays marching in lockstep in one wavefront have similar lengths (speed only:
                            // everything a ray produces is stored under its own index)
-  unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD)
+  unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD); [16] rays whose cell list outgrew
+                           // the LDS capacity (full-grid sweep), [17] rays whose list outgrew LK (traced again by the emit pass)
+  int dense;               // the reference's dense copies GVs/GGc/GGs as a second matrix ("twin", option rays.dense_twin):
+                           // 0 off; 2 (count pass): also count the twin's entries into countd; 1 (a second emit pass): write the
+                           // twin -- every non-zero entry of the |fdm| >= ftol cells, the dVs block with the Brocher derivatives
+                           // coe_a / coe_rho of the LAST such cell of the ray, which is what the reference's second loop uses
+                           // (inv/CalSurfG.f90:1369-1378, inv/CalSurfGAniso_Joint.f90:759-775 do not recompute them)
+  long *countd;            // [nray] twin entries per row (count pass out when dense = 2)
   int keep_small;          // 1: keep every non-zero row entry of the |fdm| >= ftol cells (the forward program's dense GGc/GGs,
                            // fwd/FwdTraveltimeCPS.f90:694-712); 0: the inversion's second |row| > ftol threshold
   const long *rowptr;      // [nray+1] (emit pass in)
@@ -552,11 +559,31 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     const int nparpi = nvx * nvz * (A.nz - 1);
     const bool lovf = nlist > LC;                       // list did not fit: sweep the whole grid instead (rare)
     const int ntot = lovf ? nvz * nvx : nlist;
+    long cntd = 0;
+    int jjL = 1, kkL = 1;                               // dense twin: the last cell with |fdm| >= ftol in (jj, kk) order
+    if (A.dense) {
+      int clast = -1;
+      if (!lovf) {
+        if (nlist > 0) clast = s_list[nlist - 1];
+      } else {
+        for (int base = ((nvz * nvx - 1) / GP) * GP; base >= 0 && clast < 0; base -= GP) {
+          const int c = base + gl;
+          bool k2 = false;
+          if (c < nvz * nvx) {
+            const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+            k2 = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
+          }
+          const unsigned m2 = (unsigned)((__ballot(k2) >> gmask_shift) & GMASK);
+          if (m2) clast = base + (31 - __clz(m2));
+        }
+      }
+      if (clast >= 0) { jjL = clast / nvx + 1; kkL = clast - (jjL - 1) * nvx + 1; }
+    }
     for (int blk = 0; blk < NG; blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
       for (int k = 1; k <= A.nz - 1; k++) {
         for (int base = 0; base < ntot; base += GP) {
           const int li = base + gl;
-          bool keep = false;
+          bool keep = false, keepd = false;
           float rowv = 0.0f;
           int nn = 0;
           bool cell = li < ntot;
@@ -575,12 +602,25 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
                                              0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
               const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
               rowv = (float)r;
+              if (A.dense) {   // the same expression with the derivatives left over from the last cell of the first loop
+                const float vL = A.vels[((size_t)(k - 1) * A.ny + jjL) * A.nx + kkL];
+                const float caL = (2.0947f - 0.8206f * 2 * vL + 0.2683f * 3 * (vL * vL) - 0.0251f * 4 * (vL * vL * vL));
+                const float vpL = 0.9409f + 2.0947f * vL - 0.8206f * (vL * vL) + 0.2683f * (vL * vL * vL) - 0.0251f * (vL * vL * vL * vL);
+                const float crL = caL * (1.6612f - 0.4721f * 2 * vpL + 0.0671f * 3 * (vpL * vpL) -
+                                         0.0043f * 4 * (vpL * vpL * vpL) + 0.000106f * 5 * (vpL * vpL * vpL * vpL));
+                const double rd = (A.svp[si] * (double)caL + A.srho[si] * (double)crL + A.svs[si]) * (double)fd;
+                keepd = (float)rd != 0.0f;
+                if (EMIT && A.dense == 1) rowv = (float)rd;
+              }
             } else {
               rowv = A.lsen[si] * (blk == 1 ? gfdmc : gfdms)[kk * ldf + jj];
+              keepd = rowv != 0.0f;
             }
             keep = A.keep_small ? (rowv != 0.0f) : (fabsf(rowv) > FTOL);
+            if (EMIT && A.dense == 1) keep = keepd;
             nn = blk * nparpi + (k - 1) * nvz * nvx + (jj - 1) * nvx + kk;  // 1-based column of the reference
           }
+          if (!EMIT && A.dense == 2) cntd += __popc((unsigned)((__ballot(keepd) >> gmask_shift) & GMASK));
           const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & GMASK);
           if (EMIT && keep) {
             const long pos = rstart + cnt + __popc(m & ((1u << gl) - 1u));
@@ -590,7 +630,12 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           cnt += __popc(m);
         }
       }
-    if (!EMIT && gl == 0) A.count[ray] = cnt;
+    if (!EMIT && gl == 0) {
+      A.count[ray] = cnt;
+      if (A.dense == 2) A.countd[ray] = cntd;
+      if (lovf) atomicAdd(&A.qcount[16], 1u);           // (statistics only: dazim_last_kernel_seconds("rays.list_sweeps"))
+      if (!status && nlist > A.LK) atomicAdd(&A.qcount[17], 1u);
+    }
   }
 }
 
@@ -690,6 +735,14 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (A.lcap > g.nvx * g.nvz) A.lcap = g.nvx * g.nvz;
   A.LK = A.lcap;   // cell lists handed from the count pass to the emit pass (longer ones are traced again)
   A.keep_small = ctx->opts.count("rays.keep_small") && ctx->opts["rays.keep_small"] ? 1 : 0;
+  const bool twin = ctx->opts.count("rays.dense_twin") && ctx->opts["rays.dense_twin"] && !A.keep_small;
+  A.dense = twin ? 2 : 0;
+  A.countd = nullptr;
+  if (twin) {
+    if ((rc = dz_scratch(ctx, "rays.countd", (size_t)(m + 1) * 8, &p))) return rc;
+    A.countd = (long *)p;
+    DZ_HIP(hipMemsetAsync(A.countd, 0, (size_t)(m + 1) * 8, ctx->stream));
+  }
   if ((rc = dz_scratch(ctx, "rays.nlist", nr1 * 4, &p))) return rc;
   A.nlist = (int *)p;
   if ((rc = dz_scratch(ctx, "rays.lcell", nr1 * A.LK * 2, &p))) return rc;
@@ -756,9 +809,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       A.perm = v1;
     }
   }
-  if ((rc = dz_scratch(ctx, "rays.qcount", 64, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "rays.qcount", 128, &p))) return rc;
   A.qcount = (unsigned *)p;
-  DZ_HIP(hipMemsetAsync(A.qcount, 0, 64, ctx->stream));
+  DZ_HIP(hipMemsetAsync(A.qcount, 0, 128, ctx->stream));
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
@@ -789,9 +842,41 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       hipLaunchKernelGGL((rays_kernel<true, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
     DZ_HIP(hipGetLastError());
   }
+  // ---- the dense twin: a second emit pass over the saved cell lists (no ray is traced again unless its list did not fit) ----
+  int64_t *rowptr_d = nullptr;
+  float *val_d = nullptr;
+  int *col_d = nullptr;
+  Arrays arrays_d{ctx, rowptr_d, val_d, col_d};
+  int64_t nnz_d = 0;
+  if (twin) {
+    { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m + 1) * 8, &pp))) return rc; rowptr_d = (int64_t *)pp; }
+    size_t tb = 0;
+    DZ_HIP(rocprim::exclusive_scan(nullptr, tb, A.countd, (long *)rowptr_d, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+    if ((rc = dz_scratch(ctx, "rays.scan", tb + 256, &p))) return rc;
+    DZ_HIP(rocprim::exclusive_scan(p, tb, A.countd, (long *)rowptr_d, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+    DZ_HIP(hipMemcpyAsync(&nnz_d, rowptr_d + m, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nnz_d > 0 ? nnz_d : 1) * 4, &pp))) return rc; val_d = (float *)pp; }
+    { void *pp; if ((rc = dz_big_get(ctx, (size_t)(nnz_d > 0 ? nnz_d : 1) * 4, &pp))) return rc; col_d = (int *)pp; }
+    RayArgs D = A;
+    D.dense = 1;
+    D.rowptr = (const long *)rowptr_d;
+    D.val = val_d;
+    D.col = col_d;
+    DZ_HIP(hipMemsetAsync(A.qcount + 8, 0, 32, ctx->stream));   // the emit pass's task counters
+    if (nray > 0) {
+      if (joint)
+        hipLaunchKernelGGL((rays_kernel<true, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, D);
+      else
+        hipLaunchKernelGGL((rays_kernel<true, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, D);
+      DZ_HIP(hipGetLastError());
+    }
+  }
   t.stop();
   // statuses: first failing ray is the reference's STOP
   std::vector<int> hs(nr1), hb(nr1);
+  unsigned hq[2] = {0, 0};
+  if (nray > 0) DZ_HIP(hipMemcpyAsync(hq, A.qcount + 16, 8, hipMemcpyDeviceToHost, ctx->stream));
   if (nray > 0) {
     DZ_HIP(hipMemcpyAsync(hs.data(), A.status, nray * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipMemcpyAsync(hb.data(), A.rbflag, nray * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -804,12 +889,25 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   }
   if (n_boundary) *n_boundary = nb;
   if (nnz_out) *nnz_out = nnz;
+  ctx->ksec["rays.list_sweeps"] = hq[0];     // rays that took the full-grid sweep instead of the LDS cell list
+  ctx->ksec["rays.list_retraced"] = hq[1];   // rays the emit pass traced a second time
+  ctx->ksec["rays.lcap"] = A.lcap;
   if ((rc = dsurf.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   if (err) return err;
   const int64_t n = (int64_t)g.nvx * g.nvz * (nz - 1) * (joint ? 3 : 1);
   arrays.keep = true;   // adopted (dz_csr_adopt_cap frees them itself if it fails)
-  return dz_csr_adopt_cap(ctx, m, n, nnz, rowptr, col, val, m + res_rows, cap_nnz, G);
+  if ((rc = dz_csr_adopt_cap(ctx, m, n, nnz, rowptr, col, val, m + res_rows, cap_nnz, G))) return rc;
+  if (twin) {
+    dazim_csr *Gd = nullptr;
+    arrays_d.keep = true;
+    if ((rc = dz_csr_adopt_cap(ctx, m, n, nnz_d, rowptr_d, col_d, val_d, 0, 0, &Gd)) || (rc = dz_csr_set_twin(ctx, *G, Gd))) {
+      dazim_csr_free(ctx, *G);
+      *G = nullptr;
+      return rc;
+    }
+  }
+  return 0;
 }
 
 // = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364) for every ray of a batch of fields

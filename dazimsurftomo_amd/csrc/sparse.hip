@@ -34,6 +34,7 @@ struct dazim_csr {
   // the options csr.reserve_rows / csr.reserve_nnz ask for, so that the regularisation rows are appended in place
   // (0: exactly m / nnz)
   int64_t cap_m = 0, cap_nnz = 0;
+  dazim_csr *twin = nullptr;   // option rays.dense_twin: the reference's dense copies GVs | GGc | GGs of the same rows
 };
 
 namespace {
@@ -1032,6 +1033,39 @@ __device__ __forceinline__ bool tikh_face(int cell, int nvx, int nvz, int nzm1, 
   i = r - j * nvx;
   return i == 0 || i == nvx - 1 || j == 0 || j == nvz - 1 || k == 0 || k == nzm1 - 1;
 }
+// dazim_csr_threshold: one wavefront per row; entries with |val| > tol keep their order (ballot prefix)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_threshold_rows(int64_t m, const int64_t *__restrict__ rowptr, const int *__restrict__ col,
+                                                        const float *__restrict__ val, float tol, long *__restrict__ cnt,
+                                                        const long *__restrict__ rowptr2, int *__restrict__ col2,
+                                                        float *__restrict__ val2) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r > m) return;
+  if (r == m) {
+    if (!FILL && lane == 0) cnt[m] = 0;
+    return;
+  }
+  const int64_t s = rowptr[r], e = rowptr[r + 1];
+  long kept = 0;
+  const long o = FILL ? rowptr2[r] : 0;
+  for (int64_t i = s; i < e; i += 64) {
+    const int64_t k = i + lane;
+    float v = 0.0f;
+    int c = 0;
+    if (k < e) { v = val[k]; c = col[k]; }
+    const bool keep = k < e && fabsf(v) > tol;
+    const unsigned long long b = __ballot(keep);
+    if (FILL && keep) {
+      const long q = o + kept + __popcll(b & ((1ull << lane) - 1ull));
+      val2[q] = v;
+      col2[q] = c;
+    }
+    kept += __popcll(b);
+  }
+  if (!FILL && lane == 0) cnt[r] = kept;
+}
+
 __global__ void k_tikh_count(int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, long *cnt) {
   const int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x;
   if (r > nrow) return;
@@ -1192,8 +1226,22 @@ __global__ void k_update_stats(int ncell, const float *dv, float *out) {
 
 extern "C" {
 
+int dz_csr_set_twin(dazim_ctx *ctx, dazim_csr *A, dazim_csr *B) {
+  if (!A || !B || A->twin) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dz_csr_set_twin");
+  A->twin = B;
+  return 0;
+}
+// hand out the dense twin of a matrix built with option rays.dense_twin = 1 (NULL if there is none); the caller frees it
+int dazim_csr_take_twin(dazim_ctx *ctx, dazim_csr *A, dazim_csr **twin) {
+  if (!A || !twin) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_take_twin");
+  *twin = A->twin;
+  A->twin = nullptr;
+  return 0;
+}
+
 int dazim_csr_free(dazim_ctx *ctx, dazim_csr *A) {
   if (!A) return 0;
+  if (A->twin) { dazim_csr *t = A->twin; A->twin = nullptr; (void)dazim_csr_free(ctx, t); }
   if (ctx) DZ_HIP(hipStreamSynchronize(ctx->stream));   // (a matrix may outlive its context: the arrays are still freed)
   else (void)hipDeviceSynchronize();
   void *ps[] = {A->rowptr, A->colptr, A->col, A->row, A->val, A->tval, A->tperm, A->cbptr, A->col16};
@@ -1313,6 +1361,47 @@ int dz_csr_adopt_cap(dazim_ctx *ctx, int64_t m, int64_t n, int64_t nnz, int64_t 
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   *out = A;
   return 0;
+}
+
+// B = the entries of A with |value| > tol, same shape and order.  The reference keeps two copies of every ray row: the
+// triplets rw/iw/col hold the entries with |row| > ftol (inv/CalSurfG.f90:1358), the dense GVs/GGc/GGs every entry of the cells
+// with |fdm| >= ftol (:1369-1378), and its residual diagnostics multiply with the dense ones (inv/CalSigamNorm.f90:73).  A
+// program that wants both builds the matrix once with option rays.keep_small and derives the solver's matrix here: two
+// streaming passes instead of tracing the rays twice.  reserve_rows / reserve_nnz: room for rows appended to B later.
+int dazim_csr_threshold(dazim_ctx *ctx, const dazim_csr *A, float tol, int64_t reserve_rows, int64_t reserve_nnz, dazim_csr **out) {
+  if (!ctx || !A || !out || reserve_rows < 0 || reserve_nnz < 0) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_threshold");
+  DZ_HIP(hipSetDevice(ctx->device));
+  const int64_t m = A->m;
+  int rc;
+  void *p;
+  if ((rc = dz_scratch(ctx, "thr.cnt", (size_t)(m + 1) * 8, &p))) return rc;
+  long *cnt = (long *)p;
+  int64_t *rowptr = nullptr;
+  float *val = nullptr;
+  int *col = nullptr;
+  struct Arrays {
+    dazim_ctx *c; int64_t *&rp; float *&v; int *&cl; bool keep = false;
+    ~Arrays() { if (!keep) { dz_big_put(c, rp); dz_big_put(c, v); dz_big_put(c, cl); } }
+  } arrays{ctx, rowptr, val, col};
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(m + reserve_rows + 1) * 8, &pp))) return rc; rowptr = (int64_t *)pp; }
+  const unsigned nb = (unsigned)((m + 1 + 3) / 4);
+  hipLaunchKernelGGL((k_threshold_rows<false>), dim3(nb), dim3(256), 0, ctx->stream, m, A->rowptr, A->col, A->val, tol, cnt,
+                     (const long *)nullptr, (int *)nullptr, (float *)nullptr);
+  size_t tb = 0;
+  DZ_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+  if ((rc = dz_scratch(ctx, "thr.scan", tb + 256, &p))) return rc;
+  DZ_HIP(rocprim::exclusive_scan(p, tb, cnt, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
+  long nnz = 0;
+  DZ_HIP(hipMemcpyAsync(&nnz, rowptr + m, 8, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t cap = nnz + reserve_nnz;
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap > 0 ? cap : 1) * 4, &pp))) return rc; val = (float *)pp; }
+  { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap > 0 ? cap : 1) * 4, &pp))) return rc; col = (int *)pp; }
+  hipLaunchKernelGGL((k_threshold_rows<true>), dim3(nb), dim3(256), 0, ctx->stream, m, A->rowptr, A->col, A->val, tol, cnt,
+                     (const long *)rowptr, col, val);
+  DZ_HIP(hipGetLastError());
+  arrays.keep = true;
+  return dz_csr_adopt_cap(ctx, m, A->n, nnz, rowptr, col, val, m + reserve_rows, cap, out);
 }
 
 // append rows m+1..m+extra_m given as COO (1-based absolute row ids, any order) -- the reference

@@ -30,7 +30,11 @@ program SurfAAForward_amd
   real :: sta1_lat, sta1_lon, sta2_lat, sta2_lon, velvalue, dist1, sta1_latD, sta1_lonD, Tvalue, velTrue, vsref
   real :: sumObs, sumNoise, sumAdd, sumTnos
   type(c_ptr) :: G
+  integer(8) :: c0, c1, c2, crate
 
+  call system_clock(c0, crate)
+  write (*, *)                                               ! fwd/MainForward.f90:126-127
+  write (*, *) '                SurfAniso Forward'
   if (command_argument_count() < 1) then                     ! fwd/MainForward.f90:132-142
     write (*, *) 'input file [SurfAniso.in(default)]:'
     read (*, '(a)') inputfile
@@ -183,7 +187,13 @@ program SurfAAForward_amd
   write (*, *) ' Construct True Traveltime using Ture Sensitivity  Begin!'
   call dazim_init(0)
   call dazim_check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 1), 'set_option')
+  write (6, *) ' DepthkernelTI begin!'                         ! fwd/FwdTraveltimeCPS.f90:450-455, fwd/depthkernelTI.f90:42
+  write (6, *) ' depth kernel parallel:'
+  call system_clock(c1)
   call dazim_lsen_gsc(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+  call system_clock(c2)
+  write (6, *) ' DepthkernelTI successfully!'
+  write (*, '(a,f13.1,a)') "  DepthkernelTI time cost= ", real(c2 - c1)/real(crate), " s"
   call dazim_assemble_G(.true., nx, ny, nz, vsf, obsTvs, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
                         minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv)
   xcol = 0                                                    ! (0 | GcCol | GsCol), :746-752
@@ -264,6 +274,12 @@ program SurfAAForward_amd
   open (72, file='Vs_model.real')
   call write_models(71, 72)
   close (71); close (72)
+  call system_clock(c2)
+  write (*, '(a,f13.0,a)') "     All time cost=", real(c2 - c0)/real(crate), "s"       ! fwd/MainForward.f90:491-496
+  write (*, *) 'Output True velocity model to Vs_model.real'
+  write (*, *) 'Output inverted shear velocity model to Vs_model_Syn.rela and Vs_model_Syn.abs'
+  write (66, *) 'Output True Gc Gs model to Gc_model.real Gs_model.real'                  ! :497-500
+  write (66, *) 'Output inverted shear velocity model to Vs_model_Syn.rela and Vs_model_Syn.abs'
   close (66)
   call dazim_finalize()
 

@@ -5,15 +5,13 @@
 ! lsmr.txt) in the reference's formats.
 !
 ! What runs where, per outer iteration (inv/Main_Jt.f90:360-770):
-!   device : dispersion + depth kernels, TI eigenfunction kernels (joint mode), eikonal fields, rays + G rows (dazim_assemble_G), data weighting of G
-!            (dazim_csr_scale_rows), DWS (dazim_csr_col_abs_sums), the Tikhonov rows appended to the resident
-!            CSR (dazim_csr_append_coo), LSMR (dazim_lsmr) and the G*dv diagnostics (dazim_aprod).  G never
-!            leaves HBM; only O(m)+O(n) vectors cross PCIe.
-!   host   : parsing, residual statistics, CalDdatSigma, the O(n) regularisation stencil, the clamped model
-!            update and the writers.
-! Joint (iso-mode F) inversions take the TI depth kernels Lsen_Gsc from the procedure ti_depth_kernels, which
-! host/Makefile links to ti_hip.f90 (the device kernels of ti.hip) or, for cross-checks inside the build container,
-! to ti_ref.f90 (the reference's own CPU depthkernelTI/tregn96 compiled where they lie: `make refti`).
+!   device : dispersion + depth kernels, TI eigenfunction kernels (joint mode, dazim_ti_kernels), eikonal fields, rays + G rows
+!            (dazim_assemble_G), residuals + CalDdatSigma weights + weighted right-hand side + row scaling (dazim_weight_data),
+!            DWS (dazim_csr_col_abs_sums), the Tikhonov rows generated behind the ray rows (dazim_csr_append_tikhonov), LSMR
+!            (dazim_lsmr_traced), the clamped model update and its statistics (dazim_model_update) and the G*dv diagnostics
+!            (dazim_aprod on the resident un-thresholded rows).  G never leaves HBM; only O(m) + O(n) vectors cross PCIe.
+!   host   : parsing, the O(n) copy of the regularisation stencil for the ||Lm|| diagnostics, formatted output.
+! Joint (iso-mode F) inversions take the TI depth kernels Lsen_Gsc from ti_hip.f90 (the device kernels of ti.hip).
 program DAzimSurfTomo_amd
   use iso_c_binding
   use dazim_mod
@@ -41,7 +39,7 @@ program DAzimSurfTomo_amd
   real :: mean, std_devs, meanAbs, meandeltaT, atol, btol, conlim, anorm, acond, rnorm, arnorm, xnorm, pertV
   real :: mindVs, maxdVs, meadVs, minGc, maxGc, meaGc, minGs, maxGs, meaGs, VariVs, VariGc, VariGs
   integer(8) :: maxnar
-  type(c_ptr) :: G
+  type(c_ptr) :: G, Gd
   integer :: c0, c1, crate
   real :: wstats(8)
   real, allocatable :: ustats(:, :, :)       ! (3: min, max, sum |.| ; nz-1 ; block) of the update, from dazim_model_update
@@ -53,7 +51,7 @@ program DAzimSurfTomo_amd
   call system_clock(tk0, tkrate)
   open (36, file='lsmr.txt')
   write (*, *)
-  write (*, *) '                       DAzimSurfTomo (MI355X hot path)'
+  write (*, *) '                       DAzimSurfTomo'
   write (*, *)
   if (command_argument_count() < 1) then                    ! inv/Main_Jt.f90:144-154
     write (*, *) 'input file [para.in (Default)]:'
@@ -234,9 +232,16 @@ program DAzimSurfTomo_amd
     dsyn = 0; tRcV = 0
     if (.not. iso_mod .and. .not. ti_kernels_on_device()) &
       call ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+    ! The reference keeps every ray row twice: the triplets rw/iw/col with |row| > ftol for the solver (inv/CalSurfG.f90:1358)
+    ! and the dense GVs/GGc/GGs for the residual diagnostics (inv/CalSigamNorm.f90:73), which hold EVERY entry of the cells with
+    ! |fdm| >= ftol, the dVs block with the Brocher derivatives left over from the last such cell (:1369-1378).  Option
+    ! rays.dense_twin makes the library build that second matrix from the same cell lists: Gd, resident, never scaled.
+    call dazim_check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 1_c_int), 'option')
     call dazim_assemble_G(.not. iso_mod, nx, ny, nz, vsf, dsyn, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
                           minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv, &
                           ti_here=(.not. iso_mod .and. ti_kernels_on_device()))
+    call dazim_check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 0_c_int), 'option')
+    call dazim_check(dazim_csr_take_twin(dazim_handle, G, Gd), 'dense twin')
     if (.not. iso_mod) then                       ! inv/CalSurfGAniso_Joint.f90:801-811 (the iso branch leaves tRcV = 0)
       do tt = 1, kmaxRc
         do jj = 1, ny - 2
@@ -373,7 +378,7 @@ program DAzimSurfTomo_amd
         end do
       else
         write (88, '(7a)') '          Dist(km)       T_obs(s)        T_ref-iso        Res(in)   ', &
-          '                dT(aa)        dT(dvs)        Res(out)'
+          'dT(aa)        dT(dvs)        Res(out)'
         do i = 1, dall
           write (88, '(3f10.4, 4e12.3)') dist(i), obst(i), dsyn(i), Tdata(i), fwdTvs(i), fwdTaa(i), resbst(i)
         end do
@@ -405,6 +410,7 @@ program DAzimSurfTomo_amd
     write (66, '(a)') ' '
     write (6, '(a)') '  '
     call dazim_check(dazim_csr_free(dazim_handle, G), 'free G')
+    call dazim_check(dazim_csr_free(dazim_handle, Gd), 'free Gd')
     call tick(9)                             ! output files of the iteration
   end do
 
@@ -563,23 +569,23 @@ contains
     end if
   end subroutine
 
-  ! predicted traveltime changes G*dv with the resident (row-weighted) matrix: (W G) dv / w instead of the reference's
-  ! dense matmul(GVs, dv); inv/CalSigamNorm.f90:44 (iso) and :154 (joint)
+  ! predicted traveltime changes: the reference's dense matmul(GVs, dv) (+ GGc, GGs), inv/CalSigamNorm.f90:44 (iso) and :154
+  ! (joint), as products with the resident un-thresholded, un-weighted rows Gd (= the entries GVs/GGc/GGs hold)
   subroutine residual_norms()
     real, allocatable :: resW(:)
     integer :: q
     real :: mabs
     allocate (resW(dall))
     xtmp(1:n) = 0; xtmp(1:maxvp) = dv(1:maxvp)
-    yfull(1:m) = 0
-    call dazim_check(dazim_aprod(dazim_handle, 1, G, xtmp, yfull), 'aprod')
-    fwdTvs(1:dall) = yfull(1:dall)/datweight(1:dall)
+    yfull(1:dall) = 0
+    call dazim_check(dazim_aprod(dazim_handle, 1, Gd, xtmp, yfull), 'aprod')
+    fwdTvs(1:dall) = yfull(1:dall)
     fwdTaa = 0
     if (.not. iso_mod) then
       xtmp(1:n) = dv(1:n); xtmp(1:maxvp) = 0
-      yfull(1:m) = 0
-      call dazim_check(dazim_aprod(dazim_handle, 1, G, xtmp, yfull), 'aprod')
-      fwdTaa(1:dall) = yfull(1:dall)/datweight(1:dall)
+      yfull(1:dall) = 0
+      call dazim_check(dazim_aprod(dazim_handle, 1, Gd, xtmp, yfull), 'aprod')
+      fwdTaa(1:dall) = yfull(1:dall)
     end if
     do q = 1, dall
       resbst(q) = Tdata(q) - fwdTaa(q) - fwdTvs(q)

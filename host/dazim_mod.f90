@@ -25,7 +25,7 @@ module dazim_mod
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
-            dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update
+            dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
@@ -135,6 +135,25 @@ module dazim_mod
     end function
     integer(c_int) function dazim_csr_free(ctx, A) bind(C, name="dazim_csr_free")
       import; type(c_ptr), value :: ctx, A
+    end function
+    integer(c_int) function dazim_csr_dims(A, m, n, nnz) bind(C, name="dazim_csr_dims")
+      import
+      type(c_ptr), value :: A
+      integer(c_int64_t) :: m, n, nnz
+    end function
+    ! the reference's dense copies GVs | GGc | GGs of a matrix built with option rays.dense_twin (include/dazim.h)
+    integer(c_int) function dazim_csr_take_twin(ctx, A, twin) bind(C, name="dazim_csr_take_twin")
+      import
+      type(c_ptr), value :: ctx, A
+      type(c_ptr) :: twin
+    end function
+    ! B = entries of A with |value| > tol (the solver's triplets from the keep_small matrix, inv/CalSurfG.f90:1358 vs :1369-1378)
+    integer(c_int) function dazim_csr_threshold(ctx, A, tol, reserve_rows, reserve_nnz, B) bind(C, name="dazim_csr_threshold")
+      import
+      type(c_ptr), value :: ctx, A
+      real(c_float), value :: tol
+      integer(c_int64_t), value :: reserve_rows, reserve_nnz
+      type(c_ptr) :: B
     end function
     integer(c_int) function dazim_csr_scale_rows(ctx, A, w) bind(C, name="dazim_csr_scale_rows")
       import; type(c_ptr), value :: ctx, A; real(c_float) :: w(*)
@@ -311,9 +330,9 @@ contains
   end subroutine
 
   ! G on the device -> the reference's COO triplets (iw(2:nar+1) rows, col, rw) and, when the caller's dense arrays are
-  ! given, GVs (GGc, GGs).  The dense copies hold EVERY entry of the cells with |fdm| >= ftol (inv/CalSurfG.f90:1369-1378),
-  ! the triplets only those with |row| > ftol (:1358): the matrix is built once with the library option rays.keep_small and
-  ! the second threshold is applied here, on the same fp32 values the kernel would have tested.
+  ! given, GVs (GGc, GGs).  The dense copies hold EVERY entry of the cells with |fdm| >= ftol, the dVs block formed with the
+  ! Brocher derivatives of the ray's last such cell (inv/CalSurfG.f90:1369-1378 does not recompute coe_a / coe_rho), the
+  ! triplets only the entries with |row| > ftol (:1358): the library builds both from one ray trace (option rays.dense_twin).
   subroutine build_G(joint, nx, ny, nz, vels, iw, rw, col, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, &
                      periods, depz, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, nar, pvout, &
                      dall, nparpi, GVs, GGc, GGs)
@@ -327,28 +346,36 @@ contains
     real*8, optional :: pvout(nx*ny, kmaxRc)
     integer, optional :: dall, nparpi
     real, optional :: GVs(*), GGc(*), GGs(*)
-    real, parameter :: ftol = 1e-4           ! inv/CalSurfG.f90:999
     real*8, allocatable :: pv(:, :)
     integer, allocatable :: irow(:), icol(:)
     real, allocatable :: val(:)
-    type(c_ptr) :: G
+    type(c_ptr) :: G, Gd
     logical :: dense
     integer :: nall, i, blk, c
     integer(8) :: ld, np8, k8
+    integer(c_int64_t) :: md, nd, nzd
     dense = .false.
     if (dazim_fill_dense .and. present(GVs) .and. present(dall) .and. present(nparpi)) dense = .true.
     allocate (pv(nx*ny, kmaxRc))
     call dazim_init(0)
-    if (dense) call check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 1_c_int), 'option')
+    if (dense) call check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 1_c_int), 'option')
     call dazim_assemble_G(joint, nx, ny, nz, vels, dsurf, lsen, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, tRc, periods, depz, minthk, &
                           scxf, sczf, rcxf, rczf, nrc1, nsrcsurf1, kmax, nsrcsurf, nrcf, G, nall, pv)
-    if (dense) call check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 0_c_int), 'option')
+    if (dense) call check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 0_c_int), 'option')
     if (present(pvout)) pvout = pv
     allocate (irow(max(nall, 1)), icol(max(nall, 1)), val(max(nall, 1)))
     call check(dazim_csr_to_coo(dazim_handle, G, irow, icol, val), 'CalSurfG/coo')
-    call check(dazim_csr_free(dazim_handle, G), 'free')
-    ld = 0; np8 = 0
+    nar = nall
+    do i = 1, nall
+      rw(i) = val(i); iw(i + 1) = irow(i); col(i) = icol(i)          ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
+    end do
     if (dense) then                          ! GVs = 0 etc.: inv/Main_Jt.f90:388-390, inv/CalSurfGAniso_Joint.f90:436-438
+      call check(dazim_csr_take_twin(dazim_handle, G, Gd), 'dense twin')
+      call check(dazim_csr_dims(Gd, md, nd, nzd), 'dims')
+      deallocate (irow, icol, val)
+      allocate (irow(max(int(nzd), 1)), icol(max(int(nzd), 1)), val(max(int(nzd), 1)))
+      call check(dazim_csr_to_coo(dazim_handle, Gd, irow, icol, val), 'CalSurfG/dense')
+      call check(dazim_csr_free(dazim_handle, Gd), 'free')
       ld = dall; np8 = nparpi
       do k8 = 1, ld*np8
         GVs(k8) = 0.0
@@ -358,10 +385,7 @@ contains
           GGc(k8) = 0.0; GGs(k8) = 0.0
         end do
       end if
-    end if
-    nar = 0
-    do i = 1, nall
-      if (dense) then
+      do i = 1, int(nzd)
         blk = (icol(i) - 1)/nparpi; c = icol(i) - blk*nparpi
         k8 = int(c - 1, 8)*ld + irow(i)      ! element (irow, c) of a dall x nparpi array
         if (blk == 0) then
@@ -373,11 +397,9 @@ contains
             GGs(k8) = val(i)
           end if
         end if
-        if (.not. abs(val(i)) > ftol) cycle   ! if(abs(row(nn)).gt.ftol), inv/CalSurfG.f90:1358
-      end if
-      nar = nar + 1
-      rw(nar) = val(i); iw(nar + 1) = irow(i); col(nar) = icol(i)   ! iw(nar+1)=count1, inv/CalSurfG.f90:1361
-    end do
+      end do
+    end if
+    call check(dazim_csr_free(dazim_handle, G), 'free')
   end subroutine
 
   ! The whole of CalSurfG (inv/CalSurfG.f90:909) / the GPU part of CalSurfGAnisoJoint on the device; G stays in HBM

@@ -168,6 +168,19 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
                          const int *icol, const float *rw);
 /* the matrix back as the reference's triplets (1-based, rows ascending); any pointer may be NULL  */
 int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow, int *icol, float *rw);
+/* The reference keeps every ray row twice: the triplets rw/iw/col with |row| > ftol, which LSMR sees (inv/CalSurfG.f90:1358), and
+ * the dense GVs (GGc, GGs) its residual diagnostics multiply with (inv/CalSigamNorm.f90:73): every entry of the cells with
+ * |fdm| >= ftol, the dVs block formed with the Brocher derivatives coe_a / coe_rho left over from the LAST such cell of the ray
+ * (the second loop, inv/CalSurfG.f90:1369-1378 / inv/CalSurfGAniso_Joint.f90:759-775, does not recompute them).  With option
+ * "rays.dense_twin" = 1 dazim_rays_build_G[_joint] builds that second matrix as well (one more pass over the saved cell lists,
+ * no second ray trace) and attaches it to G; this call hands it out (NULL if G has none).  The caller frees it. */
+int dazim_csr_take_twin(dazim_ctx *ctx, dazim_csr *G, dazim_csr **twin);
+/* B = the entries of A with |value| > tol (same shape, same order): the second threshold of the row assembly
+ * (inv/CalSurfG.f90:1358) applied to a matrix that was built with option "rays.keep_small" = 1 (every non-zero entry of the
+ * |fdm| >= ftol cells, the forward program's GGc/GGs, fwd/FwdTraveltimeCPS.f90:694-712) -- two streaming passes on the device.
+ * reserve_rows / reserve_nnz: room for regularisation rows appended to B in place. */
+int dazim_csr_threshold(dazim_ctx *ctx, const dazim_csr *A, float tol, int64_t reserve_rows, int64_t reserve_nnz,
+                        dazim_csr **B);
 
 /* ---- K4+K5: receiver times, ray tracing, Frechet weights, G rows ---------------------------------
  * = the receiver loop of CalSurfG (inv/CalSurfG.f90:1326-1364): srtimes (:1599), rpaths (:1735) and

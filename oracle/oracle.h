@@ -90,6 +90,16 @@ int orc_rpaths(const orc_geom *g, const orc_refbox *box, const float *veln, cons
 int orc_rpaths_azim(const orc_geom *g, const orc_refbox *box, const float *veln, const float *ttn,
                     const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
                     float *fdm, float *fdmc, float *fdms, int *rb);
+/* inv/CalSurfG.f90:1339-1364: G row of one ray from fdm and sen_*[nz][kmax][nx*ny]; kidx 0-based kernel slot; entries from
+ * index 0 of rw/irow/icol (1-based ids); returns their number or -1 (more than maxnar) */
+long orc_emit_row(int nx, int ny, int nz, const float *vels, const float *fdm, const double *svs, const double *svp,
+                  const double *srho, int kmax, int kidx, int rowid, int64_t maxnar, float *rw, int *irow, int *icol);
+/* the reference's dense copies of one ray's row (GVs; GGc, GGs when fdmc/fdms/lsen are given), inv/CalSurfG.f90:1369-1378,
+ * inv/CalSurfGAniso_Joint.f90:759-775: all entries of the |fdm| >= ftol cells, dVs with the Brocher derivatives of the LAST
+ * such cell (the reference's second loop reuses coe_a / coe_rho); rows of length (nx-2)(ny-2)(nz-1), assigned entries only */
+void orc_dense_row(int nx, int ny, int nz, const float *vels, const float *fdm, const float *fdmc, const float *fdms,
+                   const float *lsen, const double *svs, const double *svp, const double *srho, int kmax, int kidx,
+                   float *gvs, float *ggc, float *ggs);
 /* source loop of inv/CalSurfGAniso_Joint.f90:209 given Lsen_Gsc (lsen[nz-1][kmax][nx*ny], fp32):
  * rows have three column blocks dVs | Gc | Gs, n = 3*(nx-2)*(ny-2)*(nz-1) */
 int orc_calsurfg_joint(int nx, int ny, int nz, const float *vels, float goxd, float gozd, float dvxd,

@@ -146,6 +146,31 @@ class Oracle:
                                       pf(f[0]), pf(f[1]), pf(f[2]), C.byref(rb))
         return rc, f[0], f[1], f[2], rb.value
 
+    def emit_row(self, vels, fdm, sen, kidx, rowid):
+        """inv/CalSurfG.f90:1339-1364 for one ray: sen = (svs, svp, srho) each [nz][kmax][nx*ny] f64; kidx 0-based kernel slot"""
+        nz, ny, nx = vels.shape
+        cap = (nx - 2) * (ny - 2) * (nz - 1)
+        rw = np.zeros(cap, f32); irow = np.zeros(cap, i32); icol = np.zeros(cap, i32)
+        self.lib.orc_emit_row.restype = C.c_long
+        kmax = sen[0].shape[1]
+        n = self.lib.orc_emit_row(nx, ny, nz, pf(vels), pf(fdm), pd(sen[0]), pd(sen[1]), pd(sen[2]), kmax, int(kidx), int(rowid),
+                                  C.c_int64(cap), pf(rw), pi(irow), pi(icol))
+        assert n >= 0
+        return rw[:n].copy(), irow[:n].copy(), icol[:n].copy()
+
+    def dense_row(self, vels, fdm, sen, kidx, fdmc=None, fdms=None, lsen=None):
+        """the reference's dense copies of one row: GVs (and GGc, GGs), inv/CalSurfG.f90:1369-1378 -- see oracle.h"""
+        nz, ny, nx = vels.shape
+        npar = (nx - 2) * (ny - 2) * (nz - 1)
+        gvs = np.zeros(npar, f32)
+        joint = fdmc is not None
+        ggc, ggs = (np.zeros(npar, f32), np.zeros(npar, f32)) if joint else (None, None)
+        self.lib.orc_dense_row.restype = None
+        self.lib.orc_dense_row(nx, ny, nz, pf(vels), pf(fdm), pf(fdmc) if joint else None, pf(fdms) if joint else None,
+                               pf(np.ascontiguousarray(lsen, f32)) if joint else None, pd(sen[0]), pd(sen[1]), pd(sen[2]),
+                               sen[0].shape[1], int(kidx), pf(gvs), pf(ggc) if joint else None, pf(ggs) if joint else None)
+        return (gvs, ggc, ggs) if joint else gvs
+
     def calsurfg_joint(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf,
                        nrc1, nsrc1, periods, lsen, maxnar):
         vels = np.ascontiguousarray(vels, f32)
@@ -312,6 +337,28 @@ class Ref:
                               dall, maxnar, pf(rw), pi(irow), pi(icol), pf(dsurf), C.byref(nar))
         n = nar.value
         return rw[:n].copy(), irow[:n].copy(), icol[:n].copy(), dsurf
+
+    def calsurfg_dense(self, vels, depz, goxd, gozd, dvxd, dvzd, tRc, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods,
+                       maxnar, joint=False):
+        """the reference's dense copies themselves: GVs[dall][nparpi] (joint: + GGc, GGs) as CalSurfG / CalSurfGAnisoJoint fill them"""
+        vels = np.ascontiguousarray(vels, f32)
+        nz, ny, nx = vels.shape
+        kmax, nsrc = scxf.shape
+        nrcf = rcxf.shape[2]
+        dall = int(sum(int(nrc1[k, :nsrc1[k]].sum()) for k in range(kmax)))
+        npar = (nx - 2) * (ny - 2) * (nz - 1)
+        tRc = np.ascontiguousarray(tRc, f64); depz = np.ascontiguousarray(depz, f32)
+        a = [np.array(x, copy=True) for x in (scxf, sczf, rcxf, rczf)]
+        out = [np.zeros((npar, dall), f32) for _ in range(3 if joint else 1)]       # Fortran (dall, nparpi)
+        rmax = 0
+        for i in range(nz - 1):
+            thk = np.float32(depz[i + 1] - depz[i])
+            rmax += int((thk + np.float32(1e-4)) / (thk / np.float32(minthk))) + 1
+        self.lib.ref_calsurfg_dense(nx, ny, nz, pf(vels), C.c_float(goxd), C.c_float(gozd), C.c_float(dvxd), C.c_float(dvzd), kmax,
+                                    pd(tRc), pf(depz), C.c_float(minthk), rmax, nsrc, nrcf, pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]),
+                                    pi(nrc1), pi(nsrc1), pi(periods), dall, maxnar, 1 if joint else 0, pf(out[0]),
+                                    pf(out[1]) if joint else None, pf(out[2]) if joint else None)
+        return [o.T.copy() for o in out]                                            # [dall][nparpi]
 
     def aprod(self, mode, m, n, x, y, irow, icol, rw):
         self.lib.ref_aprod(mode, m, n, pf(x), pf(y), len(rw), pi(irow), pi(icol), pf(rw))

@@ -355,6 +355,55 @@ static long emit_row(int nx, int ny, int nz, const float *vels, const float *fdm
   return cnt;
 }
 
+/* the row of one ray from its Frechet grid and the depth kernels, inv/CalSurfG.f90:1339-1364, as an entry point of its own
+ * (tests that sample rays of a large batch need rows without the whole depthkernel loop of orc_calsurfg).  kidx 0-based
+ * kernel slot; COO entries (1-based) are written from index 0; returns their number, -1 if more than maxnar. */
+long orc_emit_row(int nx, int ny, int nz, const float *vels, const float *fdm, const double *svs, const double *svp,
+                  const double *srho, int kmax, int kidx, int rowid, int64_t maxnar, float *rw, int *irow, int *icol) {
+  float *row = (float *)malloc(sizeof(float) * (size_t)(nx - 2) * (ny - 2) * (nz - 1));
+  long c = emit_row(nx, ny, nz, vels, fdm, NULL, NULL, NULL, svs, svp, srho, kmax, kidx, rowid, row, 0, maxnar, rw, irow, icol);
+  free(row);
+  return c;
+}
+
+/* The reference's DENSE copies of one ray's row, inv/CalSurfG.f90:1369-1378 (GVs) and inv/CalSurfGAniso_Joint.f90:759-775 (GVs,
+ * GGc, GGs): every entry of the cells with |fdm| >= ftol, no second threshold -- and the dVs block is formed with coe_a /
+ * coe_rho as the FIRST loop (:1339-1354) left them, i.e. those of the last cell with |fdm| >= ftol in (jj, kk) order: the
+ * second loop does not recompute them.  gvs (ggc, ggs; nullable with fdmc) are rows of length (nx-2)(ny-2)(nz-1), overwritten
+ * only where the reference assigns (the caller zeroes them like inv/Main_Jt.f90:388-390). */
+void orc_dense_row(int nx, int ny, int nz, const float *vels, const float *fdm, const float *fdmc, const float *fdms,
+                   const float *lsen, const double *svs, const double *svp, const double *srho, int kmax, int kidx,
+                   float *gvs, float *ggc, float *ggs) {
+  const float ftol = 1e-4f;
+  int nvx = nx - 2, nvz = ny - 2;
+  size_t ncol = (size_t)nx * ny;
+  int jjL = 0, kkL = 0;
+  for (int jj = 1; jj <= nvz; jj++)
+    for (int kk = 1; kk <= nvx; kk++)
+      if (fabsf(fdm[(size_t)kk * (nvz + 2) + jj]) >= ftol) { jjL = jj; kkL = kk; }
+  if (!jjL) return; /* no cell: the reference's coe_a would be whatever the previous ray left; no entry is assigned either */
+  for (int jj = 1; jj <= nvz; jj++)
+    for (int kk = 1; kk <= nvx; kk++) {
+      float f = fdm[(size_t)kk * (nvz + 2) + jj];
+      if (!(fabsf(f) >= ftol)) continue;
+      size_t cell = (size_t)jj * (nvx + 2) + kk;
+      for (int k = 1; k <= nz - 1; k++) {
+        float v = vels[((size_t)(k - 1) * ny + jjL) * nx + kkL]; /* the LAST cell's column, see above */
+        float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
+        float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
+        float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
+                                 0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
+        size_t si = ((size_t)(k - 1) * kmax + kidx) * ncol + cell;
+        size_t o = (size_t)(k - 1) * nvz * nvx + (jj - 1) * nvx + kk - 1;
+        gvs[o] = (float)((svp[si] * (double)coe_a + srho[si] * (double)coe_rho + svs[si]) * (double)f);
+        if (fdmc && ggc && ggs) {
+          ggc[o] = lsen[si] * fdmc[(size_t)kk * (nvz + 2) + jj];
+          ggs[o] = lsen[si] * fdms[(size_t)kk * (nvz + 2) + jj];
+        }
+      }
+    }
+}
+
 /* inv/CalSurfG.f90:909-1422 ; with lsen != NULL the source loop of CalSurfGAnisoJoint
  * (inv/CalSurfGAniso_Joint.f90:488-792): rpathsAzim and three column blocks per row.
  * lsen[nz-1][kmax][nx*ny] = Lsen_Gsc from depthkernelTI (TI kernels are an input here). */

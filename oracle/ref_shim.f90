@@ -240,6 +240,39 @@ contains
     deallocate (iw, GVs, GGc, GGs, tRcV)
   end subroutine
 
+  ! ---- the dense copies the reference fills next to the triplets (GVs; joint: GGc, GGs), handed out as they are ----
+  subroutine ref_calsurfg_dense(nx, ny, nz, vels, goxd, gozd, dvxd, dvzd, kmax, tRc, depz, minthk, rmax, &
+       nsrc, nrcf, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods, dall, maxnar, joint, GVs, GGc, GGs) &
+       bind(C, name="ref_calsurfg_dense")
+    integer(c_int), value :: nx, ny, nz, kmax, nsrc, nrcf, dall, maxnar, rmax, joint
+    real(c_float), value :: goxd, gozd, dvxd, dvzd, minthk
+    real(c_float), intent(in) :: vels(nx, ny, nz), depz(nz)
+    real(c_double), intent(in) :: tRc(kmax)
+    real(c_float), intent(in) :: scxf(nsrc, kmax), sczf(nsrc, kmax)
+    real(c_float), intent(in) :: rcxf(nrcf, nsrc, kmax), rczf(nrcf, nsrc, kmax)
+    integer(c_int), intent(in) :: nrc1(nsrc, kmax), nsrc1(kmax), periods(nsrc, kmax)
+    real(c_float), intent(out) :: GVs(dall, (nx - 2)*(ny - 2)*(nz - 1))
+    real(c_float) :: GGc(dall, *), GGs(dall, *)
+    integer, allocatable :: iw(:), icol(:)
+    real(4), allocatable :: rw(:), dsurf(:), lsen(:, :, :)
+    real(8), allocatable :: tRcV(:, :)
+    integer :: nparpi, nar
+    nparpi = (nx - 2)*(ny - 2)*(nz - 1)
+    allocate (iw(maxnar + 1), icol(maxnar), rw(maxnar), dsurf(dall))
+    iw = 0; GVs = 0; rw = 0; icol = 0
+    if (joint == 0) then
+      call CalSurfG(nx, ny, nz, nparpi, vels, iw, rw, icol, dsurf, GVs, dall, &
+                    goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
+                    scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar)
+    else
+      allocate (lsen(nx*ny, kmax, nz - 1), tRcV((nx - 2)*(ny - 2), kmax))
+      GGc(:, 1:nparpi) = 0; GGs(:, 1:nparpi) = 0; tRcV = 0
+      call CalSurfGAnisoJoint(nx, ny, nz, nparpi, vels, iw, rw, icol, dsurf, GVs, GGc, GGs, lsen, dall, rmax, tRcV, &
+                              goxd, gozd, dvxd, dvzd, kmax, tRc, periods, depz, minthk, &
+                              scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrcf, nar, 0)
+    end if
+  end subroutine
+
   ! ---- aprod (inv/aprod.f90:7) and LSMR (inv/lsmrModule.f90:36) ---------------------------------
   subroutine ref_aprod(mode, m, n, x, y, nar, irow, icol, rw) bind(C, name="ref_aprod")
     integer(c_int), value :: mode, m, n, nar

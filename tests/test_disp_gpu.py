@@ -26,16 +26,28 @@ def model(nx, ny, depz, seed):
     return v
 
 
+# the bars (DESIGN.md section 5 quotes the measured maxima they are twice of)
+PV_ABS = 4e-6            # km/s
+PV_EQUAL_SHARE = 0.995   # share of bit-equal pvRc entries
+SEN_REL, SEN_ABS = 1e-3, 2e-4
+SEN_L2 = 1e-4
+
+
 def compare(ctx, orc, vel, depz, t, minthk):
     pv, sen, nf = ctx.depthkernel(vel, depz, t, minthk)
     pvo, seno = orc.depthkernel(vel, depz, t, minthk)
     assert nf == int((pvo == 0).sum())
     d = np.abs(pv - pvo)
-    assert d.max() <= 4e-6, d.max()
-    assert (pv == pvo).mean() >= 0.995
+    share = (pv == pvo).mean()
+    sd = [np.abs(a - b).max() for a, b in zip(sen, seno)]
+    sl = [np.linalg.norm(a - b) / np.linalg.norm(b) for a, b in zip(sen, seno)]
+    print(f"\n[disp parity] pv max |d| {d.max():.2e} bit-equal {share:.5f}; sen max |d| {max(sd):.2e} "
+          f"(max |sen| {max(np.abs(b).max() for b in seno):.2e}) rel-L2 {max(sl):.2e}")
+    assert d.max() <= PV_ABS, d.max()
+    assert share >= PV_EQUAL_SHARE, share
     for a, b in zip(sen, seno):
-        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 2e-4
-        assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+        assert np.abs(a - b).max() <= SEN_REL * np.abs(b).max() + SEN_ABS, np.abs(a - b).max()
+        assert np.linalg.norm(a - b) <= SEN_L2 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
     return pv, pvo
 
 

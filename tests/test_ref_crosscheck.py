@@ -81,3 +81,41 @@ def test_ti_kernels_random_columns(orc, ref):
         pv_o, ls_o = orc.depthkernel_ti(vel, depz, t, minthk)
         assert np.array_equal(pv_r, pv_o)
         assert np.abs(ls_r - ls_o).max() <= 2e-7 * np.abs(ls_r).max()
+
+
+@pytest.mark.parametrize("joint", [False, True])
+def test_dense_copies_GVs_GGc_GGs(orc, ref, joint):
+    """The dense copies the reference fills next to the triplets (inv/CalSurfG.f90:1369-1378, inv/CalSurfGAniso_Joint.f90:759-775)
+    against orc.dense_row: every entry of the |fdm| >= ftol cells, the dVs block with the Brocher derivatives coe_a / coe_rho of
+    the ray's LAST such cell (the reference's second loop does not recompute them) -- bit-identical, and measurably NOT the
+    values the triplets hold (so the restatement really pins that quirk)."""
+    from tests.test_rays_gpu import build_case, flatten
+    nx, ny, kmax, minthk = 11, 12, 2, 2.0
+    depz = np.asarray([0.0, 10.0, 35.0, 60.0], np.float32)
+    goxd, gozd, dv = 30.0, 100.0, 0.25
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 6, 3, seed=5)
+    t = np.array([8.0, 20.0])
+    dense = ref.calsurfg_dense(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods, 400000, joint=joint)
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    lsen = orc.depthkernel_ti(vel, depz, t, minthk)[1] if joint else None
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    g = orc.geometry(nx, ny, goxd, gozd, dv, dv)
+    npar = (nx - 2) * (ny - 2) * (len(depz) - 1)
+    assert dense[0].shape == (len(rx), npar)
+    differs_from_triplets = 0
+    for f in range(len(scx)):
+        k = int(per[f]) - 1
+        veln = orc.gridder(g, pv[k])
+        rc, ttn, ttnr, nstsr, velnr, box = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
+        for r in np.nonzero(ray_f == f)[0]:
+            if joint:
+                rc, fdm, fdmc, fdms, rb = orc.rpaths_azim(g, box, veln, ttn, ttnr, nstsr, scx[f], scz[f], rx[r], rz[r])
+                rows = orc.dense_row(vel, fdm, sen, k, fdmc, fdms, lsen)
+            else:
+                rc, fdm, rb = orc.rpaths(g, box, veln, ttn, ttnr, nstsr, scx[f], scz[f], rx[r], rz[r])
+                rows = [orc.dense_row(vel, fdm, sen, k)]
+            for got, want in zip(rows, dense):
+                assert np.array_equal(got, want[r]), (f, r)
+            rw, ir, ic = orc.emit_row(vel, fdm, sen, k, r + 1)            # the triplets' dVs values (own coefficients per cell)
+            differs_from_triplets += int((rows[0][ic - 1] != rw).sum())
+    assert differs_from_triplets > 0
