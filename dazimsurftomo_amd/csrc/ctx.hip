@@ -180,7 +180,23 @@ int dazim_create(dazim_ctx **out, int device) {
   if (device < 0 || device >= n) return DAZIM_E_BAD_ARG;
   dazim_ctx *ctx = new dazim_ctx;
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess ||
+  // Experiments only (tools/exp_cumask.sh): DAZIM_CU_MASK=<hex words, least significant first, comma separated> restricts the
+  // library's stream to a subset of the compute units -- "does a kernel's throughput follow the CUs it may use or the memory
+  // system behind them?"
+  bool masked = false;
+  if (const char *mk = getenv("DAZIM_CU_MASK")) {
+    std::vector<uint32_t> words;
+    for (const char *q = mk; *q;) {
+      words.push_back((uint32_t)strtoul(q, nullptr, 16));
+      const char *c = strchr(q, ',');
+      if (!c) break;
+      q = c + 1;
+    }
+    if (hipSetDevice(device) == hipSuccess && !words.empty() &&
+        hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)words.size(), words.data()) == hipSuccess)
+      masked = true;
+  }
+  if (hipSetDevice(device) != hipSuccess || (!masked && hipStreamCreate(&ctx->stream) != hipSuccess) ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
     delete ctx;
     return -2;

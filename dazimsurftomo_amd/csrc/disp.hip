@@ -47,7 +47,10 @@ struct DispArgs {
   int *st_f;           // [ncol*nvar] 1: the search failed, the remaining periods are 0 (:342-348)
   // first-period fast-forward (see disp_bracket_kernel): per column, the number of dc steps from the start value of the
   // first period's bracket search to the lower end of the bracket, and that lower end
-  int ffwd;
+  int ffwd;            // 0 off; 1 the column's own model jumps (exact: every skipped point was evaluated); 2 its perturbed copies too (gated)
+  int exp3;            // 1: the three exponentials of a layer by three exp() calls like the reference (option disp.exp3)
+  unsigned *ff_stat;   // [4] statistics of mode 2: columns whose copies may not jump (gate), columns with a dip limit, copies that
+                       // jumped, copies that found another sign at the arrival point and went back to the start
   int *ff_m;           // [ncol]  0: no information
   double *ff_c;        // [ncol]
   int *ff_v;           // [ncol]  steps the perturbed copies may jump at most (see disp_bracket_kernel: a dip of |del| before the bracket)
@@ -156,7 +159,7 @@ __device__ __forceinline__ void layer_model(const Knots &K, const Layer *lay, in
 // instead of dividing five times, 1/rho and 1/rho^2 are formed once per layer, and fb/omega uses the reciprocal of
 // omega hoisted out of the layer loop; the remaining divisions of the layer loop use frcp/fdiv above.
 template <int RDEN>
-__device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, bool fast, double wvno, double omga) {
+__device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, bool fast, double wvno, double omga, bool exp3 = false) {
 #pragma clang fp contract(fast)   // FMA contraction inside the secular function only (the file is built with -ffp-contract=off)
   double e0, e1, e2, e3, e4;
   double omega = omga;
@@ -216,7 +219,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
       x = 0.0;
     } else {
       fac = 0.0;
-      if (p < 16) fac = ep * ep;
+      if (p < 16) fac = exp3 ? exp(-2.0 * p) : ep * ep;
       cosp = (1.0 + fac) * 0.5;
       sinp = (1.0 - fac) * 0.5;
       w = sinp * rra;
@@ -232,7 +235,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
       z = 0.0;
     } else {
       fac = 0.0;
-      if (q < 16) fac = eq * eq;
+      if (q < 16) fac = exp3 ? exp(-2.0 * q) : eq * eq;
       cosq = (1.0 + fac) * 0.5;
       sinq = (1.0 - fac) * 0.5;
       y = sinq * rrb;
@@ -240,7 +243,7 @@ __device__ double dltar4(const Knots &K, const Layer *lay, int mmax, int nz, boo
     }
     const double exa = pex + sex;
     double a0 = 0.0;
-    if (exa < 60.0) a0 = ep * eq;
+    if (exa < 60.0) a0 = exp3 ? exp(-exa) : ep * eq;
     const double cpcq = cosp * cosq, cpy = cosp * y, cpz = cosp * z, cqw = cosq * w, cqx = cosq * x;
     const double xy = x * y, xz = x * z, wy = w * y, wz = w * z;
     const double gamm1 = gam - 1.0;
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
   for (int blk = 0; blk < FF_BLOCKS; blk++) {
     double c = cblk;
     for (int i = 0; i < lane; i++) c = c + dc;   // the reference's c2 = c1 + dc, one step after the other
-    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / c, omega);
+    const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / c, omega, A.exp3 != 0);
     const unsigned long long neg = __ballot(sgn(del) < 0.0);
     const unsigned long long before = (neg << 1) | (blk > 0 ? prev_last : (neg & 1ull));
     const unsigned long long chg = neg ^ before;                     // bit j: the sign changes between points j-1 and j
@@ -475,6 +478,10 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
     int lim = wiggle ? (jfirst - 8 > 0 ? jfirst - 8 : 0) : 0x3fffffff;   // (no dip: no extra limit)
     if (drop > FF_MAXDROP) lim = 0;
     A.ff_v[col] = lim;
+    if (A.ffwd == 2) {
+      if (drop > FF_MAXDROP) atomicAdd(&A.ff_stat[0], 1u);
+      else if (wiggle) atomicAdd(&A.ff_stat[1], 1u);
+    }
   }
 }
 
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     bool failed = false;
 
     while (__any(phase != P_DONE)) {
-      const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega);
+      const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega, A.exp3 != 0);
       if (phase == P_DONE) continue;
       bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
       switch (phase) {
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
           advance_bracket = true;
           if (A.ffwd && ifirst == 1 && chunk == 0) {   // first period: jump ahead to the bracket found by disp_bracket_kernel
             int m = A.ff_m[col];
+            if (var > 0 && A.ffwd < 2) m = 0;          // (default: only the column's own model, for which the jump is exact)
             if (m > 0 && var > 0) {
               const double steps = floor((A.ff_c[col] - FF_MARGIN - c1) / dc);
               m = steps > 0.0 ? (steps < (double)m + 8.0 ? (int)steps : m + 8) : 0;
@@ -616,14 +624,17 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
               ceval = c1;
               phase = P_GV;
               advance_bracket = false;
+              if (var > 0) atomicAdd(&A.ff_stat[2], 1u);
             }
           }
           break;
         case P_GV:   // arrival point of the jump: same sign as the start point -> go on from here, else back to the start
           if (sgn(del) == sgn(del1))
             del1 = del;
-          else
+          else {
             c1 = s_x[0][tid];
+            if (var > 0) atomicAdd(&A.ff_stat[3], 1u);
+          }
           advance_bracket = true;
           break;
         case P_G2:
@@ -926,7 +937,20 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     long nwg = (long)ctx->num_cu * occ;
     if (nwg > (long)ntask) nwg = (long)ntask;
     // first-period fast-forward (disp_bracket_kernel); off with option disp.ffwd = 0 and when the periods are handed from task to task
-    A.ffwd = (A.nchunk == 1 && !(ctx->opts.count("disp.ffwd") && !ctx->opts["disp.ffwd"])) ? 1 : 0;
+    // Option disp.ffwd: 1 (default) = the jump for the column's own model only, which is exact -- disp_bracket_kernel evaluated
+    // every skipped grid point with the same function; 2 = the 6*nz perturbed copies jump as well, behind the gates described at
+    // disp_bracket_kernel (equal to the step-by-step search on every model family tried, tools/stress_disp_ffwd.py, but a
+    // statistical statement, not a proof: hence opt-in, with its statistics under dazim_last_kernel_seconds("disp.ffwd_*"));
+    // 0 = no jump.
+    A.ffwd = 0;
+    if (A.nchunk == 1) {
+      A.ffwd = 1;
+      if (ctx->opts.count("disp.ffwd")) A.ffwd = ctx->opts["disp.ffwd"] < 0 ? 0 : (ctx->opts["disp.ffwd"] > 2 ? 2 : ctx->opts["disp.ffwd"]);
+    }
+    A.exp3 = ctx->opts.count("disp.exp3") && ctx->opts["disp.exp3"] ? 1 : 0;
+    if ((rc = dz_scratch(ctx, "disp.ff_stat", 64, &p))) return rc;
+    A.ff_stat = (unsigned *)p;
+    DZ_HIP(hipMemsetAsync(A.ff_stat, 0, 64, ctx->stream));
     if ((rc = dz_scratch(ctx, "disp.ff_m", (size_t)ncol * 4 + 16, &p))) return rc;
     A.ff_m = (int *)p;
     if ((rc = dz_scratch(ctx, "disp.ff_c", (size_t)ncol * 8 + 16, &p))) return rc;
@@ -958,9 +982,16 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     t.stop();
   }
   int nfail = 0;
+  unsigned hst[4] = {0, 0, 0, 0};
   DZ_HIP(hipMemcpyAsync(&nfail, d_nfail, 4, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(hst, A.ff_stat, 16, hipMemcpyDeviceToHost, ctx->stream));
   if ((rc = pv.finish()) || (rc = svs.finish()) || (rc = svp.finish()) || (rc = srho.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   if (n_failed) *n_failed = nfail;
+  ctx->ksec["disp.ffwd_mode"] = A.ffwd;
+  ctx->ksec["disp.ffwd_gated_columns"] = hst[0];      // mode 2: columns whose perturbed copies may not jump (roughness gate)
+  ctx->ksec["disp.ffwd_dip_columns"] = hst[1];        // ... columns whose copies stop in front of a dip of |del|
+  ctx->ksec["disp.ffwd_jumped_copies"] = hst[2];      // ... perturbed copies that jumped
+  ctx->ksec["disp.ffwd_fallback_copies"] = hst[3];    // ... of which the arrival point had the other sign (searched step by step)
   return 0;
 }

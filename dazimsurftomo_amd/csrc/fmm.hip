@@ -61,6 +61,7 @@ struct FmmArgs {
   int ovfcap;
   unsigned *counter;
   const int *flist;  // nullable: indirection used by the spill rerun
+  int fpw;           // fields a wavefront takes per batch (1, 2 or FPW = 4 of its 16-lane groups are active): see run_fmm
 };
 
 // cubic B-spline basis, inv/CalSurfG.f90:1472-1475
@@ -805,15 +806,16 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   // Work queue: the field list (sorted by period on the host) is cut into eight contiguous ranges, one per XCD (workgroup b
   // runs on XCD b % 8), so that the fields an XCD marches share one or two velocity grids and these stay in that XCD's L2;
   // a workgroup whose range is drained steals from the next ranges.
-  const unsigned nquad = ((unsigned)A.nfield + FPW - 1) / FPW;
+  const unsigned fpw = (unsigned)A.fpw;
+  const unsigned nquad = ((unsigned)A.nfield + fpw - 1) / fpw;
   int chunk = (int)(blockIdx.x & 7);
   for (;;) {
     __syncthreads();
     if (lane == 0) {
       unsigned found = 0xffffffffu;
       for (int tried = 0; tried < 8; tried++) {
-        const unsigned c0 = (nquad * (unsigned)chunk >> 3) * FPW, c1 = (nquad * (unsigned)(chunk + 1) >> 3) * FPW;
-        const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], (unsigned)FPW) : 0xffffffffu;
+        const unsigned c0 = (nquad * (unsigned)chunk >> 3) * fpw, c1 = (nquad * (unsigned)(chunk + 1) >> 3) * fpw;
+        const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], fpw) : 0xffffffffu;
         if (b < c1 - c0) {
           found = c0 + b;
           break;
@@ -826,7 +828,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
     const unsigned fbase = s_base;
     if (fbase == 0xffffffffu) break;
     const int q = (int)fbase + grp;
-    if (q < A.nfield) {
+    if (grp < (int)fpw && q < A.nfield) {
       const int f = A.flist ? A.flist[q] : q;   // the four groups run the same phases on their own field (SIMT across groups)
       const float scx = A.scx[f], scz = A.scz[f];
       const int per = A.period[f] - 1;
@@ -1036,7 +1038,12 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   ctx->ksec["fmm.wg_per_cu"] = (double)per_cu;
   if (ctx->opts.count("fmm.wg_per_cu") && ctx->opts["fmm.wg_per_cu"] > 0 && ctx->opts["fmm.wg_per_cu"] < per_cu) per_cu = ctx->opts["fmm.wg_per_cu"];
   int nwg = ctx->num_cu * per_cu;
-  if (nwg > (nfield + FPW - 1) / FPW) nwg = (nfield + FPW - 1) / FPW;
+  // Small batches: a launch lasts at least as long as ONE field takes alone, and with fewer wavefronts than SIMDs most of the
+  // chip idles; fewer fields per wavefront then put every field on a SIMD of its own sooner.  Option fmm.fpw forces 1, 2 or 4.
+  A.fpw = FPW;
+  if (ctx->opts.count("fmm.fpw") && (ctx->opts["fmm.fpw"] == 1 || ctx->opts["fmm.fpw"] == 2 || ctx->opts["fmm.fpw"] == 4)) A.fpw = ctx->opts["fmm.fpw"];
+  ctx->ksec["fmm.fpw"] = A.fpw;
+  if (nwg > (nfield + A.fpw - 1) / A.fpw) nwg = (nfield + A.fpw - 1) / A.fpw;
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
   A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
@@ -1115,6 +1122,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     A.flist = (const int *)p;
     A.nfield = (int)redo.size();
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
+    A.fpw = FPW;
     int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
     if (nwg2 > nwg) nwg2 = nwg;
     // the spill kernel keeps every slot >= CAP in HBM: maxbt entries per resident field, allocated only when a field needs it

@@ -5,7 +5,7 @@ that is not in the repository) is missing, so a synthetic station lattice inside
 (T = T_iso + T_aa exactly as fwd/FwdTraveltimeCPS.f90 forms it).  Everything else is the examples' own: para.in values,
 MOD, grid, periods.  The outer loops are driven like make_inversion_golden.py: reference routines in the reference's order,
 glue restated.  Build container only, about 5 minutes:
-    ulimit -s unlimited; OMP_STACKSIZE=256M OMP_NUM_THREADS=8 python tests/golden/make_example_goldens.py
+    ulimit -s unlimited; OMP_STACKSIZE=256M OMP_NUM_THREADS=1 python tests/golden/make_example_goldens.py
 """
 import os
 import sys
@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 f32 = np.float32
 EX = "/root/reference/example"
 

@@ -9,7 +9,7 @@ driven from here: every numerical step is the UNMODIFIED reference routine in or
 The fixture holds the three input files as text (para.in, the traveltime data file, MOD: synthetic,
 written by this script) and the reference's results: the model after every iteration, the first
 update dv, LSMR iteration counts and the residual statistics the program prints.
-Usage: OMP_NUM_THREADS=8 python tests/golden/make_inversion_golden.py   (about a minute)
+Usage: OMP_NUM_THREADS=1 python tests/golden/make_inversion_golden.py   (about a minute)
 """
 import os
 import sys
@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 f32 = np.float32
 PI = f32(3.1415926535898)
 

@@ -4,7 +4,7 @@ oracle/_ref (CalSurfGAnisoJoint incl. depthkernelTI/tregn96, CalDdatSigma, TikhR
 inv/Main_Jt.f90 restated (see make_inversion_golden.py).  The fixture carries the example's three input files as text
 (para.in, China_YN_Rayleigh_RS_5-40s.dat, MOD: reference data files) so that host/DAzimSurfTomo_amd can be run on them.
 Build container only, about 35 minutes:
-    ulimit -s unlimited; OMP_STACKSIZE=512M OMP_NUM_THREADS=8 python -u tests/golden/make_test4_full_golden.py
+    ulimit -s unlimited; OMP_STACKSIZE=512M OMP_NUM_THREADS=1 python -u tests/golden/make_test4_full_golden.py
 """
 import os
 import sys
@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
-os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 f32 = np.float32
 EX = "/root/reference/example/test4_Yunnan"
 

@@ -5,7 +5,7 @@ Build container only.  Inputs stored in the fixture: MOD (38x42x18 Vs model), th
 20877 rays of China_YN_Rayleigh_RS_5-40s.dat, para.in values.  Reference outputs stored: pvRc, dsurf
 (predicted traveltimes of all rays), row/column |G| sums + nnz of the 17.7 M-entry G (G itself is too
 big to commit), and the LSMR solution of [G; Tikhonov] x = obst - dsurf.
-Usage:  OMP_NUM_THREADS=8 python tests/golden/make_test4_golden.py     (about 3 minutes)
+Usage:  OMP_NUM_THREADS=1 python tests/golden/make_test4_golden.py     (about 3 minutes)
 """
 import os
 import sys
@@ -16,7 +16,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("OMP_NUM_THREADS", "8")   # depthkernel's OpenMP loop; see the SAVE-variable note in SURVEY.md 5
+os.environ.setdefault("OMP_NUM_THREADS", "1")   # depthkernel's OpenMP loop; see the SAVE-variable note in SURVEY.md 5
 EX = "/root/reference/example/test4_Yunnan"
 PI = np.float32(3.1415926535898)
 

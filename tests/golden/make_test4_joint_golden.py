@@ -4,7 +4,7 @@ produced by the UNMODIFIED reference routines (oracle/_ref): CalSurfGAnisoJoint 
 CalDdatSigma, TikhRegul_joint, LSMR with the joint controls of inv/Main_Jt.f90:548-553.  Inputs are those of
 test4_yunnan.npz (make_test4_golden.py).  Stored: Lsen_Gsc, nnz, |G| row/column sums of the weighted matrix, the LSMR
 solution and its info.  Build container only; about 6 minutes:
-    ulimit -s unlimited; OMP_STACKSIZE=512M OMP_NUM_THREADS=8 python tests/golden/make_test4_joint_golden.py
+    ulimit -s unlimited; OMP_STACKSIZE=512M OMP_NUM_THREADS=1 python tests/golden/make_test4_joint_golden.py
 """
 import os
 import sys
@@ -15,7 +15,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "1")
 f32 = np.float32
 
 

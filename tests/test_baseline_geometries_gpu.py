@@ -18,6 +18,9 @@ test_dispersion_on_columns_of_the_bench_model below):
 """
 import numpy as np
 import pytest
+
+from tests.bars import at_least, within
+from tests.test_rays_gpu import G_FROB, G_MAX, TPRED_REL
 import scipy.sparse as sp
 
 import bench
@@ -114,14 +117,15 @@ def test_rays_G_and_lsmr_at_the_baseline_geometry(ctx, orc, workload_guard, name
     assert lcap == (1024 if name == "s512" else 512)
     g = orc.geometry(*geo)
     tp_o, rw_o, ir_o, ic_o = oracle_rows(orc, g, vel, pv, sen, scx, scz, per, ray_f, rx, rz, dev_ttn=fields["ttn"])
-    assert np.abs(tpred - tp_o).max() <= 1e-6 * np.abs(tp_o).max(), np.abs(tpred - tp_o).max() / np.abs(tp_o).max()
+    within(f"{name} tpred rel", np.abs(tpred - tp_o).max() / np.abs(tp_o).max(), TPRED_REL)
     ir, ic, rw = G.to_coo()
     assert np.all(np.diff(ir) >= 0) and np.all(np.abs(rw) > 1e-4)
     D, Do = csr(m, n, ir, ic, rw), csr(m, n, ir_o, ic_o, rw_o)
     diff = D - Do
     dmax = np.abs(diff.data).max() if diff.nnz else 0.0
     frob = np.sqrt((diff.data ** 2).sum()) / np.sqrt((Do.data ** 2).sum())
-    assert dmax <= 2e-4 and frob <= 1e-4, (dmax, frob)
+    within(f"{name} G max |d|", dmax, G_MAX)
+    within(f"{name} G rel-Frobenius", frob, G_FROB)
     assert abs(len(rw) - len(rw_o)) <= 1e-4 * len(rw_o)          # entries on the 1e-4 threshold may fall either way
     if name == "s512":
         # Measured here: even corner-to-corner rays of the 103 x 103 grid keep fewer than 1 024 cells above ftol, so the default
@@ -153,13 +157,13 @@ def test_rays_G_and_lsmr_at_the_baseline_geometry(ctx, orc, workload_guard, name
     xo, io = orc.lsmr(m + c3, n, irT, icT, rwT, b, *cfg)
     assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3, (info, io)
     rel = np.linalg.norm(x - xo) / np.linalg.norm(xo)
-    assert rel <= 1e-3, rel
+    within(f"{name} LSMR x rel-L2 (identical A, b)", rel, 3e-4)
     # and the device-built rows give the same solution (G differs from the oracle's by last-bit entries only)
     G.append_coo(c3, irT[len(rw_o):], icT[len(rw_o):], rwT[len(rw_o):])
     x2, info2 = ctx.lsmr(G, b, *cfg)
     assert info2["istop"] == io["istop"] and abs(info2["itn"] - io["itn"]) <= 3
     rel2 = np.linalg.norm(x2 - xo) / np.linalg.norm(xo)
-    assert rel2 <= 1e-3, rel2
+    within(f"{name} LSMR x rel-L2 (device rows)", rel2, 3e-4)
     A.free(); G.free()
     print(f"\n[{name}] rays {m}, nnz {len(rw)}: tpred rel {np.abs(tpred - tp_o).max() / np.abs(tp_o).max():.2e}, "
           f"G max {dmax:.2e} frob {frob:.2e}; lsmr itn {info['itn']}/{io['itn']} x rel {rel:.2e} (device rows {rel2:.2e}); "

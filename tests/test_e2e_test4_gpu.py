@@ -14,6 +14,9 @@ import os
 import numpy as np
 import pytest
 
+from tests.bars import at_least, within
+from tests.test_disp_gpu import PV_ABS, PV_EQUAL_SHARE
+
 from tests.test_rays_gpu import flatten
 
 pytestmark = pytest.mark.gpu
@@ -29,21 +32,22 @@ def test_test4_yunnan_iso_iteration(ctx, orc):
     pv, sen, nfail = ctx.depthkernel(vel, depz, t, minthk)
     assert nfail == 0
     dpv = np.abs(pv - d["pv"].astype(np.float64))
-    assert dpv.max() <= 4e-6 and (pv.astype(np.float32) == d["pv"]).mean() >= 0.995
+    within("test4 pvRc max |d| km/s", dpv.max(), PV_ABS)
+    at_least("test4 pvRc bit-equal share", (pv.astype(np.float32) == d["pv"]).mean(), PV_EQUAL_SHARE)
     scx, scz, per, ray_f, rx, rz = flatten(d["scxf"], d["sczf"], d["rcxf"], d["rczf"], d["nrc1"], d["nsrc1"], d["periods"])
     assert len(scx) == 1469 and len(rx) == 20877
     fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
     G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
     dsurf = d["dsurf"]
-    assert np.abs(tpred - dsurf).max() <= 1e-5 * np.abs(dsurf).max()
+    within("test4 tpred rel", np.abs(tpred - dsurf).max() / np.abs(dsurf).max(), 1e-7)
     dall, n = len(dsurf), (nx - 2) * (ny - 2) * (nz - 1)
     assert (G.m, G.n) == (dall, n)
-    assert abs(G.nnz - int(d["nnz"])) <= 1e-3 * int(d["nnz"])
+    within("test4 iso nnz difference", abs(G.nnz - int(d["nnz"])), 2.0)
     ir, ic, rw = G.to_coo()
     rowsum = np.bincount(ir - 1, weights=np.abs(rw).astype(np.float64), minlength=dall)
     colsum = np.bincount(ic - 1, weights=np.abs(rw).astype(np.float64), minlength=n)
-    assert np.linalg.norm(rowsum - d["rowsum"]) <= 1e-4 * np.linalg.norm(d["rowsum"])
-    assert np.linalg.norm(colsum - d["colsum"]) <= 1e-4 * np.linalg.norm(d["colsum"])
+    within("test4 iso |G| row sums rel-L2", np.linalg.norm(rowsum - d["rowsum"]) / np.linalg.norm(d["rowsum"]), 1e-7)
+    within("test4 iso |G| column sums rel-L2", np.linalg.norm(colsum - d["colsum"]) / np.linalg.norm(d["colsum"]), 1e-7)
     del ir, ic, rw
     # Tikhonov rows exactly as the reference appends them (inv/TikhRegul.f90:2, weight 20 = para.in)
     e = np.zeros(0, np.float32)
@@ -55,8 +59,8 @@ def test_test4_yunnan_iso_iteration(ctx, orc):
     x, info = ctx.lsmr(G, b, 0.0, 1e-3, 1e-3, 1200.0, 1000, 64)
     gi = d["info"]
     assert info["istop"] == int(gi[0]) and abs(info["itn"] - int(gi[1])) <= 3
-    assert np.linalg.norm(x - d["x"]) <= 1e-2 * np.linalg.norm(d["x"])
-    assert abs(info["normr"] - gi[4]) <= 1e-3 * gi[4]
+    within("test4 iso LSMR update rel-L2", np.linalg.norm(x - d["x"]) / np.linalg.norm(d["x"]), 1e-4)
+    within("test4 iso LSMR normr rel", abs(info["normr"] - gi[4]) / gi[4], 1e-5)
     G.free()
 
 
@@ -77,21 +81,21 @@ def test_test4_yunnan_joint_iteration(ctx, orc):
     pv, sen, nfail = ctx.depthkernel(vel, depz, t, minthk)
     lsen = ctx.ti_kernels(vel, depz, t, minthk, pv)
     dl = np.abs(lsen - j["lsen"])
-    assert dl.max() <= 2e-5 * np.abs(j["lsen"]).max() and (dl <= 1e-6 * np.abs(j["lsen"]).max()).mean() >= 0.995
+    within("test4 Lsen_Gsc max |d| / max", dl.max() / np.abs(j["lsen"]).max(), 3e-7)
     scx, scz, per, ray_f, rx, rz = flatten(d["scxf"], d["sczf"], d["rcxf"], d["rczf"], d["nrc1"], d["nsrc1"], d["periods"])
     fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
     G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
     dall, nvp = len(tpred), (nx - 2) * (ny - 2) * (nz - 1)
     assert (G.m, G.n) == (dall, 3 * nvp)
-    assert abs(G.nnz - int(j["nnz"])) <= 1e-3 * int(j["nnz"])
+    within("test4 joint nnz difference", abs(G.nnz - int(j["nnz"])), 20.0)
     # data weights exactly as the reference formed them (CalDdatSigma on the reference's residuals)
     G.scale_rows(j["w"])
     ir, ic, rw = G.to_coo()
     rowsum = np.bincount(ir - 1, weights=np.abs(rw).astype(np.float64), minlength=dall)
     colsum = np.bincount(ic - 1, weights=np.abs(rw).astype(np.float64), minlength=3 * nvp)
     del ir, ic, rw
-    assert np.linalg.norm(rowsum - j["rowsum"]) <= 1e-4 * np.linalg.norm(j["rowsum"])
-    assert np.linalg.norm(colsum - j["colsum"]) <= 1e-4 * np.linalg.norm(j["colsum"])
+    within("test4 joint weighted |G| row sums rel-L2", np.linalg.norm(rowsum - j["rowsum"]) / np.linalg.norm(j["rowsum"]), 1e-6)
+    within("test4 joint weighted |G| column sums rel-L2", np.linalg.norm(colsum - j["colsum"]) / np.linalg.norm(j["colsum"]), 1e-6)
     # joint Tikhonov rows: dVs block with 20, Gc and Gs blocks with 30 (inv/TikhRegul.f90:108)
     e = np.zeros(0, np.float32)
     ei = np.zeros(0, np.int32)
@@ -110,6 +114,6 @@ def test_test4_yunnan_joint_iteration(ctx, orc):
     assert info["istop"] == int(gi[0]) and abs(info["itn"] - int(gi[1])) <= max(3, 0.05 * gi[1])
     for blk in range(3):
         a, r = x[blk * nvp:(blk + 1) * nvp], j["x"][blk * nvp:(blk + 1) * nvp]
-        assert np.linalg.norm(a - r) <= 2e-2 * np.linalg.norm(r), blk
-    assert abs(info["normr"] - gi[4]) <= 1e-3 * gi[4]
+        within(f"test4 joint LSMR update block {blk} rel-L2", np.linalg.norm(a - r) / np.linalg.norm(r), 3e-4)
+    within("test4 joint LSMR normr rel", abs(info["normr"] - gi[4]) / gi[4], 1e-5)
     G.free()

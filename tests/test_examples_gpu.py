@@ -12,6 +12,9 @@ import subprocess
 import numpy as np
 import pytest
 
+from tests.bars import at_least, within
+from tests.test_host_program_gpu import LOOP_GCS, LOOP_VS
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "host", "DAzimSurfTomo_amd")
@@ -49,9 +52,9 @@ def test_example_test2_iso_20_iterations(tmp_path):
             cur.extend(float(v) for v in ln.split())
     assert len(blocks) == 20
     dev = [np.abs(np.array(b).reshape(nz, ny, nx) - m).max() for b, m in zip(blocks, models)]
-    assert max(dev) <= 2e-3 + 5e-4, dev                      # IterVel.out prints 3 decimals
+    within("test2 example Vs after every iteration (3 decimals)", max(dev), LOOP_VS + 1e-3)
     final = np.loadtxt(tmp_path / "DSurfTomo.inv")[:, 3].reshape(nz, ny, nx)
-    assert np.abs(final - models[-1]).max() <= 2e-3
+    within("test2 example final Vs", np.abs(final - models[-1]).max(), LOOP_VS + 1e-4)
     # the inversion recovers the checkerboard it was generated from (sanity of the whole chain, not a parity claim)
     start = np.array(str(g["test2_mod"]).split()[nz:], float).reshape(nz, ny, nx)
     inner = (slice(0, nz - 1), slice(1, ny - 1), slice(1, nx - 1))
@@ -69,12 +72,12 @@ def test_example_test3_joint_5_iterations(tmp_path):
     nx, ny, nz = int(g["nx"]), int(g["ny"]), int(g["nz"])
     run(tmp_path, g, "test3")
     final = np.loadtxt(tmp_path / "DSurfTomo.inv")[:, 3].reshape(nz, ny, nx)
-    assert np.abs(final - g["test3_models"][-1]).max() <= 2e-3
+    within("test3 example final Vs", np.abs(final - g["test3_models"][-1]).max(), LOOP_VS + 1e-4)
     az = np.loadtxt(tmp_path / "Gc_Gs_model.inv")
     gc = az[:, 6].reshape(nz - 1, ny - 2, nx - 2)
     gs = az[:, 7].reshape(nz - 1, ny - 2, nx - 2)
-    assert np.abs(gc - g["test3_gc"] * 100).max() <= 0.02 + 5e-5
-    assert np.abs(gs - g["test3_gs"] * 100).max() <= 0.02 + 5e-5
+    within("test3 example Gc/L %", np.abs(gc - g["test3_gc"] * 100).max(), LOOP_GCS + 1e-4)
+    within("test3 example Gs/L %", np.abs(gs - g["test3_gs"] * 100).max(), LOOP_GCS + 1e-4)
     # recovered anisotropy correlates with the true Gc model of test1
     r = np.corrcoef(gc.ravel(), g["gc_true"].ravel())[0, 1]
     assert r > 0.5, r
@@ -101,13 +104,13 @@ def test_example_test4_yunnan_joint_5_iterations(tmp_path):
     assert out.returncode == 0 and "Program finishes successfully" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     # fixed-width columns (5f8.4 / 8f10.4): depths >= 100 km fill their field and touch the previous column, like in the reference
     final = np.genfromtxt(tmp_path / "DSurfTomo.inv", delimiter=[8, 8, 8, 8])[:, 3].reshape(nz, ny, nx)
-    assert np.abs(final - g["models"][-1]).max() <= 2e-3
+    within("test4 example final Vs (5 iterations)", np.abs(final - g["models"][-1]).max(), 2e-4 + 1e-4)
     az = np.genfromtxt(tmp_path / "Gc_Gs_model.inv", delimiter=[10] * 8)
     gc = az[:, 6].reshape(nz - 1, ny - 2, nx - 2)
     gs = az[:, 7].reshape(nz - 1, ny - 2, nx - 2)
     assert np.abs(g["gc"]).max() * 100 > 1.0
-    assert np.abs(gc - g["gc"] * 100).max() <= 0.02 + 5e-5
-    assert np.abs(gs - g["gs"] * 100).max() <= 0.02 + 5e-5
+    within("test4 example Gc/L %", np.abs(gc - g["gc"] * 100).max(), 4e-3 + 1e-4)
+    within("test4 example Gs/L %", np.abs(gs - g["gs"] * 100).max(), 4e-3 + 1e-4)
     log = open(tmp_path / "para.in_inv.log").read()
     itn = [int(ln.split("=")[1]) for ln in log.splitlines() if ln.strip().startswith("itn=")]
     assert len(itn) == 5

@@ -12,6 +12,14 @@ import subprocess
 import numpy as np
 import pytest
 
+from tests.bars import at_least, within
+
+# These goldens come from the reference ROUTINES driven by a Python restatement of the main program's glue
+# (tests/golden/make_inversion_golden.py); the reference PROGRAM itself is compared file by file in tests/test_program_files_gpu.py.
+# The loop differs from the program by up to 2.3e-4 km/s, so these bars cannot go below that.
+LOOP_VS = 6e-4       # km/s
+LOOP_GCS = 0.04      # % (LSMR with a 10-vector reorthogonalisation window: see tests/test_program_files_gpu.py)
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "host", "DAzimSurfTomo_amd")
@@ -52,7 +60,7 @@ def test_iso_inversion_matches_reference_loop(tmp_path):
     assert len(vs_blocks) == niter and len(dws_blocks) == niter
     for it in range(niter):
         got = np.array(vs_blocks[it]).reshape(nz, ny, nx)
-        assert np.abs(got - models[it]).max() <= 2e-3 + 5e-4, (it, np.abs(got - models[it]).max())
+        within(f"iso program Vs after iteration {it + 1} vs the reference routines' loop (3 decimals)", np.abs(got - models[it]).max(), LOOP_VS + 1e-3)
     dws = np.array(dws_blocks[0])
     assert dws.shape == g["dws1"].shape
     assert np.abs(dws - g["dws1"]).max() <= 1e-3 * np.abs(g["dws1"]).max() + 1e-3
@@ -61,7 +69,7 @@ def test_iso_inversion_matches_reference_loop(tmp_path):
     inv = np.loadtxt(tmp_path / "DSurfTomo.inv")
     assert inv.shape == (nx * ny * nz, 4)
     final = inv[:, 3].reshape(nz, ny, nx)
-    assert np.abs(final - models[-1]).max() <= 2e-3
+    within("iso program final Vs vs the reference routines' loop", np.abs(final - models[-1]).max(), LOOP_VS + 1e-4)
     # lon/lat/depth columns of writeVsmodel (inv/Main_Jt.f90:849): gozd+(j-2)*dvzd, goxd-(i-2)*dvxd, depz(k)
     k, j, i = 2, 3, 4
     row = inv[(k * ny + j) * nx + i]
@@ -102,14 +110,14 @@ def test_joint_inversion_matches_reference_loop(tmp_path):
     assert "Program finishes successfully" in stdout and "invert for dVs, Gc, Gs" in stdout
     inv = np.loadtxt(tmp_path / "DSurfTomo.inv")
     final = inv[:, 3].reshape(nz, ny, nx)
-    assert np.abs(final - g["models"][-1]).max() <= 2e-3
+    within("joint program final Vs vs the reference routines' loop", np.abs(final - g["models"][-1]).max(), LOOP_VS + 1e-4)
     az = np.loadtxt(tmp_path / "Gc_Gs_model.inv")           # lon lat depth vs angle amp Gc% Gs%
     assert az.shape == ((nx - 2) * (ny - 2) * (nz - 1), 8)
     gc = az[:, 6].reshape(nz - 1, ny - 2, nx - 2)
     gs = az[:, 7].reshape(nz - 1, ny - 2, nx - 2)
     assert np.abs(g["gc"][-1]).max() * 100 > 1.0             # a few per cent of anisotropy in the golden
-    assert np.abs(gc - g["gc"][-1] * 100).max() <= 0.02 + 5e-5
-    assert np.abs(gs - g["gs"][-1] * 100).max() <= 0.02 + 5e-5
+    within("joint program Gc/L % vs the loop", np.abs(gc - g["gc"][-1] * 100).max(), LOOP_GCS + 1e-4)
+    within("joint program Gs/L % vs the loop", np.abs(gs - g["gs"][-1] * 100).max(), LOOP_GCS + 1e-4)
     amp = 0.5 * np.sqrt(g["gc"][-1].astype(np.float64) ** 2 + g["gs"][-1].astype(np.float64) ** 2)
     assert np.abs(az[:, 5].reshape(amp.shape) - amp).max() <= 2e-4
     log = open(tmp_path / "para.in_inv.log").read()

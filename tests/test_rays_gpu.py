@@ -12,6 +12,14 @@ differ in the last bit and, rarely, land in the neighbouring cell.  Hence (SURVE
 import numpy as np
 import pytest
 
+from tests.bars import at_least, within
+
+# bars.  G: an entry sitting on the 1e-4 threshold may appear on one side only, so max |dG| can reach ftol
+# however well the rays agree; everything else is twice the measured maximum.
+TPRED_REL = 1e-7
+G_MAX = 2e-4
+G_FROB = 2e-5
+
 from tests import synth
 from tests.test_disp_gpu import model
 
@@ -83,14 +91,14 @@ def test_G_matches_oracle(ctx, orc, nx, ny, depz, kmax, minthk):
     fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
     G, tpred, nb = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
     assert len(tpred) == len(ds_o)
-    assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
+    within("tpred rel", np.abs(tpred - ds_o).max() / np.abs(ds_o).max(), TPRED_REL)
     ir, ic, rw = G.to_coo()
     m, n = len(ds_o), (nx - 2) * (ny - 2) * (len(depz) - 1)
     assert (G.m, G.n) == (m, n)
     assert np.all(np.diff(ir) >= 0) and np.all(np.abs(rw) > 1e-4)        # row order + threshold
     D, Do = dense(m, n, ir, ic, rw), dense(m, n, ir_o, ic_o, rw_o)
-    assert np.abs(D - Do).max() <= 2e-4
-    assert np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
+    within("G max |d|", np.abs(D - Do).max(), G_MAX)
+    within("G rel-Frobenius", np.linalg.norm(D - Do) / np.linalg.norm(Do), G_FROB)
     # every row ascending in column = the reference's nn loop order
     for r in np.unique(ir)[:50]:
         assert np.all(np.diff(ic[ir == r]) > 0)
@@ -101,7 +109,7 @@ def test_G_matches_oracle(ctx, orc, nx, ny, depz, kmax, minthk):
     x = np.random.default_rng(0).standard_normal(n).astype(np.float32)
     y = np.zeros(m + c3, np.float32); yo = y.copy()
     ctx.aprod(1, G, x, y); orc.aprod(1, m + c3, n, x.copy(), yo, irT, icT, rwT)
-    assert np.linalg.norm(y - yo) <= 1e-4 * np.linalg.norm(yo)
+    within("A.x with Tikhonov rows rel-L2", np.linalg.norm(y - yo) / np.linalg.norm(yo), 1e-5)
     # the same matrix with the regularisation rows announced beforehand (options csr.reserve_*): they are appended in place,
     # behind the ray rows, instead of by reallocating and copying G -- identical triplets and products
     coo = G.to_coo()
@@ -144,8 +152,8 @@ def test_G_matches_oracle_on_a_rough_model(ctx, orc):
     ir, ic, rw = G.to_coo()
     m, n = len(ds_o), (nx - 2) * (ny - 2) * (len(depz) - 1)
     D, Do = dense(m, n, ir, ic, rw), dense(m, n, ir_o, ic_o, rw_o)
-    assert np.abs(D - Do).max() <= 2e-4
-    assert np.linalg.norm(D - Do) <= 1e-4 * np.linalg.norm(Do)
+    within("G max |d|", np.abs(D - Do).max(), G_MAX)
+    within("G rel-Frobenius", np.linalg.norm(D - Do) / np.linalg.norm(Do), G_FROB)
     G.free()
 
 
@@ -190,11 +198,11 @@ def test_joint_G_matches_oracle(ctx, orc):
     assert np.abs(tpred - ds_o).max() <= 1e-6 * np.abs(ds_o).max()
     ir, ic, rw = G.to_coo()
     D, Do = dense(m, 3 * nvp, ir, ic, rw), dense(m, 3 * nvp, ir_o, ic_o, rw_o)
-    assert np.abs(D - Do).max() <= 2e-4
+    within("joint G max |d|", np.abs(D - Do).max(), G_MAX)
     for b in range(3):   # every block on its own: dVs, Gc, Gs
         blk, blko = D[:, b * nvp:(b + 1) * nvp], Do[:, b * nvp:(b + 1) * nvp]
         assert np.linalg.norm(blko) > 0
-        assert np.linalg.norm(blk - blko) <= 1e-4 * np.linalg.norm(blko), b
+        within(f"joint G block {b} rel-Frobenius", np.linalg.norm(blk - blko) / np.linalg.norm(blko), G_FROB)
     G.free()
 
 
@@ -319,8 +327,8 @@ def test_dense_twin_is_the_reference_dense_copy(ctx, orc, joint):
                 Do[r] = orc.dense_row(vel, fdm, sen, k)
     for b in range(3 if joint else 1):
         blk, blko = D[:, b * npar:(b + 1) * npar], Do[:, b * npar:(b + 1) * npar]
-        assert np.abs(blk - blko).max() <= 2e-4, (b, np.abs(blk - blko).max())          # a cell on the |fdm| = ftol edge
-        assert np.linalg.norm(blk - blko) <= 1e-4 * np.linalg.norm(blko), (b, np.linalg.norm(blk - blko) / np.linalg.norm(blko))
+        within(f"dense twin block {b} max |d|", np.abs(blk - blko).max(), G_MAX)          # a cell on the |fdm| = ftol edge
+        within(f"dense twin block {b} rel-Frobenius", np.linalg.norm(blk - blko) / np.linalg.norm(blko), G_FROB)
     # the quirk is really there: the dVs block is NOT the un-thresholded row with each cell's own derivatives
     try:
         ctx.set_option("rays.keep_small", 1)

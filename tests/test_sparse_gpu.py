@@ -7,6 +7,10 @@ LSMR `x` with rel-L2 <= 1e-3 and `itn` within +-3 of the oracle for identical (A
 import numpy as np
 import pytest
 
+from tests.bars import at_least, within
+
+LSMR_X = 1e-3      # rel-L2 of the solution for identical (A, b); DESIGN.md section 5 quotes the measured maxima
+
 pytestmark = pytest.mark.gpu
 
 
@@ -38,11 +42,11 @@ def test_aprod_matches_oracle(ctx, orc, m, n, per_row):
     y_gpu, y_cpu = y0.copy(), y0.copy()
     ctx.aprod(1, A, x, y_gpu)
     orc.aprod(1, mm, n, x.copy(), y_cpu, irow, icol, rw)
-    assert np.linalg.norm(y_gpu - y_cpu) <= 2e-6 * np.linalg.norm(y_cpu)
+    within("A.x rel-L2", np.linalg.norm(y_gpu - y_cpu) / np.linalg.norm(y_cpu), 2e-6)
     x_gpu, x_cpu = x.copy(), x.copy()
     ctx.aprod(2, A, x_gpu, y0.copy())
     orc.aprod(2, mm, n, x_cpu, y0.copy(), irow, icol, rw)
-    assert np.linalg.norm(x_gpu - x_cpu) <= 2e-6 * np.linalg.norm(x_cpu)
+    within("At.y rel-L2", np.linalg.norm(x_gpu - x_cpu) / np.linalg.norm(x_cpu), 2e-6)
     A.free()
 
 
@@ -82,8 +86,8 @@ def test_lsmr_matches_oracle(ctx, orc, cfg):
     xo, io = orc.lsmr(m, n, irow, icol, rw, b, 0.01, cfg["atol"], cfg["btol"], cfg["conlim"], cfg["itnlim"], ls)
     assert info["istop"] == io["istop"]
     assert abs(info["itn"] - io["itn"]) <= 3
-    assert np.linalg.norm(x - xo) <= 1e-3 * np.linalg.norm(xo)
-    assert abs(info["normr"] - io["normr"]) <= 1e-3 * io["normr"]
+    within("LSMR x rel-L2", np.linalg.norm(x - xo) / np.linalg.norm(xo), LSMR_X)
+    within("LSMR normr rel", abs(info["normr"] - io["normr"]) / io["normr"], 1e-4)
     assert abs(info["normA"] - io["normA"]) <= 1e-2 * io["normA"]
     # residual property, independent of the oracle: A^T(b - A x) is small relative to |A||r|
     r = b.copy(); tmp = np.zeros(m, np.float32)
@@ -132,7 +136,7 @@ def test_lsmr_distributed_driver_on_gpu(ctx, orc):
     x, info = lsmr_distributed(GpuLocalOps(ctx, A), torch.from_numpy(b).cuda(), 500, *cfg)
     xo, io = orc.lsmr(m, 500, irow, icol, rw, b, *cfg)
     assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3
-    assert np.linalg.norm(x.cpu().numpy() - xo) <= 1e-3 * np.linalg.norm(xo)
+    within("LSMR x rel-L2 (device tensors)", np.linalg.norm(x.cpu().numpy() - xo) / np.linalg.norm(xo), LSMR_X)
     A.free()
 
 
@@ -153,8 +157,8 @@ def test_lsmr_native_rccl_single_rank(orc):
             c.comm_free()
             xo, io = orc.lsmr(m, 600, irow, icol, rw, b, *cfg)
             assert i1["istop"] == io["istop"] and abs(i1["itn"] - io["itn"]) <= 3
-            assert np.linalg.norm(x1 - xo) <= 1e-3 * np.linalg.norm(xo)
-            assert np.linalg.norm(x1 - x0) <= 1e-3 * np.linalg.norm(x0)
+            within("LSMR x rel-L2 (kernel variants vs oracle)", np.linalg.norm(x1 - xo) / np.linalg.norm(xo), LSMR_X)
+            within("LSMR x rel-L2 (kernel variants among themselves)", np.linalg.norm(x1 - x0) / np.linalg.norm(x0), LSMR_X)
         A.free()
     finally:
         c.close()

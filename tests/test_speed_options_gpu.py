@@ -2,7 +2,7 @@
 on the S-256 geometry with a reduced batch, once with the library's defaults and once with every speed device of round 2
 switched off:
 
-  disp.ffwd = 0     first period's bracket search step by step (no jump to the bracket found by disp_bracket_kernel)
+  disp.ffwd = 0     first period's bracket search step by step (against disp.ffwd = 2: the column AND its perturbed copies jump)
   rays.sort = 0     rays dealt to the wavefronts in input order
   spmv.col16 = 0    32-bit column indices in the products
   fmm.sort = 0      fields of a period marched in input order
@@ -45,8 +45,9 @@ def _step(ctx, nsrc=24, nrcv=12, kmax=4):
 
 
 def test_speed_options_do_not_change_any_result(ctx):
-    fast = _step(ctx)
     try:
+        ctx.set_option("disp.ffwd", 2)          # (the opt-in jump of the perturbed copies as well: every speed device on)
+        fast = _step(ctx)
         for name in ("disp.ffwd", "rays.sort", "spmv.col16", "fmm.sort"):
             ctx.set_option(name, 0)
         plain = _step(ctx)

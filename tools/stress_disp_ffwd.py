@@ -33,7 +33,7 @@ def differing(vel):
     pv1, sen1, nf1 = ctx.depthkernel(vel, depz, t, 3.0)
     ctx.set_option("disp.ffwd", 0)
     pv0, sen0, nf0 = ctx.depthkernel(vel, depz, t, 3.0)
-    ctx.set_option("disp.ffwd", 1)
+    ctx.set_option("disp.ffwd", 2)
     d = (pv0 != pv1).any(axis=0)
     for a, b in zip(sen0, sen1):
         d |= (a != b).any(axis=(0, 1))
