@@ -21,13 +21,19 @@ module dazim_mod
   use iso_c_binding
   implicit none
   private
-  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense
+  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense, dazim_aprod_forget
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
             dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
+  ! the matrix of the last aprod call (see aprod) and how often it had to be (re)built
+  type(c_ptr), save :: aprod_A = c_null_ptr
+  integer(c_intptr_t), save :: aprod_iw = 0, aprod_rw = 0
+  integer, save :: aprod_kk = -1, aprod_m = -1, aprod_n = -1
+  real(8), save :: aprod_fp = 0
+  integer, save, public :: aprod_builds = 0
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
   logical, save :: dazim_fill_dense = .true.
   ! device buffers of the eikonal fields, kept between calls of dazim_assemble_G (one per outer iteration, same sizes)
@@ -229,6 +235,7 @@ contains
     integer :: q
     integer(c_int) :: rc
     if (c_associated(dazim_handle)) then
+      call dazim_aprod_forget()
       do q = 1, 5
         if (c_associated(fld_ptr(q))) rc = dazim_free(dazim_handle, fld_ptr(q))
         fld_ptr(q) = c_null_ptr; fld_bytes(q) = 0
@@ -489,17 +496,50 @@ contains
   end subroutine
 
   ! ---- inv/aprod.f90:7 -----------------------------------------------------------------------------
+  ! A caller that keeps the reference's own LSMR and swaps only aprod calls this twice per iteration with the same iw / rw: the
+  ! device CSR is built once and kept, keyed on the arrays' addresses, sizes and a fingerprint of their contents (the count
+  ! iw(1), 1024 evenly spaced samples of rw, of the row ids and of the column ids -- a caller that rewrites the arrays in place
+  ! between two solves changes it; dazim_aprod_forget() drops the cached matrix explicitly).
   subroutine aprod(mode, m, n, x, y, leniw, lenrw, iw, rw)
-    integer :: mode, m, n, leniw, lenrw, iw(leniw)
-    real :: x(n), y(m), rw(lenrw)
-    type(c_ptr) :: A
+    integer :: mode, m, n, leniw, lenrw
+    integer, target :: iw(leniw)
+    real, target :: rw(lenrw)
+    real :: x(n), y(m)
     integer :: kk
+    integer(c_intptr_t) :: a_iw, a_rw
+    real(8) :: fp
     call dazim_init(0)
     kk = iw(1)
-    call check(dazim_csr_from_coo(dazim_handle, int(m, c_int64_t), int(n, c_int64_t), int(kk, c_int64_t), &
-                                  iw(2:kk + 1), iw(kk + 2:2*kk + 1), rw, A), 'aprod')
-    call check(dazim_aprod(dazim_handle, mode, A, x, y), 'aprod')
-    call check(dazim_csr_free(dazim_handle, A), 'aprod')
+    a_iw = transfer(c_loc(iw), a_iw); a_rw = transfer(c_loc(rw), a_rw)
+    fp = fingerprint(kk, iw, rw)
+    if (.not. (c_associated(aprod_A) .and. a_iw == aprod_iw .and. a_rw == aprod_rw .and. kk == aprod_kk .and. m == aprod_m &
+               .and. n == aprod_n .and. fp == aprod_fp)) then
+      call dazim_aprod_forget()
+      call check(dazim_csr_from_coo(dazim_handle, int(m, c_int64_t), int(n, c_int64_t), int(kk, c_int64_t), &
+                                    iw(2:kk + 1), iw(kk + 2:2*kk + 1), rw, aprod_A), 'aprod')
+      aprod_iw = a_iw; aprod_rw = a_rw; aprod_kk = kk; aprod_m = m; aprod_n = n; aprod_fp = fp
+      aprod_builds = aprod_builds + 1
+    end if
+    call check(dazim_aprod(dazim_handle, mode, aprod_A, x, y), 'aprod')
+  contains
+    real(8) function fingerprint(kk, iw, rw)
+      integer, intent(in) :: kk, iw(*)
+      real, intent(in) :: rw(*)
+      integer :: q, step
+      fingerprint = kk
+      if (kk < 1) return
+      step = max(1, kk/1024)
+      do q = 1, kk, step
+        fingerprint = fingerprint*1.0000001d0 + real(rw(q), 8) + 3.0d0*iw(1 + q) + 7.0d0*iw(1 + kk + q)
+      end do
+      fingerprint = fingerprint + real(rw(kk), 8) + iw(1 + kk) + iw(1 + 2*kk)
+    end function
+  end subroutine
+
+  ! drop the matrix the aprod drop-in keeps on the device (also done by dazim_finalize)
+  subroutine dazim_aprod_forget()
+    if (c_associated(aprod_A)) call check(dazim_csr_free(dazim_handle, aprod_A), 'aprod')
+    aprod_A = c_null_ptr
   end subroutine
 
   ! ---- inv/lsmrModule.f90:36 -------------------------------------------------------------------------

@@ -75,6 +75,25 @@ program host_example
   write (11, '(10i8)') iw(2:nar + 1)
   write (11, '(10i8)') col(1:nar)
   write (11, '(5es16.8)') gx
+  ! the aprod drop-in as a caller with its own LSMR would use it: both products, twice, on the same iw / rw (one CSR build),
+  ! then on rescaled values in the same arrays (a second build): y = G x, z = G^T b
+  block
+    real, allocatable :: yy(:), zz(:)
+    allocate (yy(m), zz(n))
+    do i = 1, 2
+      yy = 0; zz = 0
+      call aprod(1, m, n, x, yy, 2*nar + 1, nar, iw, rw)
+      call aprod(2, m, n, zz, b, 2*nar + 1, nar, iw, rw)
+    end do
+    write (11, *) aprod_builds
+    write (11, '(5es16.8)') yy
+    write (11, '(5es16.8)') zz
+    rw(1:nar) = 2.0*rw(1:nar)
+    yy = 0
+    call aprod(1, m, n, x, yy, 2*nar + 1, nar, iw, rw)
+    write (11, *) aprod_builds
+    write (11, '(5es16.8)') yy
+  end block
   close (11)
   call dazim_finalize()
 end program

@@ -4,9 +4,9 @@ Tolerance, stated and justified: the root search is fp64 and the device's exp/si
 from glibc's in the last bit, so the converged root can differ by a few 1e-16 relative -- invisible
 after the reference's own rounding cg(k)=sngl(c(k)) except when the root sits on an fp32 rounding
 boundary or a convergence test (|c1-c2| <= 1e-6*c1, inv/surfdisp96.f:608) flips.  Hence:
-  pvRc : |d| <= 4e-6 km/s everywhere (the root tolerance), and bit-equal on >= 99.5 % of entries;
-  sen_*: |d| <= 1e-3 * max|sen| + 2e-4 abs (one-ulp flip of c divided by 0.01*v)
-         and relative L2 error <= 1e-4.
+  pvRc : |d| <= one fp32 ulp and bit-equal on >= 99.9 % of entries (measured: bit-equal everywhere on layered models);
+  sen_*: |d| <= 2e-5 abs (one-ulp flip of c divided by 0.01*v) and relative L2 error <= 1e-6
+  (see the constants below; columns of independent random knots have their own, measured, bars).
 """
 import numpy as np
 import pytest
@@ -29,10 +29,15 @@ def model(nx, ny, depz, seed):
 
 
 # the bars (DESIGN.md section 5 quotes the measured maxima they are twice of)
-PV_ABS = 4e-6            # km/s
-PV_EQUAL_SHARE = 0.995   # share of bit-equal pvRc entries
-SEN_REL, SEN_ABS = 1e-3, 2e-4
-SEN_L2 = 1e-4
+# Measured (MI355X, round 3): pvRc and sen_* are BIT-EQUAL to the oracle on every layered model of this file and of the examples
+# (max |d| = 0, share 1.0); only columns whose knots are drawn independently at random differ (max 2.9e-6 km/s, 0.4 % of the
+# entries: the root tolerance 1e-6 c decides).  Bars: one fp32 ulp of c on at most 0.1 % of the entries for models (SURVEY 8d's
+# proposal), twice the measured figures for the rough random columns.
+PV_ABS = 4.8e-7          # km/s: one ulp of an fp32 phase velocity in 4..8 km/s
+PV_EQUAL_SHARE = 0.999   # share of bit-equal pvRc entries
+PV_ABS_ROUGH, PV_EQUAL_SHARE_ROUGH = 6e-6, 0.9925
+SEN_REL, SEN_ABS = 0.0, 2e-5   # one-ulp flip of c divided by 0.01 v
+SEN_L2 = 1e-6
 
 
 def compare(ctx, orc, vel, depz, t, minthk):
@@ -229,15 +234,15 @@ def test_first_period_fast_forward_on_graded_random_models(ctx, p):
 
 def test_phase_velocities_on_rough_random_columns(ctx, orc):
     """600 of the rough random columns (knots drawn independently from 2.6 .. 4.7 km/s) against the oracle, phase velocities only:
-    the usual bars (4e-6 km/s, >= 99.5 % bit-equal) and the same root failures"""
+    their own bars (twice the measured 2.9e-6 km/s / 0.4 %) and the same root failures"""
     rng = np.random.default_rng(5)
     vel = rng.uniform(2.6, 4.7, (len(ROUGH_DEPZ), 20, 30)).astype(np.float32)
     vel[-1] = np.maximum(vel[-1], 4.2)
     pv, _, nf = ctx.depthkernel(vel, ROUGH_DEPZ, ROUGH_T, 3.0, kernels=False)
     pvo, _ = orc.depthkernel(vel, ROUGH_DEPZ, ROUGH_T, 3.0, kernels=False)
     assert np.array_equal(pv == 0, pvo == 0) and nf == int((pvo == 0).sum())
-    within("rough random columns pvRc max |d| km/s", np.abs(pv - pvo).max(), PV_ABS)
-    at_least("rough random columns pvRc bit-equal share", (pv == pvo).mean(), PV_EQUAL_SHARE)
+    within("rough random columns pvRc max |d| km/s", np.abs(pv - pvo).max(), PV_ABS_ROUGH)
+    at_least("rough random columns pvRc bit-equal share", (pv == pvo).mean(), PV_EQUAL_SHARE_ROUGH)
 
 
 def test_first_period_fast_forward_on_the_example_models(ctx):

@@ -114,6 +114,6 @@ def test_test4_yunnan_joint_iteration(ctx, orc):
     assert info["istop"] == int(gi[0]) and abs(info["itn"] - int(gi[1])) <= max(3, 0.05 * gi[1])
     for blk in range(3):
         a, r = x[blk * nvp:(blk + 1) * nvp], j["x"][blk * nvp:(blk + 1) * nvp]
-        within(f"test4 joint LSMR update block {blk} rel-L2", np.linalg.norm(a - r) / np.linalg.norm(r), 3e-4)
-    within("test4 joint LSMR normr rel", abs(info["normr"] - gi[4]) / gi[4], 1e-5)
+        within(f"test4 joint LSMR update block {blk} rel-L2", np.linalg.norm(a - r) / np.linalg.norm(r), 4.5e-4)
+    within("test4 joint LSMR normr rel", abs(info["normr"] - gi[4]) / gi[4], 2e-5)
     G.free()

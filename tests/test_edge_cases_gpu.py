@@ -3,6 +3,9 @@ inv/CalSurfG.f90:1114-1328 for a period without sources, :1326 for a source with
 import numpy as np
 import pytest
 
+from tests.bars import within
+from tests.test_disp_gpu import PV_ABS, SEN_ABS, SEN_REL
+
 from tests.test_rays_gpu import build_case, flatten
 
 pytestmark = pytest.mark.gpu
@@ -84,9 +87,10 @@ def test_maximum_layer_count(ctx, orc):
     t = np.array([8.0, 20.0, 45.0])
     pv, sen, nf = ctx.depthkernel(vel, depz, t, 5.0)
     pvo, seno = orc.depthkernel(vel, depz, t, 5.0)
-    assert nf == 0 and np.abs(pv - pvo).max() <= 4e-6
+    assert nf == 0
+    within("199-layer column pvRc max |d| km/s", np.abs(pv - pvo).max(), PV_ABS)
     for a, b in zip(sen, seno):
-        assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max() + 2e-4
+        within("199-layer column sen max |d|", np.abs(a - b).max(), SEN_REL * np.abs(b).max() + 10 * SEN_ABS)
     lsen = ctx.ti_kernels(vel, depz, t, 5.0, pvo)
     _, lo = orc.depthkernel_ti(vel, depz, t, 5.0)
     assert np.abs(lsen - lo).max() <= 1e-6 * np.abs(lo).max()

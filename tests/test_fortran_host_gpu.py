@@ -52,7 +52,14 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     rw = np.array(toks[p:p + nar], np.float32); p += nar
     irow = np.array(toks[p:p + nar], np.int32); p += nar
     icol = np.array(toks[p:p + nar], np.int32); p += nar
-    gx = np.array(toks[p:p + dall], np.float32)          # matmul(GVs, x) formed by the Fortran caller from its dense copy
+    gx = np.array(toks[p:p + dall], np.float32); p += dall   # matmul(GVs, x) formed by the Fortran caller from its dense copy
+    # the aprod drop-in: four calls on the same arrays = one CSR build; after the values were rescaled in place, a second one
+    builds1 = int(toks[p]); p += 1
+    ya = np.array(toks[p:p + dall], np.float32); p += dall
+    za = np.array(toks[p:p + n], np.float32); p += n
+    builds2 = int(toks[p]); p += 1
+    ya2 = np.array(toks[p:p + dall], np.float32); p += dall
+    assert builds1 == 1 and builds2 == 2
     rc, rw_o, ir_o, ic_o, ds_o, nb = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
                                                   nrc1, nsrc1, periods, 2_000_000)
     assert rc == 0 and dall == len(ds_o)
@@ -67,6 +74,12 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     assert istop == io["istop"] and abs(itn - io["itn"]) <= max(3, 0.03 * io["itn"])
     assert abs(normr - io["normr"]) <= 1e-3 * io["normr"] + 1e-7
     assert np.linalg.norm(x - xo) <= 5e-3 * np.linalg.norm(xo)
+    yo = np.zeros(dall, np.float32); zo = np.zeros(n, np.float32)
+    bvec = (dsurf * np.float32(1e-3)).astype(np.float32)
+    orc.aprod(1, dall, n, x.copy(), yo, irow, icol, rw)
+    orc.aprod(2, dall, n, zo, bvec.copy(), irow, icol, rw)
+    assert np.linalg.norm(ya - yo) <= 3e-6 * np.linalg.norm(yo) and np.linalg.norm(za - zo) <= 3e-6 * np.linalg.norm(zo)
+    assert np.linalg.norm(ya2 - 2 * yo) <= 3e-6 * np.linalg.norm(2 * yo)
     # ---- the dense copy GVs the drop-in fills like the reference (inv/CalSurfG.f90:1369-1378): the caller's matmul(GVs, x)
     # (inv/CalSigamNorm.f90:73) must be the product with the library's dense twin (every entry of the |fdm| >= ftol cells, dVs
     # with the Brocher derivatives of the ray's last such cell; tests/test_rays_gpu.py checks the twin against the oracle)

@@ -9,7 +9,7 @@ import pytest
 
 from tests.bars import at_least, within
 
-LSMR_X = 1e-3      # rel-L2 of the solution for identical (A, b); DESIGN.md section 5 quotes the measured maxima
+LSMR_X = 3e-4      # rel-L2 of the solution for identical (A, b); DESIGN.md section 5 quotes the measured maxima
 
 pytestmark = pytest.mark.gpu
 
@@ -87,7 +87,7 @@ def test_lsmr_matches_oracle(ctx, orc, cfg):
     assert info["istop"] == io["istop"]
     assert abs(info["itn"] - io["itn"]) <= 3
     within("LSMR x rel-L2", np.linalg.norm(x - xo) / np.linalg.norm(xo), LSMR_X)
-    within("LSMR normr rel", abs(info["normr"] - io["normr"]) / io["normr"], 1e-4)
+    within("LSMR normr rel", abs(info["normr"] - io["normr"]) / io["normr"], 1e-5)
     assert abs(info["normA"] - io["normA"]) <= 1e-2 * io["normA"]
     # residual property, independent of the oracle: A^T(b - A x) is small relative to |A||r|
     r = b.copy(); tmp = np.zeros(m, np.float32)
@@ -212,3 +212,4 @@ def test_aprod_large_uses_lds_and_scatter_paths(ctx, orc, n, m, per_row):
     x32 = np.zeros(n, np.float32); ctx.aprod(2, A32, x32, y)
     assert np.array_equal(y32, outs["fast"][0]) and np.array_equal(x32, outs["fast"][1])
     A32.free()
+
