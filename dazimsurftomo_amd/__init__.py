@@ -237,6 +237,18 @@ class Context:
         n = (nx - 2) * (ny - 2) * (nz - 1) * (1 if lsen is None else 3)
         return SparseMatrix(self, h, nray, n, nnz.value), tpred, nb.value
 
+    def ray_paths(self):
+        """ray geometries of the last rays_build_G call made with option rays.keep_paths = 1: a list of [nrp][2] arrays
+        (colatitude, longitude in rad; receiver first, source last) -- the reference's raypath_refmdl_<T>s.dat content"""
+        nray, cap = C.c_int64(0), C.c_int(0)
+        self._check(self.lib.dazim_ray_paths_dims(self._h, C.byref(nray), C.byref(cap)))
+        xz = np.zeros((max(nray.value, 1), max(cap.value, 1), 2), np.float32)
+        nrp = np.zeros(max(nray.value, 1), np.int32)
+        self._check(self.lib.dazim_ray_paths_copy(self._h, _ptr(xz), _ptr(nrp)))
+        if (nrp[:nray.value] < 0).any():
+            raise DazimError(DAZIM_E_BAD_ARG if "DAZIM_E_BAD_ARG" in globals() else -1, "a ray path outgrew the point buffer")
+        return [xz[i, :nrp[i]].copy() for i in range(nray.value)]
+
     # ---- K6/K7 -----------------------------------------------------------------------------
     def csr_from_coo(self, m, n, irow, icol, rw):
         """COO triplets as the reference holds them (1-based rows iw(2:nar+1), cols, values rw;

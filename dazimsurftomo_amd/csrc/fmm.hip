@@ -552,6 +552,38 @@ __device__ unsigned long long g_fmm_prof[8];
 #define PROF_FLUSH
 #endif
 
+// experiment switch (tools/exp_fmm_nt.sh): cache-policy hints on the node-record accesses of the marching loop.
+// DZ_FMM_NT bit 0: loads non-temporal, bit 1: stores non-temporal.
+#ifndef DZ_FMM_NT
+#define DZ_FMM_NT 0
+#endif
+__device__ __forceinline__ Node ld_node(const Node *p) {
+#if DZ_FMM_NT & 1
+  const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long *>(p));
+  Node n;
+  n.t = __int_as_float((int)(v & 0xffffffffll));
+  n.s = (int)(v >> 32);
+  return n;
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ void st_node(Node *p, Node n) {
+#if DZ_FMM_NT & 2
+  const long long v = ((long long)n.s << 32) | (unsigned)__float_as_int(n.t);
+  __builtin_nontemporal_store(v, reinterpret_cast<long long *>(p));
+#else
+  *p = n;
+#endif
+}
+__device__ __forceinline__ void st_slot(Node *p, int s) {
+#if DZ_FMM_NT & 2
+  __builtin_nontemporal_store(s, &p->s);
+#else
+  p->s = s;
+#endif
+}
+
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
@@ -585,7 +617,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         break;
       }
     }
-    if (H.g0) rec[iroot].s = 0;
+    if (H.g0) st_slot(&rec[iroot], 0);
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
@@ -603,11 +635,11 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
     const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
     const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
-    Node nself = rec[uself];
-    Node nj = rec[vj ? (unsigned)(xj + zn) : uroot];
-    Node nj2 = rec[vj2 ? (unsigned)(xj2 + zn) : uroot];
-    Node nk = rec[vk ? (unsigned)(xn + zk) : uroot];
-    Node nk2 = rec[vk2 ? (unsigned)(xn + zk2) : uroot];
+    Node nself = ld_node(&rec[uself]);
+    Node nj = ld_node(&rec[vj ? (unsigned)(xj + zn) : uroot]);
+    Node nj2 = ld_node(&rec[vj2 ? (unsigned)(xj2 + zn) : uroot]);
+    Node nk = ld_node(&rec[vk ? (unsigned)(xn + zk) : uroot]);
+    Node nk2 = ld_node(&rec[vk2 ? (unsigned)(xn + zk2) : uroot]);
     const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
     const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
@@ -647,8 +679,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     } else {
 #pragma unroll
       for (int b = 0; b < NCAP; b++)
-        if (cslot[b] > 0) rec[(unsigned)cnode[b]].s = cslot[b];
-      if (H.g0 && fin_slot > 0) rec[(unsigned)fin_node].s = fin_slot;
+        if (cslot[b] > 0) st_slot(&rec[(unsigned)cnode[b]], cslot[b]);
+      if (H.g0 && fin_slot > 0) st_slot(&rec[(unsigned)fin_node], fin_slot);
     }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
@@ -704,7 +736,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
-        if (wr) rec[uself] = Node{trav, c};
+        if (wr) st_node(&rec[uself], Node{trav, c});
         if (HYB && __ballot(whi) != 0) {
           if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }

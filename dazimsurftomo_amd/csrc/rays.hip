@@ -60,6 +60,9 @@ struct RayArgs {
                            // everything a ray produces is stored under its own index)
   unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD); [16] rays whose cell list outgrew
                            // the LDS capacity (full-grid sweep), [17] rays whose list outgrew LK (traced again by the emit pass)
+  float2 *pts;             // option rays.keep_paths: [nray][pcap] ray-path points (colatitude, longitude in rad) as the reference's
+  int *npts;               //   rgx/rgz(1:nrp) (receiver first, source last; fwd/rpathsAzim.f90:221-380); npts = nrp, or -1 if > pcap
+  int pcap;
   int dense;               // the reference's dense copies GVs/GGc/GGs as a second matrix ("twin", option rays.dense_twin):
                            // 0 off; 2 (count pass): also count the twin's entries into countd; 1 (a second emit pass): write the
                            // twin -- every non-zero entry of the |fdm| >= ftol cells, the dVs block with the Brocher derivatives
@@ -331,6 +334,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       };
       int igref = in_refined(ipxr, ipzr);
       if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
+      // ray geometry for the path files (writepath): point 1 = the receiver; a ray that ends at once gets the source as point 2
+      const bool keep_pts = !EMIT && A.pts != nullptr && gl == 0;
+      float2 *rp = A.pts ? A.pts + (size_t)ray * A.pcap : nullptr;
+      int np = 1;
+      if (keep_pts) {
+        rp[0] = make_float2(rcx, rcz);
+        if (sw == 1) { if (A.pcap > 1) rp[1] = make_float2(scx, scz); np = 2; }
+      }
       // register-cached 4x4 block of the Frechet grid(s): this lane's cell is (bz+ll, bx+lm)
       int cbx = -100, cbz = -100;
       float acc[LPR], accc[LPR], accs[LPR];
@@ -400,6 +411,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         if (ipz < 1) { z1 = goz; ipz = 1; rb = 1; }
         if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; rb = 1; }
         load_corner_times();
+        if (keep_pts) {   // rgx(j+1) after the clipping, then rgx(j+2) = the source if this was the last step (:352-400)
+          if (np < A.pcap) rp[np] = make_float2(x1, z1);
+          np++;
+          if (sw == 1) {
+            if (np < A.pcap) rp[np] = make_float2(scx, scz);
+            np++;
+          }
+        }
         if (clipx) sinx1 = dz_sinf(x1);   // the next step starts from the clipped point
         float c2psi = 0.0f, s2psi = 0.0f;
         if (AZIM) step_azimuth(x0, z0, x1, z1, c2psi, s2psi);
@@ -500,9 +519,11 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         sinx0 = sinx1;
       }
       flush();
+      if (keep_pts) A.npts[ray] = np <= A.pcap ? np : -1;
     }
     cbar();
     if (!EMIT && gl == 0) {
+      if (A.pts && status) A.npts[ray] = 0;
       A.status[ray] = status;
       A.rbflag[ray] = rb;
     }
@@ -735,6 +756,20 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (A.lcap > g.nvx * g.nvz) A.lcap = g.nvx * g.nvz;
   A.LK = A.lcap;   // cell lists handed from the count pass to the emit pass (longer ones are traced again)
   A.keep_small = ctx->opts.count("rays.keep_small") && ctx->opts["rays.keep_small"] ? 1 : 0;
+  A.pts = nullptr;
+  A.npts = nullptr;
+  A.pcap = 0;
+  if (ctx->opts.count("rays.keep_paths") && ctx->opts["rays.keep_paths"]) {
+    // a ray advances half a cell per step: a few times (nnx + nnz) points even for a path that wanders; longer ones are flagged
+    A.pcap = 4 * (g.nnx + g.nnz) + 16;
+    if ((rc = dz_scratch(ctx, "rays.pts", nr1 * (size_t)A.pcap * sizeof(float2), &p))) return rc;
+    A.pts = (float2 *)p;
+    if ((rc = dz_scratch(ctx, "rays.npts", nr1 * 4, &p))) return rc;
+    A.npts = (int *)p;
+    DZ_HIP(hipMemsetAsync(A.npts, 0, nr1 * 4, ctx->stream));
+  }
+  ctx->ksec["rays.path_cap"] = A.pcap;
+  ctx->ksec["rays.path_rays"] = A.pts ? (double)nray : 0.0;
   const bool twin = ctx->opts.count("rays.dense_twin") && ctx->opts["rays.dense_twin"] && !A.keep_small;
   A.dense = twin ? 2 : 0;
   A.countd = nullptr;
@@ -934,4 +969,29 @@ extern "C" int dazim_rays_build_G_joint(dazim_ctx *ctx, int nx, int ny, int nz, 
   if (!lsen) return dz_fail(ctx, DAZIM_E_BAD_ARG, "joint mode needs Lsen_Gsc");
   return rays_build_impl(ctx, nx, ny, nz, goxd, gozd, dvxd, dvzd, kmax, vels, nfield, scx, scz, period, kidx, veln, ttn, ttnr,
                          nstsr, boxes, nray, field, rcx, rcz, svs, svp, srho, lsen, dsurf, G, nnz_out, n_boundary);
+}
+
+// The ray geometries of the last dazim_rays_build_G[_joint] call made with option "rays.keep_paths" = 1: what the reference
+// writes to raypath_refmdl_<T>s.dat when writepath is set (fwd/rpathsAzim.f90:617-625, fwd/FwdTraveltimeCPS.f90:673-691).
+// dims: *nray rays, *cap points per ray at most.  copy: xz[nray][cap][2] (colatitude, longitude in rad) and nrp[nray]
+// (number of points, receiver first, source last; -1: more than cap points) into host or device arrays.
+extern "C" int dazim_ray_paths_dims(dazim_ctx *ctx, int64_t *nray, int *cap) {
+  if (!ctx || !nray || !cap) return DAZIM_E_BAD_ARG;
+  *nray = (int64_t)dazim_last_kernel_seconds(ctx, "rays.path_rays");
+  *cap = (int)dazim_last_kernel_seconds(ctx, "rays.path_cap");
+  if (*nray < 0) *nray = 0;
+  if (*cap < 0) *cap = 0;
+  return 0;
+}
+extern "C" int dazim_ray_paths_copy(dazim_ctx *ctx, float *xz, int *nrp) {
+  int64_t nray;
+  int cap;
+  if (!ctx || !xz || !nrp || dazim_ray_paths_dims(ctx, &nray, &cap)) return DAZIM_E_BAD_ARG;
+  if (nray == 0 || cap == 0) return dz_fail(ctx, DAZIM_E_BAD_ARG, "no ray paths were kept (option rays.keep_paths)");
+  auto a = ctx->scratch.find("rays.pts"), b = ctx->scratch.find("rays.npts");
+  if (a == ctx->scratch.end() || b == ctx->scratch.end()) return dz_fail(ctx, DAZIM_E_BAD_ARG, "no ray paths were kept");
+  DZ_HIP(hipMemcpyAsync(xz, a->second.first, (size_t)nray * cap * 8, hipMemcpyDefault, ctx->stream));
+  DZ_HIP(hipMemcpyAsync(nrp, b->second.first, (size_t)nray * 4, hipMemcpyDefault, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
 }

@@ -25,7 +25,7 @@ module dazim_mod
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
-            dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin
+            dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin, dazim_ray_paths_dims, dazim_ray_paths_copy
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
   ! the matrix of the last aprod call (see aprod) and how often it had to be (re)built
@@ -146,6 +146,19 @@ module dazim_mod
       import
       type(c_ptr), value :: A
       integer(c_int64_t) :: m, n, nnz
+    end function
+    ! ray geometries kept by the last assembly made with option rays.keep_paths (include/dazim.h)
+    integer(c_int) function dazim_ray_paths_dims(ctx, nray, cap) bind(C, name="dazim_ray_paths_dims")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int64_t) :: nray
+      integer(c_int) :: cap
+    end function
+    integer(c_int) function dazim_ray_paths_copy(ctx, xz, nrp) bind(C, name="dazim_ray_paths_copy")
+      import
+      type(c_ptr), value :: ctx
+      real(c_float) :: xz(*)
+      integer(c_int) :: nrp(*)
     end function
     ! the reference's dense copies GVs | GGc | GGs of a matrix built with option rays.dense_twin (include/dazim.h)
     integer(c_int) function dazim_csr_take_twin(ctx, A, twin) bind(C, name="dazim_csr_take_twin")

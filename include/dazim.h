@@ -168,6 +168,13 @@ int dazim_csr_append_coo(dazim_ctx *ctx, dazim_csr *A, int64_t extra_m, int64_t 
                          const int *icol, const float *rw);
 /* the matrix back as the reference's triplets (1-based, rows ascending); any pointer may be NULL  */
 int dazim_csr_to_coo(dazim_ctx *ctx, const dazim_csr *A, int *irow, int *icol, float *rw);
+/* Ray geometries (the reference's raypath_refmdl_<T>s.dat, written when `writepath` is set: fwd/rpathsAzim.f90:617-625,
+ * fwd/FwdTraveltimeCPS.f90:673-691).  With option "rays.keep_paths" = 1 dazim_rays_build_G[_joint] keeps the points rgx/rgz(1:nrp)
+ * of every ray -- receiver first, one point per half-cell step (after the clipping to the grid), source last -- on the device.
+ * dazim_ray_paths_dims: rays and the capacity in points per ray of the last such call; dazim_ray_paths_copy: xz[nray][cap][2]
+ * (colatitude, longitude in rad) and nrp[nray] (points of each ray; -1 if it needed more than cap) into host or device arrays. */
+int dazim_ray_paths_dims(dazim_ctx *ctx, int64_t *nray, int *cap);
+int dazim_ray_paths_copy(dazim_ctx *ctx, float *xz, int *nrp);
 /* The reference keeps every ray row twice: the triplets rw/iw/col with |row| > ftol, which LSMR sees (inv/CalSurfG.f90:1358), and
  * the dense GVs (GGc, GGs) its residual diagnostics multiply with (inv/CalSigamNorm.f90:73): every entry of the cells with
  * |fdm| >= ftol, the dVs block formed with the Brocher derivatives coe_a / coe_rho left over from the LAST such cell of the ray

@@ -90,6 +90,10 @@ int orc_rpaths(const orc_geom *g, const orc_refbox *box, const float *veln, cons
 int orc_rpaths_azim(const orc_geom *g, const orc_refbox *box, const float *veln, const float *ttn,
                     const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
                     float *fdm, float *fdmc, float *fdms, int *rb);
+/* ray geometry rgx/rgz(1:nrp) of one ray (receiver first, source last), fwd/rpathsAzim.f90:221-380 = inv/CalSurfG.f90:1818-2066:
+ * pxz[pcap][2] colatitude, longitude (rad); *npts = nrp */
+int orc_ray_path(const orc_geom *g, const orc_refbox *box, const float *veln, const float *ttn, const float *ttnr,
+                 const int *nstsr, float scx, float scz, float rcx, float rcz, float *pxz, int pcap, int *npts);
 /* inv/CalSurfG.f90:1339-1364: G row of one ray from fdm and sen_*[nz][kmax][nx*ny]; kidx 0-based kernel slot; entries from
  * index 0 of rw/irow/icol (1-based ids); returns their number or -1 (more than maxnar) */
 long orc_emit_row(int nx, int ny, int nz, const float *vels, const float *fdm, const double *svs, const double *svp,

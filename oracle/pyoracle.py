@@ -138,6 +138,15 @@ class Oracle:
                                  C.c_float(scx), C.c_float(scz), C.c_float(rcx), C.c_float(rcz), pf(fdm), C.byref(rb))
         return rc, fdm, rb.value
 
+    def ray_path(self, g, box, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, cap=4096):
+        """points of one ray, receiver first, source last: [nrp][2] (colatitude, longitude in rad)"""
+        pts = np.zeros((cap, 2), f32)
+        n = C.c_int(0)
+        rc = self.lib.orc_ray_path(C.byref(g), C.byref(box), pf(veln), pf(ttn), pf(ttnr), pi(nstsr), C.c_float(scx), C.c_float(scz),
+                                   C.c_float(rcx), C.c_float(rcz), pf(pts), cap, C.byref(n))
+        assert rc == 0 and n.value <= cap
+        return pts[:n.value].copy()
+
     def rpaths_azim(self, g, box, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz):
         f = [np.zeros((g.nvx + 2, g.nvz + 2), f32) for _ in range(3)]
         rb = C.c_int(0)

@@ -130,8 +130,10 @@ static float azdist_az(float stalat, float stalon, float evtlat, float evtlon) {
  * rpathsAzim (inv/rpathsAzim.f90:16-684): the same ray plus cos/sin(2 psi)-weighted grids */
 static int rpaths_impl(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
                        const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
-                       float *fdm, float *fdmc, float *fdms, int *rb) {
+                       float *fdm, float *fdmc, float *fdms, int *rb, float *pxz, int pcap, int *npts) {
   int nnx = g->nnx, nnz = g->nnz, nvz = g->nvz, nvx = g->nvx;
+  int np = 0; /* ray points rgx/rgz(1:nrp), fwd/rpathsAzim.f90:221-380 (pxz nullable) */
+#define PUSH_PT(X, Z) do { if (pxz && np < pcap) { pxz[2 * np] = (X); pxz[2 * np + 1] = (Z); } np++; } while (0)
   float gox = g->gox, goz = g->goz, dnx = g->dnx, dnz = g->dnz, dvx = g->dvx, dvz = g->dvz;
   float goxr = b->goxr, gozr = b->gozr, dnxr = b->dnxr, dnzr = b->dnzr;
   int nnxr = b->nnxr, nnzr = b->nnzr;
@@ -164,6 +166,8 @@ static int rpaths_impl(const orc_geom *g, const orc_refbox *b, const float *veln
     if (SR(ipzr, ipxr + 1) != 0 || SR(ipzr + 1, ipxr + 1) != 0) igref = 0;
   }
   if (sw == 0 && igref == 1 && ipxr == isx && ipzr == isz) sw = 1;
+  PUSH_PT(rcx, rcz);                 /* rgx(1) = the receiver */
+  if (sw == 1) PUSH_PT(scx, scz);    /* nrp = 2 */
   long maxrp = (long)nnx * nnz;
   for (long j = 1; j <= maxrp; j++) {
     if (sw == 1) break;
@@ -208,6 +212,8 @@ static int rpaths_impl(const orc_geom *g, const orc_refbox *b, const float *veln
     if (ipx >= nnx) { x1 = gox + (float)(nnx - 1) * dnx; ipx = nnx - 1; *rb = 1; }
     if (ipz < 1) { z1 = goz; ipz = 1; *rb = 1; }
     if (ipz >= nnz) { z1 = goz + (float)(nnz - 1) * dnz; ipz = nnz - 1; *rb = 1; }
+    PUSH_PT(x1, z1);                   /* rgx(j+1), after the clipping */
+    if (sw == 1) PUSH_PT(scx, scz);    /* rgx(j+2) = the source, nrp = j+2 */
     float c2psi = 0.0f, s2psi = 0.0f;
     if (fdmc) { /* inv/rpathsAzim.f90:415-423 */
       const float rgx1 = (PI_F / 2 - x0) * 180.0f / PI_F, rgz1 = z0 * 180.0f / PI_F;
@@ -295,18 +301,32 @@ static int rpaths_impl(const orc_geom *g, const orc_refbox *b, const float *veln
     x0 = x1;
     z0 = z1;
   }
+  if (npts) *npts = np;
   return 0;
+#undef PUSH_PT
+}
+
+/* the ray geometry alone (what the reference writes to raypath_refmdl_<T>s.dat, fwd/rpathsAzim.f90:617-625): pxz[pcap][2]
+ * (colatitude, longitude in rad), *npts = nrp (may exceed pcap: then only the first pcap points were stored) */
+int orc_ray_path(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn, const float *ttnr,
+                 const int *nstsr, float scx, float scz, float rcx, float rcz, float *pxz, int pcap, int *npts) {
+  float *fdm = (float *)malloc(sizeof(float) * (size_t)(g->nvz + 2) * (g->nvx + 2));
+  int rb = 0;
+  *npts = 0;
+  int rc = rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, NULL, NULL, &rb, pxz, pcap, npts);
+  free(fdm);
+  return rc;
 }
 
 int orc_rpaths(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
                const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
                float *fdm, int *rb) {
-  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, NULL, NULL, rb);
+  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, NULL, NULL, rb, NULL, 0, NULL);
 }
 int orc_rpaths_azim(const orc_geom *g, const orc_refbox *b, const float *veln, const float *ttn,
                     const float *ttnr, const int *nstsr, float scx, float scz, float rcx, float rcz,
                     float *fdm, float *fdmc, float *fdms, int *rb) {
-  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, fdmc, fdms, rb);
+  return rpaths_impl(g, b, veln, ttn, ttnr, nstsr, scx, scz, rcx, rcz, fdm, fdmc, fdms, rb, NULL, 0, NULL);
 }
 
 /* G-row of one ray: inv/CalSurfG.f90:1339-1364.  sen_*[nz][kmax][nx*ny]; kidx 0-based period.
@@ -446,7 +466,7 @@ static int calsurfg_impl(int nx, int ny, int nz, const float *vels, float goxd, 
         if ((rc = orc_srtimes(&g, veln, ttn, x, z, rx, rz, &t))) break;
         count1++;
         dsurf[count1 - 1] = t;
-        if ((rc = rpaths_impl(&g, &box, veln, ttn, ttnr, nstsr, x, z, rx, rz, fdm, fdmc, fdms, &rb))) break;
+        if ((rc = rpaths_impl(&g, &box, veln, ttn, ttnr, nstsr, x, z, rx, rz, fdm, fdmc, fdms, &rb, NULL, 0, NULL))) break;
         long c = emit_row(nx, ny, nz, vels, fdm, fdmc, fdms, lsen, svs, svp, srho, kmax, knumi, count1, row, nar, maxnar, rw, irow, icol);
         if (c < 0) { rc = 4; break; }
         nar += c;

@@ -10,7 +10,7 @@ tests/test_reference_main_links.py applies.  No reference source enters the repo
                  the input files held by tests/golden/inversion_iso_small.npz and inversion_joint_small.npz;
   SurfAAForward  (fwd/MainForward.f90 + the files of fwd/Makefile) on the inputs of tests/golden/forward_test1.npz.
 
-Every file a program writes is stored as text, keyed by its name, in tests/golden/program_{iso,joint,forward}.npz together with
+Every file a program writes is stored as text, keyed by its name, in tests/golden/program_{iso,joint,forward,forward_paths}.npz together with
 the program's stdout.  tests/test_program_files_gpu.py runs host/DAzimSurfTomo_amd / host/SurfAAForward_amd on the same inputs and
 compares file by file: identical line structure (lines, fields per line, field widths) and values at the printed precision.
 
@@ -127,6 +127,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, "program_forward.npz"), **{"in:" + k: v for k, v in inputs.items()},
                             **{"out:" + k: v for k, v in out.items()})
         print("forward", {k: len(v.splitlines()) for k, v in out.items()})
+        # the same run with `writepath` set: the ray-path dump files raypath_refmdl_<T>s.dat (fwd/FwdTraveltimeCPS.f90:673-691)
+        pl = para.splitlines()
+        i_w = next(i for i, ln in enumerate(pl) if "Output raypaths" in ln)
+        pl[i_w] = "T" + pl[i_w][1:]
+        inputs["para.in"] = "\n".join(pl) + "\n"
+        out = run_program(fwd_exe, inputs, os.path.join(tmp, "run_fwd_paths"))
+        np.savez_compressed(os.path.join(HERE, "program_forward_paths.npz"), **{"in:" + k: v for k, v in inputs.items()},
+                            **{"out:" + k: v for k, v in out.items()})
+        print("forward + paths", {k: len(v.splitlines()) for k, v in out.items()})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

@@ -42,7 +42,7 @@ def tokens(line):
     return [(m.group(0), m.end()) for m in re.finditer(r"\S+", line)]
 
 
-def compare_text(name, ref, got, bars, default_bar, structure_only_cols=(), line_bars=()):
+def compare_text(name, ref, got, bars, default_bar, structure_only_cols=(), line_bars=(), check_columns=True):
     """-> (problems, {column: max |diff|}).  bars: {column index: bar}; default_bar for numeric columns not listed;
     line_bars: ((label, bar), ...) -- a line of the reference that contains `label` uses that bar for all its numbers."""
     problems, worst = [], {}
@@ -54,7 +54,7 @@ def compare_text(name, ref, got, bars, default_bar, structure_only_cols=(), line
         if len(ta) != len(tb):
             problems.append(f"{name}:{i + 1}: {len(tb)} fields, reference {len(ta)}: {b!r} vs {a!r}")
             continue
-        if [e for _, e in ta] != [e for _, e in tb]:
+        if check_columns and [e for _, e in ta] != [e for _, e in tb]:
             problems.append(f"{name}:{i + 1}: field widths differ: {b!r} vs {a!r}")
             continue
         timing = bool(TIMING.search(a))
@@ -155,6 +155,8 @@ def check(tag, got, ref, spec, skip=()):
                     worst[kind[0] + str(c)] = max(worst.get(kind[0] + str(c), 0.0), d)
             if len(split_itervel(ref[name])) != len(split_itervel(got[name])):
                 p.append(f"{name}: {len(split_itervel(got[name]))} blocks, reference {len(split_itervel(ref[name]))}")
+        elif name.startswith("raypath_"):   # list-directed output (WRITE(40,*)): shortest decimal form, so widths follow the digits
+            p, worst = compare_text(name, ref[name], got[name], bars, dflt, so, check_columns=False)
         else:
             p, worst = compare_text(name, ref[name], got[name], bars, dflt, so, LINE_BARS if name in ("__stdout__", "para.in_inv.log") else ())
         problems += p[:12] + ([f"{name}: ... {len(p) - 12} more"] if len(p) > 12 else [])
@@ -259,8 +261,10 @@ def test_inversion_program_files_match_the_reference_program(tmp_path, tag):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(FWD_EXE), reason="no flang and no prebuilt host")
-def test_forward_program_files_match_the_reference_program(tmp_path):
-    ins, ref = load("forward")
+@pytest.mark.parametrize("tag", ["forward", "forward_paths"])
+def test_forward_program_files_match_the_reference_program(tmp_path, tag):
+    """forward_paths: the same run with `writepath` = T, which adds the ray-path dump files raypath_refmdl_<T>s.dat"""
+    ins, ref = load(tag)
     got = run(FWD_EXE, ins, tmp_path)
     spec = {
         "Gc_Gs_model.real": ({}, 0.0, ()),
@@ -273,4 +277,8 @@ def test_forward_program_files_match_the_reference_program(tmp_path):
         "para.in.log": ({}, lambda v: 2e-2 * abs(v) + 1e-2, ()),
         "__stdout__": ({}, lambda v: 2e-2 * abs(v) + 1e-2, ()),
     }
-    check("forward", got, ref, spec)
+    for name in ref:
+        if name.startswith("raypath_"):     # longitude, latitude in degrees (fp32: an ulp at 100 degrees is 7.6e-6)
+            spec[name] = ({}, 2e-5, ())
+    assert tag == "forward" or sum(n.startswith("raypath_") for n in ref) == 4
+    check(tag, got, ref, spec)

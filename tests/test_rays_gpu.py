@@ -341,3 +341,41 @@ def test_dense_twin_is_the_reference_dense_copy(ctx, orc, joint):
         assert np.array_equal(Dk[:, npar:], D[:, npar:])
     for M in (G0, G, Gd, Gk):
         M.free()
+
+
+def test_ray_path_points_match_the_oracle(ctx, orc):
+    """option rays.keep_paths: the points rgx/rgz(1:nrp) of every ray -- what the reference dumps to raypath_refmdl_<T>s.dat
+    when writepath is set (fwd/rpathsAzim.f90:617-625) -- against orc.ray_path: same number of points, receiver first, source
+    last, coordinates to 2e-7 rad (one ulp of a longitude near 1.8 rad; the device's sine is correctly rounded, libm's is not)"""
+    nx, ny, kmax, minthk = 17, 15, 2, 2.0
+    depz = np.asarray([0.0, 10.0, 35.0, 60.0], np.float32)
+    goxd, gozd, dv = 30.0, 100.0, 0.25
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 9, 5, seed=37)
+    t = np.array([8.0, 25.0])
+    pv, sen = orc.depthkernel(vel, depz, t, minthk)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    # one receiver right next to its source: the two-point path
+    rx[0], rz[0] = scx[ray_f[0]] + np.float32(1e-5), scz[ray_f[0]]
+    fields = ctx.fmm_batch(nx, ny, goxd, gozd, dv, dv, pv, scx, scz, per)
+    G0, tp0, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+    try:
+        ctx.set_option("rays.keep_paths", 1)
+        G, tp, _ = ctx.rays_build_G(nx, ny, goxd, gozd, dv, dv, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+        paths = ctx.ray_paths()
+    finally:
+        ctx.set_option("rays.keep_paths", 0)
+    assert all(np.array_equal(a, b) for a, b in zip(G0.to_coo(), G.to_coo())) and np.array_equal(tp0, tp)
+    assert len(paths) == len(rx) and len(paths[0]) == 2
+    g = orc.geometry(nx, ny, goxd, gozd, dv, dv)
+    worst = 0.0
+    for f in range(len(scx)):
+        k = int(per[f]) - 1
+        veln = orc.gridder(g, pv[k])
+        rc, ttn, ttnr, nstsr, velnr, box = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
+        for r in np.nonzero(ray_f == f)[0]:
+            po = orc.ray_path(g, box, veln, ttn, ttnr, nstsr, scx[f], scz[f], rx[r], rz[r])
+            assert paths[r].shape == po.shape, (r, paths[r].shape, po.shape)
+            assert np.array_equal(paths[r][0], [rx[r], rz[r]]) and np.array_equal(paths[r][-1], [scx[f], scz[f]])
+            worst = max(worst, float(np.abs(paths[r] - po).max()))
+    within("ray path points max |d| rad", worst, 2e-7)
+    G0.free(); G.free()
