@@ -293,9 +293,8 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
             ref_extra["port_over_reference"] = {
                 "depthkernel": ref_extra["port_depthkernel_columns_per_s_same_sample"] / ref_extra["reference_depthkernel_columns_per_s"],
                 "fmm": (1.0 / t_field) / ref_extra["reference_fmm_fields_per_s"],
-                "note": "flang -O2 build of the unmodified reference (oracle/_ref, 1 thread) vs gcc -O2 build of the C restatement; "
-                        "depthkernel: the Fortran build is slower than the C port (flang's fp64 transcendental calls and "
-                        "assumed-size array copies in surfdisp96), so the speed-up quoted against the PORT is the conservative one"}
+                "note": "gcc -O2 build of the C restatement over flang -O2 build of the unmodified reference (oracle/_ref), 1 thread "
+                        "each, same columns / fields; BASELINE.md section 3 asks for 1 +- 0.15"}
     except Exception as e:   # the reference build is optional equipment
         ref_extra["reference_note"] = f"oracle/_ref not usable here: {e}"
     try:
