@@ -467,6 +467,75 @@ struct Heap {
 
 // fouds2 for one quadrant: inv/CalSurfG.f90:586-723.  (tj,sj) = neighbour along x, (tj2,sj2) the
 // node behind it, (tk,..) along z; vj2/vk2 = second node inside the grid.
+//
+// Straight-line form (round 3).  The reference distinguishes eight cases by which of the two directions has an alive neighbour
+// and whether that direction is second order; the sixteen lanes of a group are in different cases at almost every pop, so a
+// branch per case costs the wavefront the sum of all eight bodies plus the exec-mask bookkeeping (~100 VALU + ~45 scalar
+// instructions of the 364 + 150 per wave-pop).  Here every lane evaluates ONE set of expressions whose operands are selected
+// per case -- each fp32 operation is the one the reference's case performs, in its order:
+//   two-sided (both directions alive), reference cases with u, v, em as below:
+//     a = v*v + k9*(u*u)            k9 = 1 (both second order / both first order: v*v + u*u), 9 (mixed: v*v + 9*(u*u))
+//     b = (kb*em)*(u*u)             kb = 2 (2*em*(u*u)), 6 (6*em*(u*u)), -2 (-2*(u*u)*em: x2 is exact, so the order of the two
+//                                   factors does not change the one rounding)
+//     c = (u*u)*(em*em - (s*s)*(v*v))
+//     both second order : u = 2 ri dnx, v = 2 risti dnz, em = ((4tj - tj2) - 4tk) + tk2, tref = 4tj - tj2, tdiv = 3
+//     j second, k first : u = risti dnz, v = 2 ri dnx,  em = (3tk - 4tj) + tj2,          tref = tk
+//     j first, k second : u = ri dnx,    v = 2 risti dnz, em = (3tj - 4tk) + tk2,        tref = tj
+//     both first order  : u = ri dnx,    v = risti dnz,  em = tk - tj,                   tref = tj
+//     (2*ri*dnx = 2*(ri*dnx) exactly: scaling by two commutes with rounding)
+//   one-sided: a = 1, b = 0 and
+//     second order: c = -(u*u)*(s*s) with u = 2 ri dnx (tref = 4tj - tj2) or 2 risti dnz (tref = 4tk - tk2), tdiv = 3
+//     first order : c = -(s*s)*(ri*ri)*(dnx*dnx), tref = tj, or -(s*s)*(risti*risti)*(dnz*dnz), tref = tk
+// then the common tail tdsh = (-b + sqrt(max(b*b - 4*a*c, 0))) / (2*a), (tref + tdsh) / tdiv.  Bit-identical fields
+// (tests/test_fmm_gpu.py against the oracle on every grid size; option-free, so the old form is kept below for reference only
+// under DZ_FMM_QUADRANT_BRANCHES).
+#ifndef DZ_FMM_QUADRANT_BRANCHES
+__device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, Node nj, Node nj2,
+                                               Node nk, Node nk2, bool vj2, bool vk2) {
+  const float ri = EARTH;
+  const bool aj = nj.s == 0, ak = nk.s == 0;
+  const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
+  const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
+  const float tj = nj.t, tj2 = nj2.t, tk = nk.t, tk2 = nk2.t;
+  const bool two = aj && ak, both2 = so2j && so2k, mixed = so2j != so2k, onlyj = aj && !ak;
+  const float U1 = ri * dnx, U2 = U1 + U1, V1 = risti * dnz, V2 = V1 + V1;
+  const float fourtj = 4.0f * tj, fourtk = 4.0f * tk;
+  const float X2 = fourtj - tj2, Z2 = fourtk - tk2;
+  const float ss = slown * slown;
+  // ---- two-sided ----
+  const float emA = (X2 - fourtk) + tk2;
+  const float emBD = (3.0f * (so2j ? tk : tj) - (so2j ? fourtj : fourtk)) + (so2j ? tj2 : tk2);
+  const float emE = tk - tj;
+  const float em = both2 ? emA : (mixed ? emBD : emE);
+  const float u = both2 ? U2 : (so2j ? V1 : U1);
+  const float v = both2 ? V2 : (so2j ? U2 : (so2k ? V2 : V1));
+  const float uu = u * u, vv = v * v;
+  const float a2 = vv + (mixed ? 9.0f : 1.0f) * uu;
+  const float b2 = ((both2 ? 2.0f : (mixed ? 6.0f : -2.0f)) * em) * uu;
+  const float c2 = uu * (em * em - ss * vv);
+  const float tref2 = both2 ? X2 : (so2j ? tk : tj);
+  // ---- one-sided ----
+  const bool so1 = onlyj ? so2j : so2k;
+  const float u1 = onlyj ? U2 : V2;
+  const float c1s = -(u1 * u1) * ss;
+  const float c1f = (-ss * (onlyj ? ri * ri : risti * risti)) * (onlyj ? dnx * dnx : dnz * dnz);
+  const float c1 = so1 ? c1s : c1f;
+  const float tref1 = onlyj ? (so2j ? X2 : tj) : (so2k ? Z2 : tk);
+  // ---- common tail ----
+  const float a = two ? a2 : 1.0f, b = two ? b2 : 0.0f, c = two ? c2 : c1;
+  const float tref = two ? tref2 : tref1;
+  const bool third = two ? both2 : so1;            // tdiv = 3 (else 1)
+  float rd1 = b * b - 4.0f * a * c;
+  if (rd1 < 0.0f) rd1 = 0.0f;
+  const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+  const float tsum = tref + tdsh;
+  // (tsum / 3 as convert - multiply by RN(1/3) in double - convert is exact too, tools/check_divr.c 3, but measured 0.5 % slower
+  // than the IEEE fp32 sequence in a same-box A/B: fp64 instructions issue at half rate here)
+  const float t3 = tsum / 3.0f;
+  const float t = third ? t3 : tsum;
+  return (aj || ak) ? t : INFINITY;
+}
+#else
 __device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, Node nj, Node nj2,
                                                Node nk, Node nk2, bool vj2, bool vk2) {
   const float ri = EARTH;
@@ -538,6 +607,8 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
   return (tref + tdsh) / tdiv;
 }
+
+#endif
 
 #ifdef DZ_FMM_PROF   // experiment-only build: per-phase shader-clock totals of the marching loop
 __device__ unsigned long long g_fmm_prof[8];
