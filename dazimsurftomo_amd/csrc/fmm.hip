@@ -790,6 +790,11 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       const bool room = H.ntr + cnt < TOT;
       const int pc = c >> 1;
       float pk = H.keys[(act && room) ? pc : 0];
+      // (for the one-level rise below: the grandparent's key and the parent's node, requested with the parent's key so that
+      // they cost no LDS round trip of their own)
+      const int gp = pc >> 1;
+      const float gk = H.keys[(act && room && gp >= 1) ? gp : 0];
+      const NT pn = H.nodes[(act && room) ? pc : 0];
       const int cact = act ? c : 0;
       const int c0 = dpp_i<DPP_BCAST0 + 0>(cact), c1 = dpp_i<DPP_BCAST0 + 4>(cact), c2 = dpp_i<DPP_BCAST0 + 8>(cact);
       const float t0 = dpp_f<DPP_BCAST0 + 0>(trav), t1 = dpp_f<DPP_BCAST0 + 4>(trav), t2 = dpp_f<DPP_BCAST0 + 8>(trav);
@@ -800,9 +805,42 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       const unsigned riseb = (unsigned)(__ballot(rise) >> gbase) & 0xffffu;
       // neighbours before the first rising one (n < n0) are written directly; from n0 on, sequentially
       n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) >> 2) : 4);
+      // One-level rise in place (round 3).  41 % of the wave-pops have a rising entry in some group, and in 92 % of those every
+      // such group has exactly ONE riser that stops after one level and whose move touches no slot another neighbour of the pop
+      // reads or writes (measured, DZ_FMM_PROF2): then the sequential addtree/updtree calls still reduce to independent
+      // writes -- the riser swaps with its parent, everybody else writes as above -- instead of up to four parallel rounds.
+      // Conditions, per group (r = the riser, at slot c_r with parent slot p_r and grandparent slot g_r):
+      //   * one riser, and its key is not smaller than the key at g_r (it stops at p_r);
+      //   * no other active neighbour m sits at p_r or g_r (c_m) or has p_r or c_r as its parent slot: their comparisons, made
+      //     against the array as it was, are then the ones the sequential order makes (neighbours before r see r's old
+      //     entry, neighbours after r see slots r did not touch), and r's own comparisons see no slot an earlier neighbour wrote;
+      //   * (hybrid heap) the riser's slot lies in the LDS part.
+      bool f2 = false;
+      if (__ballot(riseb != 0u && room) != 0) {            // wave-uniform: some group has a rising entry
+        const int c3 = dpp_i<DPP_BCAST0 + 12>(cact);
+        const int nbr = __builtin_ctz(riseb | 0x10000u) >> 2;
+        const int cr = nbr == 0 ? c0 : (nbr == 1 ? c1 : (nbr == 2 ? c2 : c3));
+        const int pr = cr >> 1, gr = cr >> 2;
+        const bool okr = rise && !(gp >= 1 && trav < gk) && (!HYB || c < CAP);
+        const bool clash = owner && act && !rise && (c == pr || c == gr || pc == cr || pc == pr);
+        const unsigned okb = (unsigned)(__ballot(okr) >> gbase) & 0xffffu;
+        const unsigned clb = (unsigned)(__ballot(clash) >> gbase) & 0xffffu;
+        f2 = room && riseb != 0u && (riseb & (riseb - 1u)) == 0u && okb == riseb && clb == 0u;
+        if (f2) n0 = 4;
+      }
       fast = n0 == 4;
+      if (__ballot(f2 && rise) != 0) {                     // the risers: entry to the parent's slot, parent down to the entry's
+        if (f2 && rise) {
+          H.keys[pc] = trav;
+          H.nodes[pc] = (NT)uself;
+          st_node(&rec[uself], Node{trav, pc});
+          H.keys[c] = pk;
+          H.nodes[c] = pn;
+          st_slot(&rec[(unsigned)pn], c);
+        }
+      }
       {
-        const bool wr = owner && act && nb < n0;
+        const bool wr = owner && act && nb < n0 && !(f2 && rise);
         const bool whi = HYB && wr && c >= CAP;            // (HYB) the entry's slot lies in the HBM level
         const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
@@ -818,6 +856,28 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     PROF(5);
     if (__ballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
     pa_[7] += 1000000;                        // iterations (x1e6) on top of the loop-top ticks
+#endif
+#ifdef DZ_FMM_PROF2   // experiment: how many slow-path pops consist of single one-level rises with untouched siblings?
+    if (!SPILL && __ballot(!fast)) {
+      const bool owner = q == 0;
+      const bool act = stfix != 0, isnew = stfix < 0;
+      const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
+      const int ntr0 = H.ntr - __popc(newb & ((1u << (4 * n0)) - 1u));            // (H.ntr was advanced for the neighbours < n0)
+      const int c = isnew ? ntr0 + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
+      const int pc = c >> 1, gp = pc >> 1;
+      const float pk = H.keys[act ? pc : 0], gk = H.keys[(act && gp >= 1) ? gp : 0];
+      const bool rise = owner && act && c > 1 && trav < pk;
+      const unsigned rb = (unsigned)(__ballot(rise) >> gbase) & 0xffffu;
+      const int rl = rb ? __builtin_ctz(rb) : 0;
+      const int cr = __shfl(c, gbase + rl), pr = __shfl(pc, gbase + rl);
+      const bool one = __popc(rb) == 1;
+      const bool stops = !(gp >= 1 && trav < gk);                         // the riser stops after one level
+      const bool clash = owner && act && gl != rl && (c == pr || pc == cr || pc == pr);
+      const unsigned cl = (unsigned)(__ballot(clash) >> gbase) & 0xffffu;
+      const bool stopr = __shfl((int)stops, gbase + rl) != 0;
+      const bool ok = rb == 0 || (one && stopr && cl == 0 && !fast);
+      if (__ballot(!ok) == 0) pa_[0] += 1000000;   // covered slow pops (x1e6 on the "setup+loads" slot)
+    }
 #endif
     if (!fast) {
       nbs[0] = dpp_i<DPP_BCAST0 + 0>(stfix); nbs[1] = dpp_i<DPP_BCAST0 + 4>(stfix);
