@@ -177,3 +177,73 @@ def test_ti_kernels_golden(orc):
     _, lsen = orc.depthkernel_ti(a["vel"], a["depz"], d["t"], 2.0)
     assert lsen.shape == d["lsen"].shape
     assert np.abs(lsen - d["lsen"]).max() <= 2e-7 * np.abs(d["lsen"]).max() + 1e-12
+
+
+def test_ray_paths_and_times_of_the_reference_forward_program(orc):
+    """The reference's SurfAAForward, run with `writepath` = T on the test1 forward fixture (tests/golden/
+    make_program_goldens.py), dumps every ray to raypath_refmdl_<T>s.dat (fwd/rpathsAzim.f90:617-625) and the isotropic
+    traveltimes to Synthetic_fwd.dat.  The oracle, fed the same input files, must retrace them: same number of points per
+    ray, coordinates to the printed precision (list-directed fp32, ~1e-5 degrees), T_iso to 2e-5 relative."""
+    from tests import synth
+    g = np.load(os.path.join(G, "program_forward_paths.npz"))
+    ins = {k[3:]: str(g[k]) for k in g.files if k.startswith("in:")}
+    outs = {k[4:]: str(g[k]) for k in g.files if k.startswith("out:")}
+    pl = [ln for ln in ins["para.in"].splitlines()]
+    nx, ny, nz = (int(v) for v in pl[4].split()[:3])
+    goxd, gozd = (float(v) for v in pl[5].split()[:2])
+    dvx, dvz = (float(v) for v in pl[6].split()[:2])
+    minthk = float(pl[8].split()[0])
+    kmax = int(pl[11].split()[0])
+    t = np.array([float(v) for v in pl[12].split()[:kmax]])
+    toks = ins["MODVs.true"].split()
+    depz = np.array(toks[:nz], np.float32)
+    vel = np.array(toks[nz:nz + nx * ny * nz], np.float32).reshape(nz, ny, nx)
+    pv, _ = orc.depthkernel(vel, depz, t, minthk, kernels=False)
+    geo = orc.geometry(nx, ny, goxd, gozd, dvx, dvz)
+    # the path file: '# lat lon period 2 0' then 'lat lon vel' lines, in file order = ray order
+    rays, src = [], None
+    for ln in ins[[k for k in ins if k.endswith(".dat")][0]].splitlines():
+        f = ln.split()
+        if not f:
+            continue
+        if f[0] == "#":
+            src = (np.float32(f[1]), np.float32(f[2]), int(f[3]))
+        else:
+            rays.append((src, np.float32(f[0]), np.float32(f[1])))
+    # the reference's files, per period
+    ref_paths = {}
+    for name, text in outs.items():
+        if name.startswith("raypath_refmdl_"):
+            cur = None
+            for ln in text.splitlines():
+                if ln.startswith(">"):
+                    cur = []
+                    ref_paths.setdefault(float(ln[1:]), []).append(cur)
+                else:
+                    cur.append([float(v) for v in ln.split()])
+    assert sum(len(v) for v in ref_paths.values()) == len(rays) == 96
+    syn = np.loadtxt(outs["Synthetic_fwd.dat"].splitlines()[1:])
+    PI = np.float32(3.1415926535898)
+    fields, count = {}, {}
+    worst, worst_t = 0.0, 0.0
+    for i, ((slat, slon, k), rlat, rlon) in enumerate(rays):
+        sx, sz = synth.radians(np.array([slat]), np.array([slon]))
+        rx, rz = synth.radians(np.array([rlat]), np.array([rlon]))
+        key = (float(slat), float(slon), k)
+        if key not in fields:
+            veln = orc.gridder(geo, pv[k - 1])
+            fields[key] = (veln,) + orc.fmm_field(geo, pv[k - 1], veln, sx[0], sz[0])
+        veln, rc, ttn, ttnr, nstsr, velnr, box = fields[key]
+        assert rc == 0
+        pts = orc.ray_path(geo, box, veln, ttn, ttnr, nstsr, sx[0], sz[0], rx[0], rz[0])
+        j = count.get(k, 0)
+        count[k] = j + 1
+        ref = np.array(ref_paths[float(t[k - 1])][j])             # [nrp][2]: longitude, latitude in degrees
+        assert len(pts) == len(ref), (i, len(pts), len(ref))
+        lat = ((PI / np.float32(2) - pts[:, 0]) * np.float32(180.0) / PI).astype(np.float64)
+        lon = (pts[:, 1] * np.float32(180.0) / PI).astype(np.float64)
+        worst = max(worst, np.abs(lon - ref[:, 0]).max(), np.abs(lat - ref[:, 1]).max())
+        rc, tt = orc.srtimes(geo, veln, ttn, sx[0], sz[0], rx[0], rz[0])
+        worst_t = max(worst_t, abs(tt - syn[i, 3]) / syn[i, 3])
+    assert worst <= 1e-5, worst          # printed with 8-9 significant digits: identical up to the print
+    assert worst_t <= 2e-7, worst_t      # f16.7 of a ~50 s time
