@@ -140,6 +140,25 @@ class Context:
         self._check(rc)
         return pv, (sen if kernels else None), nf.value
 
+    def surfdisp96(self, thk, vp, vs, rho, t, iflsph=1, iwave=2, mode=1, igr=0, nlayer=None):
+        """surfdisp96 (inv/surfdisp96.f:52) with the subroutine's own arguments, for one model (1-D arrays) or a batch
+        (thk, vp, vs, rho [nmodel][nlayer_max], `nlayer` [nmodel] if the models have different numbers of layers):
+        iwave 1 Love / 2 Rayleigh, mode 1 = fundamental, igr 0 phase / 1 group velocity, iflsph 0 flat / 1 spherical.
+        Returns (cg [nmodel][kmax] or [kmax], n_failed)."""
+        a = [np.ascontiguousarray(x, np.float32) for x in (thk, vp, vs, rho)]
+        single = a[0].ndim == 1
+        if single:
+            a = [x[None, :] for x in a]
+        nmodel, nlm = a[0].shape
+        nl = np.full(nmodel, nlm, np.int32) if nlayer is None else np.ascontiguousarray(nlayer, np.int32)
+        t = np.ascontiguousarray(t, np.float64)
+        cg = np.zeros((nmodel, len(t)), np.float64)
+        nf = C.c_int(0)
+        rc = self.lib.dazim_surfdisp96(self._h, nmodel, nlm, _ptr(nl), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]), _ptr(a[3]),
+                                       int(iflsph), int(iwave), int(mode), int(igr), len(t), _ptr(t), _ptr(cg), C.byref(nf))
+        self._check(rc)
+        return (cg[0] if single else cg), nf.value
+
     # ---- N1 --------------------------------------------------------------------------------
     def ti_kernels(self, vel, depz, tRc, minthk, pv, lsen=None):
         """depthkernelTI/tregn96 (inv/depthkernelTI.f90:2): vel[nz][ny][nx] and pvRc[kmax][nx*ny] (output of

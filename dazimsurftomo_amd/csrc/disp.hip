@@ -934,6 +934,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     const void *kf = rden == 1 ? (const void *)disp_kernel<1> : (rden == 2 ? (const void *)disp_kernel<2> : (const void *)disp_kernel<0>);
     int occ = 3;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, DT, dyn_lds) != hipSuccess || occ < 1) occ = 1;
+    // option disp.occ: at most that many workgroups per CU (room for a kernel of another stream on the same CUs)
+    if (ctx->opts.count("disp.occ") && ctx->opts["disp.occ"] >= 1 && ctx->opts["disp.occ"] < occ) occ = ctx->opts["disp.occ"];
     long nwg = (long)ctx->num_cu * occ;
     if (nwg > (long)ntask) nwg = (long)ntask;
     // first-period fast-forward (disp_bracket_kernel); off with option disp.ffwd = 0 and when the periods are handed from task to task

@@ -135,7 +135,9 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 
 // Cross-lane moves inside a 16-lane group as DPP modifiers on a v_mov (no LDS crossbar round trip):
 // quad_perm swaps for the xor-1 / xor-2 exchanges and row_newbcast (gfx90a+) to broadcast lane L of each row.
-template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+// (mov_dpp = update_dpp with an undefined `old`: every lane is written by these controls, so the destination needs no
+// initialising v_mov -- one instruction per move instead of two)
+template <int CTRL> __device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
 template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
 constexpr int DPP_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]

@@ -21,7 +21,7 @@ module dazim_mod
   use iso_c_binding
   implicit none
   private
-  public :: dazim_init, dazim_finalize, depthkernel, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense, dazim_aprod_forget
+  public :: dazim_init, dazim_finalize, depthkernel, surfdisp96, dazim_surfdisp96, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense, dazim_aprod_forget
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
@@ -68,6 +68,15 @@ module dazim_mod
       real(c_float) :: vel(*), depz(*)
       real(c_double) :: periods(*), pv(*)
       integer(c_int) :: nfail
+    end function
+    integer(c_int) function dazim_surfdisp96(ctx, nmodel, nlayer_max, nlayer, thk, vp, vs, rho, iflsph, iwave, mode, igr, &
+        kmax, periods, cg, nfail) bind(C, name="dazim_surfdisp96")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nmodel, nlayer_max, iflsph, iwave, mode, igr, kmax
+      integer(c_int) :: nlayer(*), nfail
+      real(c_float) :: thk(*), vp(*), vs(*), rho(*)
+      real(c_double) :: periods(*), cg(*)
     end function
     integer(c_int) function dazim_set_option(ctx, name, value) bind(C, name="dazim_set_option")
       import; type(c_ptr), value :: ctx; character(kind=c_char) :: name(*); integer(c_int), value :: value
@@ -283,6 +292,19 @@ contains
     end do
     write (6, *) what, ': ', msg(1:i - 1)
     stop
+  end subroutine
+
+  ! ---- inv/surfdisp96.f:52, the subroutine's own argument list (one model per call; dazim_surfdisp96 takes batches) ----
+  subroutine surfdisp96(thkm, vpm, vsm, rhom, nlayer, iflsph, iwave, mode, igr, kmax, t, cg)
+    integer :: nlayer, iflsph, iwave, mode, igr, kmax
+    real*4 :: thkm(nlayer), vpm(nlayer), vsm(nlayer), rhom(nlayer)
+    real*8 :: t(kmax), cg(kmax)
+    integer(c_int) :: nl(1), nfail
+    call dazim_init(0)
+    nl(1) = nlayer
+    call check(dazim_surfdisp96(dazim_handle, 1, nlayer, nl, thkm, vpm, vsm, rhom, iflsph, iwave, mode, igr, kmax, t, cg, &
+                                nfail), 'surfdisp96')
+    if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found'   ! inv/surfdisp96.f:311
   end subroutine
 
   ! ---- inv/CalSurfG.f90:1 ------------------------------------------------------------------------

@@ -94,6 +94,21 @@ program host_example
     write (11, *) aprod_builds
     write (11, '(5es16.8)') yy
   end block
+  ! surfdisp96 with the subroutine's own arguments: Love-wave group velocities of the first higher mode, Rayleigh phase
+  ! velocities of the fundamental mode, for a four-layer crust on a flat and on a spherical earth
+  block
+    real*4 :: thk(5), vp5(5), vs5(5), rho5(5)
+    real*8 :: tt(6), cgl(6), cgr(6)
+    thk = (/4.0, 8.0, 10.0, 14.0, 0.0/)
+    vs5 = (/2.6, 3.2, 3.6, 3.9, 4.5/)
+    vp5 = 1.73*vs5
+    rho5 = 0.32*vp5 + 0.77
+    tt = (/3.d0, 5.d0, 8.d0, 12.d0, 20.d0, 30.d0/)
+    call surfdisp96(thk, vp5, vs5, rho5, 5, 0, 1, 2, 1, 6, tt, cgl)
+    call surfdisp96(thk, vp5, vs5, rho5, 5, 1, 2, 1, 0, 6, tt, cgr)
+    write (11, '(6es24.16)') cgl
+    write (11, '(6es24.16)') cgr
+  end block
   close (11)
   call dazim_finalize()
 end program

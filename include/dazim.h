@@ -110,6 +110,21 @@ int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float
                              double *pvRc, double *sen_vs, double *sen_vp, double *sen_rho,
                              int *n_failed);
 
+/* ---- surfdisp96 itself, every argument -------------------------------------------------------------
+ * = surfdisp96(thkm,vpm,vsm,rhom,nlayer,iflsph,iwave,mode,igr,kmax,t,cg) (inv/surfdisp96.f:52-354) for a batch of
+ *   layered models: iflsph 0 flat / 1 spherical (sphere, :480); iwave 1 Love (dltar1, :704) / 2 Rayleigh (dltar4,
+ *   :767, with the water-layer branch :844 when vs of the first layer is <= 0); mode 1 = fundamental, 2 = first
+ *   higher, ... (:217); igr 0 phase velocity / > 0 group velocity from the roots at T/(1+h), T/(1-h), h = 0.005
+ *   (:226-233, :276-304).  dazim_dispersion_kernels above is the tuned form of the one combination the reference's
+ *   programs call (1, 2, 1, 0); this entry is the subroutine as it stands, one lane per model.
+ *  nlayer [nmodel] layers of each model (<= nlayer_max <= 200 = NL); thk, vp, vs, rho [nmodel][nlayer_max] fp32
+ *  (thickness of the last layer = half-space, ignored); periods [kmax <= 60 = NP] fp64 (host)
+ *  cg [nmodel][kmax] fp64 holding fp32-rounded values, 0 from the first period without a root on (:342-348)
+ *  n_failed  number of (model, period) entries left at 0, nullable                                        */
+int dazim_surfdisp96(dazim_ctx *ctx, int nmodel, int nlayer_max, const int *nlayer, const float *thk, const float *vp,
+                     const float *vs, const float *rho, int iflsph, int iwave, int mode, int igr, int kmax,
+                     const double *periods, double *cg, int *n_failed);
+
 /* ---- N1: TI eigenfunction partials -> azimuthal depth kernels ---------------------------------------
  * = depthkernelTI (inv/depthkernelTI.f90:2) calling tregn96 (inv/tregn96.f:52) once per column: Rayleigh fundamental-mode
  *   eigenfunctions of the flattened TI column (A=C=rho*Vp^2, L=N=rho*Vs^2, F=A-2L), partials dc/dah, dc/dbv, dc/dn with the

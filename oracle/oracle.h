@@ -32,6 +32,9 @@ extern "C" {
 /* inv/surfdisp96.f:52 with iflsph=1, iwave=2, mode=1, igr=0. returns #periods with a root. */
 int orc_surfdisp96(const float *thk, const float *vp, const float *vs, const float *rho,
                    int nlayer, int kmax, const double *t, double *cg);
+/* inv/surfdisp96.f:52 with every argument: iflsph 0/1, iwave 1 (Love) / 2 (Rayleigh), mode >= 1, igr 0 / >0 (surfdisp_full.c) */
+int orc_surfdisp96_full(const float *thk, const float *vp, const float *vs, const float *rho, int nlayer, int iflsph,
+                        int iwave, int mode, int igr, int kmax, const double *t, double *cg);
 /* inv/CalSurfG.f90:2317 */
 int orc_refine_layers(float minthk0, int mmax, const float *dep, const float *vp, const float *vs,
                       const float *rho, float *rthk, float *rvp, float *rvs, float *rrho);

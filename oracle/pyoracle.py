@@ -73,6 +73,14 @@ class Oracle:
         self.lib.orc_surfdisp96(pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]), len(a[0]), len(t), pd(t), pd(cg))
         return cg
 
+    def surfdisp96_full(self, thk, vp, vs, rho, t, iflsph=1, iwave=2, mode=1, igr=0):
+        t = np.ascontiguousarray(t, f64)
+        cg = np.zeros(len(t), f64)
+        a = [np.ascontiguousarray(x, f32) for x in (thk, vp, vs, rho)]
+        self.lib.orc_surfdisp96_full(pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]), len(a[0]), int(iflsph), int(iwave), int(mode), int(igr), len(t),
+                                     pd(t), pd(cg))
+        return cg
+
     def depthkernel(self, vel, depz, t, minthk, kernels=True):
         """vel[nz][ny][nx] fp32 -> pv[kmax][nx*ny], (svs, svp, srho)[nz][kmax][nx*ny]"""
         vel = np.ascontiguousarray(vel, f32)
@@ -267,6 +275,14 @@ class Ref:
         cg = np.zeros(len(t), f64)
         a = [np.ascontiguousarray(x, f32) for x in (thk, vp, vs, rho)]
         self.lib.ref_surfdisp96(pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]), len(a[0]), len(t), pd(t), pd(cg))
+        return cg
+
+    def surfdisp96_full(self, thk, vp, vs, rho, t, iflsph=1, iwave=2, mode=1, igr=0):
+        t = np.ascontiguousarray(t, f64)
+        cg = np.zeros(len(t), f64)
+        a = [np.ascontiguousarray(x, f32) for x in (thk, vp, vs, rho)]
+        self.lib.ref_surfdisp96_full(pf(a[0]), pf(a[1]), pf(a[2]), pf(a[3]), len(a[0]), int(iflsph), int(iwave), int(mode), int(igr), len(t),
+                                     pd(t), pd(cg))
         return cg
 
     def depthkernel(self, vel, depz, t, minthk):

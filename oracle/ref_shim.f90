@@ -29,6 +29,23 @@ contains
     cg(1:kmax) = cc(1:kmax)
   end subroutine
 
+  ! ---- surfdisp96 with all of its arguments (Love / Rayleigh, higher modes, group velocity, flat / spherical) ----
+  subroutine ref_surfdisp96_full(thk, vp, vs, rho, nlayer, iflsph, iwave, mode, igr, kmax, t, cg) &
+       bind(C, name="ref_surfdisp96_full")
+    integer(c_int), value :: nlayer, iflsph, iwave, mode, igr, kmax
+    real(c_float), intent(in) :: thk(*), vp(*), vs(*), rho(*)
+    real(c_double), intent(in) :: t(*)
+    real(c_double), intent(out) :: cg(*)
+    real(4) :: a(200), b(200), c(200), d(200)
+    real(8) :: tt(60), cc(60)
+    a = 0; b = 0; c = 0; d = 0; tt = 0; cc = 0
+    a(1:nlayer) = thk(1:nlayer); b(1:nlayer) = vp(1:nlayer)
+    c(1:nlayer) = vs(1:nlayer);  d(1:nlayer) = rho(1:nlayer)
+    tt(1:kmax) = t(1:kmax)
+    call surfdisp96(a, b, c, d, nlayer, iflsph, iwave, mode, igr, kmax, tt, cc)
+    cg(1:kmax) = cc(1:kmax)
+  end subroutine
+
   ! ---- depthkernel (inv/CalSurfG.f90:1) -------------------------------------------------------
   subroutine ref_depthkernel(nx, ny, nz, vel, kmax, tRc, depz, minthk, pvRc, svs, svp, srho) &
        bind(C, name="ref_depthkernel")

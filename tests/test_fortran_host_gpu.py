@@ -60,6 +60,16 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     builds2 = int(toks[p]); p += 1
     ya2 = np.array(toks[p:p + dall], np.float32); p += dall
     assert builds1 == 1 and builds2 == 2
+    # surfdisp96 through the Fortran mirror of the reference's argument list (Love group velocity, mode 2, flat; Rayleigh phase)
+    cgl = np.array(toks[p:p + 6], np.float64); p += 6
+    cgr = np.array(toks[p:p + 6], np.float64); p += 6
+    vs5 = np.array([2.6, 3.2, 3.6, 3.9, 4.5], np.float32)
+    vp5 = np.float32(1.73) * vs5
+    m5 = (np.array([4.0, 8.0, 10.0, 14.0, 0.0], np.float32), vp5, vs5, np.float32(0.32) * vp5 + np.float32(0.77))
+    t6 = np.array([3.0, 5.0, 8.0, 12.0, 20.0, 30.0])
+    want_l, want_r = orc.surfdisp96_full(*m5, t6, 0, 1, 2, 1), orc.surfdisp96_full(*m5, t6, 1, 2, 1, 0)
+    assert np.array_equal(cgl == 0, want_l == 0) and (want_l != 0).any() and np.abs(cgl - want_l).max() <= 2e-4
+    assert np.abs(cgr - want_r).max() <= 4.8e-7 and (want_r != 0).all()
     rc, rw_o, ir_o, ic_o, ds_o, nb = orc.calsurfg(vel, depz, goxd, gozd, dv, dv, t, minthk, scxf, sczf, rcxf, rczf,
                                                   nrc1, nsrc1, periods, 2_000_000)
     assert rc == 0 and dall == len(ds_o)
