@@ -204,7 +204,10 @@ __global__ void k_ray_keys(long nray, const int *__restrict__ field, const float
 
 // lanes per ray: 8 in the count pass, which traces every ray (measured: 16 lanes 94 ms, 8 lanes 73 ms, 4 lanes 84 ms on the S-256
 // batch); 16 in the emit pass, which only walks the saved cell lists (lane-parallel work: 8.2 ms with 16 lanes, 12.5 with 8)
-constexpr int GP_COUNT = 8, GP_EMIT = 16;
+#ifndef DZ_GP_COUNT
+#define DZ_GP_COUNT 8   // (experiment switch, tools/exp_rays_ab.sh: 4 and 16 lanes per ray are both 17 % slower at S-256)
+#endif
+constexpr int GP_COUNT = DZ_GP_COUNT, GP_EMIT = 16;
 constexpr int RPW_MAX = 64 / GP_COUNT;   // rays per wavefront (most of the two passes: sizes the scratch slots)
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier (same-wave ops are in order)
 
