@@ -628,8 +628,12 @@ contains
     localVecs = min(localSize, m, n)
     write (nout, 1000) enter, m, n, damp, atol, conlim, btol, itnlim, localVecs
     normb = tr(1)%normr
-    if (tr(1)%normAr == 0.0) then            ! b = 0 or A'b = 0 (:455-460)
-      write (nout, '(a)') msg(1)
+    ! b = 0 or A'b = 0: the reference leaves for its exit block before the table (go to 800, :399-400; its second test at
+    ! :451-457 is never reached) and prints it -- there with istop, itn and the norms still unset; here with the values the
+    ! solver returned (istop = 0: "The exact solution is  x = 0")
+    if (tr(1)%normAr == 0.0) then
+      write (nout, 2000) exitt, istop, itn, exitt, normA, condA, exitt, normb, normx, exitt, normr, normAr
+      write (nout, 3000) exitt, msg(istop)
       return
     end if
     if (damped) then

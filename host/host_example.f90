@@ -64,6 +64,17 @@ program host_example
   call LSMR(m, n, 2*nar + 1, nar, iw, rw, b, damp, atol, btol, conlim, itnlim, localSize, 36, &
             x, istop, itn, normA, condA, normr, normAr, normx)
   close (36)
+  block   ! b = 0: the reference leaves for its exit block at once (inv/lsmrModule.f90:399-400) -- <out>.lsmr0
+    real, allocatable :: b0(:), x0(:)
+    integer :: istop0, itn0
+    real :: nA0, cA0, nr0, nAr0, nx0
+    allocate (b0(m), x0(n))
+    b0 = 0.0
+    open (37, file=trim(fout)//'.lsmr0')
+    call LSMR(m, n, 2*nar + 1, nar, iw, rw, b0, damp, atol, btol, conlim, itnlim, localSize, 37, &
+              x0, istop0, itn0, nA0, cA0, nr0, nAr0, nx0)
+    close (37)
+  end block
   allocate (gx(dall))
   gx = matmul(GVs, x)                                            ! like CalVsReslNorm, inv/CalSigamNorm.f90:73
   open (11, file=fout)

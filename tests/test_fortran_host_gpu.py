@@ -120,3 +120,8 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     assert its == sorted(set(its)) and all(i in its for i in range(0, min(itn, 10) + 1))   # the first ten are always printed
     assert abs(float(rows[-1][2]) - normr) <= 1e-6 * normr                                 # norm rbar of the last line
     assert "Exit  LSMR.       istop  =%2d               itn    =%8d" % (istop, itn) in log
+    # b = 0: header, then the exit block at once (the reference's `go to 800`), no iteration table
+    log0 = open(str(fout) + ".lsmr0").read()
+    assert "Enter LSMR." in log0 and "Itn       x(1)" not in log0
+    assert "Exit  LSMR.       istop  = 0               itn    =       0" in log0
+    assert "Exit  LSMR.       The exact solution is  x = 0" in log0
