@@ -687,6 +687,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
         if (H.g0) rec[iroot].s = 0;
+        if (!SPILL)   // lazy back-pointers (below): the records of entries that only moved up are behind; nstsr wants them exact
+          for (int i = 2 + gl; i <= H.ntr; i += GP) rec[(unsigned)H.get(i).node].s = i;
         break;
       }
     }
@@ -750,9 +752,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     if (SPILL) {
       if (gl < nmoves) rec[mynode].s = myslot;   // deferred back-pointers of the sift-down
     } else {
-#pragma unroll
-      for (int b = 0; b < NCAP; b++)
-        if (cslot[b] > 0) st_slot(&rec[(unsigned)cnode[b]], cslot[b]);
+      // (the entries the sift-down moved UP get no store: lazy back-pointers, see below; the dropped entry moved down)
       if (H.g0 && fin_slot > 0) st_slot(&rec[(unsigned)fin_node], fin_slot);
     }
     if (!nvalid) nself.s = 0;
@@ -780,10 +780,35 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // Did the sift-down move this neighbour's heap entry?  The hole went from slot 1 down to fin_slot and every entry on
       // that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its ancestors (except the
       // root); the last entry of the old heap is the one that was dropped into the hole.
-      if (stfix > 1 && fin_slot > 0) {
-        const int dP = 31 - __clz(fin_slot), ds = 31 - __clz(stfix);
-        if (stfix == ntr_old) stfix = fin_slot;
-        else if (ds <= dP && (fin_slot >> (dP - ds)) == stfix) stfix >>= 1;
+      // Lazy back-pointers (round 3).  A sift-down moves ~9 entries up one level each, and the reference stores the new slot of
+      // every one of them in its node's status -- nine 4-byte writes into nine random lines per pop, half of this kernel's HBM
+      // traffic.  Here the record of an entry that moves UP (child slot -> parent slot) is left alone, so a band node's record
+      // holds a slot whose ancestor-or-self is the entry's true slot; every other movement still stores at once (the dropped
+      // last entry, entries pushed down by a rising one, new and rising entries themselves).  The true slot is looked up when it
+      // is needed, after the sift-down: the four lanes of the neighbour's quad read the node ids at srec >> k, k = q, q+4, q+8(,
+      // q+12) -- ids are unique in the heap, so the one that matches is it.  The entry the pop dropped into the hole is
+      // recognised by its id (its record was loaded before it moved).  The heap array itself evolves exactly as before; the
+      // refined march restores exact slots when it leaves its band in nstsr (above).
+      {
+        const int srec = stfix;
+        const bool band = srec > 0;
+        constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
+        constexpr int LT = LEV / 4 + 1;
+        int found = 64;
+#pragma unroll
+        for (int t = 0; t < LT; t++) {
+          const int k = q + 4 * t;
+          const int a = band ? (srec >> k) : 0;
+          const bool ok = a >= 1 && (!HYB || a < CAP);
+          const int id = (int)H.nodes[ok ? a : 0];
+          if (ok && id == (int)uself) found = found < k ? found : k;
+        }
+        { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
+        { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+        if (band) {
+          if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
+          else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
+        }
       }
       const bool act = stfix != 0, isnew = stfix < 0;
       const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
