@@ -687,7 +687,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
         if (H.g0) rec[iroot].s = 0;
-        if (!SPILL)   // lazy back-pointers (below): the records of entries that only moved up are behind; nstsr wants them exact
+        if (!SPILL && !HYB)   // lazy back-pointers (below): the records of entries that only moved up are behind; nstsr wants them exact
           for (int i = 2 + gl; i <= H.ntr; i += GP) rec[(unsigned)H.get(i).node].s = i;
         break;
       }
@@ -733,6 +733,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     int mynode = 0, myslot = 0, nmoves = 0;
     const int ntr_old = H.ntr;                               // slot of the entry the pop drops into the hole
     constexpr int NCAP = Heap<CAP, SPILL, NT, HYB>::NCAP, TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
+    // lazy back-pointers (below) on the all-in-LDS heap; the hybrid heap of the 342..682-node grids keeps the eager stores: with
+    // five workgroups per CU that kernel waits on latencies, not on HBM traffic, and the look-up costs it 3 % (S-512, measured)
+    constexpr bool LAZY = !SPILL && !HYB;
     int cnode[NCAP], cslot[NCAP], fin_node = 0, fin_slot = 0;
     PROF(0);
     if (SPILL) {
@@ -752,7 +755,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     if (SPILL) {
       if (gl < nmoves) rec[mynode].s = myslot;   // deferred back-pointers of the sift-down
     } else {
-      // (the entries the sift-down moved UP get no store: lazy back-pointers, see below; the dropped entry moved down)
+      // (LAZY: the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
+      if (!LAZY) {
+#pragma unroll
+        for (int b = 0; b < NCAP; b++)
+          if (cslot[b] > 0) st_slot(&rec[(unsigned)cnode[b]], cslot[b]);
+      }
       if (H.g0 && fin_slot > 0) st_slot(&rec[(unsigned)fin_node], fin_slot);
     }
     if (!nvalid) nself.s = 0;
@@ -760,17 +768,62 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     if (!vj2) nj2.s = -1;
     if (!vk) nk.s = -1;
     if (!vk2) nk2.s = -1;
+    int stfix = nself.s;                                   // -1 far, 0 alive / outside, >0 heap slot
+    // Lazy back-pointers (round 3).  A sift-down moves ~9 entries up one level each, and the reference stores the new slot of
+    // every one of them in its node's status -- nine 4-byte writes into nine random lines per pop, half of this kernel's HBM
+    // traffic.  Here the record of an entry that moves UP (child slot -> parent slot) is left alone, so a band node's record
+    // holds a slot whose ancestor-or-self is the entry's true slot; every other movement still stores at once (the dropped
+    // last entry, entries pushed down by a rising one, new and rising entries themselves).  The true slot is looked up when it
+    // is needed, after the sift-down: the four lanes of the neighbour's quad read the node ids at srec >> k, k = q, q+4, q+8(,
+    // q+12) -- ids are unique in the heap, so the one that matches is it.  The entry the pop dropped into the hole is
+    // recognised by its id (its record was loaded before it moved).  The heap array itself evolves exactly as before; the
+    // refined march restores exact slots when it leaves its band in nstsr (above).
+    // (the reads go out here and are looked at after the quadrant solve: their latency hides behind it)
+    const int srec = stfix;
+    const bool band = srec > 0;
+    constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
+    constexpr int LT = LEV / 4 + 1;
+    int lz_id[LT];
+    if (LAZY) {
+#pragma unroll
+      for (int t = 0; t < LT; t++) {
+        const int a = band ? (srec >> (q + 4 * t)) : 0;
+        lz_id[t] = (int)H.nodes[(a >= 1 && (!HYB || a < CAP)) ? a : 0];
+      }
+    }
     float trav = INFINITY;
     PROF(3);
     if (vj && vk && nself.s != 0) trav = quadrant_time(vel, risti, dnx, dnz, nj, nj2, nk, nk2, vj2, vk2);
     trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
     trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
+    if (!SPILL && !LAZY && stfix > 1 && fin_slot > 0) {
+      // eager back-pointers, loaded before the sift-down: did it move this neighbour's entry?  The hole went from slot 1 down to
+      // fin_slot and every entry on that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its
+      // ancestors (except the root); the last entry of the old heap is the one that was dropped into the hole.
+      const int dP = 31 - __clz(fin_slot), ds = 31 - __clz(stfix);
+      if (stfix == ntr_old) stfix = fin_slot;
+      else if (ds <= dP && (fin_slot >> (dP - ds)) == stfix) stfix >>= 1;
+    }
+    if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
+      int found = 64;
+#pragma unroll
+      for (int t = 0; t < LT; t++) {
+        const int k = q + 4 * t;
+        const int a = band ? (srec >> k) : 0;
+        if (a >= 1 && (!HYB || a < CAP) && lz_id[t] == (int)uself) found = found < k ? found : k;
+      }
+      { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
+      { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+      if (band) {
+        if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
+        else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
+      }
+    }
     PROF(4);
     // ---- the (up to) four heap updates in the reference's order (x-1, x+1, z-1, z+1) ----
     // Lane (nb, q=0) "owns" neighbour nb: it holds that node's status (nself.s) and new time (trav).
     bool fast = false;
     int n0 = 0;                                            // first neighbour handled by the sequential code
-    int stfix = nself.s;                                   // -1 far, 0 alive / outside, >0 heap slot
     if (!SPILL) {
       // all-in-LDS heap.  Usual case: none of the four entries has to rise above its parent (the new times
       // lie at the far side of the band), so the four addtree/updtree calls reduce to independent writes,
@@ -780,36 +833,6 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // Did the sift-down move this neighbour's heap entry?  The hole went from slot 1 down to fin_slot and every entry on
       // that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its ancestors (except the
       // root); the last entry of the old heap is the one that was dropped into the hole.
-      // Lazy back-pointers (round 3).  A sift-down moves ~9 entries up one level each, and the reference stores the new slot of
-      // every one of them in its node's status -- nine 4-byte writes into nine random lines per pop, half of this kernel's HBM
-      // traffic.  Here the record of an entry that moves UP (child slot -> parent slot) is left alone, so a band node's record
-      // holds a slot whose ancestor-or-self is the entry's true slot; every other movement still stores at once (the dropped
-      // last entry, entries pushed down by a rising one, new and rising entries themselves).  The true slot is looked up when it
-      // is needed, after the sift-down: the four lanes of the neighbour's quad read the node ids at srec >> k, k = q, q+4, q+8(,
-      // q+12) -- ids are unique in the heap, so the one that matches is it.  The entry the pop dropped into the hole is
-      // recognised by its id (its record was loaded before it moved).  The heap array itself evolves exactly as before; the
-      // refined march restores exact slots when it leaves its band in nstsr (above).
-      {
-        const int srec = stfix;
-        const bool band = srec > 0;
-        constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
-        constexpr int LT = LEV / 4 + 1;
-        int found = 64;
-#pragma unroll
-        for (int t = 0; t < LT; t++) {
-          const int k = q + 4 * t;
-          const int a = band ? (srec >> k) : 0;
-          const bool ok = a >= 1 && (!HYB || a < CAP);
-          const int id = (int)H.nodes[ok ? a : 0];
-          if (ok && id == (int)uself) found = found < k ? found : k;
-        }
-        { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
-        { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
-        if (band) {
-          if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
-          else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
-        }
-      }
       const bool act = stfix != 0, isnew = stfix < 0;
       const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
       const int cnt = __popc(newb);
