@@ -547,13 +547,14 @@ def main():
             # the dominant kernel.  It is bound by the serial heap order of fast marching (instruction issue + small random record
             # accesses), not by HBM bandwidth: `bound` says so; the HBM fraction of its algorithmic bytes is still reported
             # (achieved / peak / frac) because the metric asks for it, next to what the kernel is really limited by (pops/s).
-            "roofline": {"kernel": "fmm_kernel", "bound": "latency", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fmm_gbs / HBM_PEAK_GBS, "traffic": traffic["fmm"],
                          "node_acceptances_per_s": pops / stats["fmm_s"],
                          "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
                          "traffic_source": traffic_src,
-                         "note": "serial dependence chain per field (one heap pop after the other), all parallelism across "
-                                 f"fields; algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
+                         "note": "bound by the rate of cache-missing 64-128-byte accesses to the node records (a serial chain of heap "
+                                 "pops per field, all parallelism across fields; `traffic` is what really moves, DESIGN.md 4); "
+                                 f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
                                  "FETCH_SIZE + WRITE_SIZE per launch (8-byte accesses: raw counter values, the gfx950 x2 read "
                                  "correction is only calibrated for 16-byte streams)"},
             "spmv": {"kernels": {"Ax": kind_ax.get(int(stats.get("spmv_kind", -1)), "?"),
