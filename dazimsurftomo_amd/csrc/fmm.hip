@@ -783,13 +783,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const bool band = srec > 0;
     constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
     constexpr int LT = LEV / 4 + 1;
-    int lz_id[LT];
-    if (LAZY) {
-#pragma unroll
-      for (int t = 0; t < LT; t++) {
-        const int a = band ? (srec >> (q + 4 * t)) : 0;
-        lz_id[t] = (int)H.nodes[(a >= 1 && (!HYB || a < CAP)) ? a : 0];
-      }
+    int lz_id0 = 0;
+    if (LAZY) {   // k = q first: an entry rarely moves up more than three levels between two stores of its slot
+      const int a = band ? (srec >> q) : 0;
+      lz_id0 = (int)H.nodes[(a >= 1 && (!HYB || a < CAP)) ? a : 0];
     }
     float trav = INFINITY;
     PROF(3);
@@ -806,14 +803,25 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     }
     if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
       int found = 64;
-#pragma unroll
-      for (int t = 0; t < LT; t++) {
-        const int k = q + 4 * t;
-        const int a = band ? (srec >> k) : 0;
-        if (a >= 1 && (!HYB || a < CAP) && lz_id[t] == (int)uself) found = found < k ? found : k;
+      {
+        const int a = band ? (srec >> q) : 0;
+        if (a >= 1 && (!HYB || a < CAP) && lz_id0 == (int)uself) found = q;
       }
       { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
       { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+      const bool isdrop = (int)uself == fin_node && fin_slot > 0;
+      if (__ballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
+#pragma unroll
+        for (int t = 1; t < LT; t++) {
+          const int k = q + 4 * t;
+          const int a = band ? (srec >> k) : 0;
+          const bool ok = a >= 1 && (!HYB || a < CAP);
+          const int id = (int)H.nodes[ok ? a : 0];
+          if (ok && id == (int)uself) found = found < k ? found : k;
+        }
+        { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
+        { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+      }
       if (band) {
         if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
         else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
