@@ -124,8 +124,9 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
 // One heap per 16-lane group.  "Hole" formulation: the moving element stays in registers while
 // displaced entries are copied; the comparisons, and hence the final array, are those of the
-// reference's swap formulation.  Like the reference, the node status in HBM carries the heap slot
-// of every band node (nsts>0), written (lane 0 of the group) whenever an entry moves.
+// reference's swap formulation.  Like the reference, the node status in HBM carries a heap slot
+// for every band node (nsts>0) -- exact in the spill and hybrid kernels, written whenever an entry moves;
+// in the all-in-LDS kernel an ancestor-or-self relation of the true slot (lazy back-pointers, see march()).
 constexpr int GP = 16;   // lanes per field
 constexpr int FPW = 4;   // fields per wavefront
 
@@ -339,7 +340,8 @@ struct Heap {
   // it and all move (per-lane constant masks G/E/A) copies its smaller child into its own slot: same comparisons, same final
   // array as the sequential loop.  A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child
   // tail.  Two steps empty a heap below 512 slots (every refined grid, grids up to ~170 nodes a side), three one below 8192.
-  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores; where a pending
+  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores of the hybrid kernel
+  // (the all-in-LDS kernel leaves the records of entries that move up alone: lazy back-pointers, see march()); where a pending
   // neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
   static constexpr int NSTEP = CAP <= 32 ? 1 : (CAP <= 512 ? 2 : 3);
   static constexpr int NCAP = NSTEP + (HYB ? 1 : 0);  // captured moves: one per parallel step (+ the HBM level's)
@@ -1006,6 +1008,8 @@ template <int CAP, bool SPILL, class NT, bool HYB>
 __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
+  // (rows padded so that the four fields sit eight LDS banks apart -- they are walked in step, and CAP is a multiple of the 32
+  // banks -- measured: no difference, 53.4 k fields/s either way)
   // the queue position is handed to the wavefront through slot 0 of the first field's keys (the dummy slot of the marching
   // loop, idle between fields): the kernel's LDS is exactly the heaps, so five 32 KB workgroups of the hybrid heap fill 160 KB
   unsigned &s_base = *reinterpret_cast<unsigned *>(&s_keys[0][0]);
