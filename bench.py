@@ -455,17 +455,28 @@ def main():
         wall[name] = wall.get(name, 0.0) + now - tw[0]
         tw[0] = now
 
+    # N > 1: the dispersion tables belong to the model every rank shares -- each rank computes a block of its rows and one
+    # all-gather (RCCL) joins them (dazimsurftomo_amd.distributed.depthkernel_sharded; DAZIM_SHARD_DISP=0: every rank all of it)
+    shard_disp = use_dist and os.environ.get("DAZIM_SHARD_DISP", "1") != "0"
+
     def step():
         tw[0] = time.perf_counter()
-        pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
+        if shard_disp:
+            from dazimsurftomo_amd.distributed import depthkernel_sharded
+            t_d = time.perf_counter()
+            pv, sen, nfail = depthkernel_sharded(ctx.depthkernel, d_vel, DEPZ, PERIODS, MINTHK, world, rank)
+            torch.cuda.synchronize()                        # (the library launches on its own stream)
+            stats["disp_s"] = time.perf_counter() - t_d     # local curves + all-gather
+        else:
+            pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
+            stats["disp_s"] = ctx.kernel_seconds("disp")
         lap("depthkernel")
-        stats["disp_s"] = ctx.kernel_seconds("disp")
-        fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, d_pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
+        fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
         lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
-                                        d_rcx, d_rcz, d_sen, tpred=d_tpred)
+                                        d_rcx, d_rcz, sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
         lap("rays_build_G")
         stats["nnz_data"] = G.nnz
@@ -573,6 +584,8 @@ def main():
                                else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
                      "host_syncs_per_iteration": (stats["host_syncs"] / max(stats["lsmr_itn"], 1)) if stats.get("host_syncs", -1) >= 0 else None,
                      "host_syncs_note": "host waits on the device counted by the solver during its iteration loop / iterations"},
+            "dispersion": ("model rows sharded over the ranks, tables joined by one all-gather (RCCL)" if shard_disp
+                           else ("every rank computes the whole model's tables" if use_dist else "single GPU")),
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],

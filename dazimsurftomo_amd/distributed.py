@@ -1,8 +1,11 @@
 """Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
 
 Forward pass: the (source x period) eikonal fields and their rays are independent, so they are
-sharded over ranks with NO collective (`shard_fields`); every rank recomputes the small dispersion
-tables.  Solve: G is row-partitioned exactly as its rows were produced (each rank keeps the rows of
+sharded over ranks with NO collective (`shard_fields`).  The dispersion curves and depth kernels
+belong to the MODEL, which all ranks share: its columns are independent too, so each rank computes
+the curves of a block of rows of the model and one all-gather hands every rank the whole tables
+(`depthkernel_sharded`: the eikonal solve needs every column's phase velocity, the G rows every
+column's kernels -- a real exchange step, 13 MB at 54 x 54 x 12 x 16 periods).  Solve: G is row-partitioned exactly as its rows were produced (each rank keeps the rows of
 its own rays; the Tikhonov rows are split evenly, `shard_rows`), and LSMR (inv/lsmrModule.f90:36)
 needs per iteration one all-reduce of the n-vector A^T u and one scalar all-reduce for ||u||^2;
 everything n-sized (v, h, hbar, x, localV) is replicated and updated redundantly, so no other
@@ -36,6 +39,48 @@ def shard_rows(nrows, world, rank):
     base, rem = divmod(nrows, world)
     start = rank * base + min(rank, rem)
     return start, start + base + (1 if rank < rem else 0)
+
+
+def depthkernel_sharded(depthkernel, vel, depz, periods, minthk, world, rank, group=None, kernels=True, always_gather=False):
+    """depthkernel (inv/CalSurfG.f90:1) with the model's columns sharded over the ranks: `depthkernel(vel_block, depz, periods,
+    minthk, kernels=...)` -> (pv [kmax][ncol_block], sen 3 x [nz][kmax][ncol_block] or None, n_failed) is called on this rank's
+    block of rows vel[:, j0:j1, :] (columns are numbered jj*nx + ii, so a block of rows is a contiguous block of columns), the
+    blocks are all-gathered (padded to the largest block: all_gather wants equal shapes) and joined along the column axis.
+    Every column is computed by exactly one rank with the same kernel as in the single-process call: the joined tables are
+    bit-identical to it.  torch tensors (CUDA with backend nccl = RCCL, CPU with gloo).  Returns (pv, sen, n_failed summed)."""
+    import torch
+    import torch.distributed as dist
+    nz, ny, nx = vel.shape
+    if world <= 1 and not always_gather:                  # (always_gather: tests run the collective with one rank too)
+        return depthkernel(vel, depz, periods, minthk, kernels=kernels)
+    bounds = [shard_rows(ny, world, r) for r in range(world)]
+    j0, j1 = bounds[rank]
+    rows_max = max(b - a for a, b in bounds)
+    kmax = len(periods)
+    dev = vel.device
+    if j1 > j0:
+        pv_b, sen_b, nf = depthkernel(vel[:, j0:j1, :].contiguous(), depz, periods, minthk, kernels=kernels)
+    else:
+        pv_b, sen_b, nf = None, None, 0
+    ncb = rows_max * nx
+    nt = 4 if kernels else 1
+    send = torch.zeros((nt, nz, kmax, ncb), dtype=torch.float64, device=dev)
+    if j1 > j0:
+        n = (j1 - j0) * nx
+        send[0, 0, :, :n] = torch.as_tensor(pv_b, device=dev)
+        if kernels:
+            for q in range(3):
+                send[1 + q, :, :, :n] = torch.as_tensor(sen_b[q], device=dev)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    nfail = torch.tensor([nf], dtype=torch.int64, device=dev)
+    dist.all_reduce(nfail, group=group)
+    cols = [(b - a) * nx for a, b in bounds]
+    pv = torch.cat([recv[r][0, 0, :, :cols[r]] for r in range(world)], dim=-1).contiguous()
+    sen = None
+    if kernels:
+        sen = [torch.cat([recv[r][1 + q, :, :, :cols[r]] for r in range(world)], dim=-1).contiguous() for q in range(3)]
+    return pv, sen, int(nfail.item())
 
 
 class GpuLocalOps:

@@ -65,12 +65,25 @@ def main(out_path):
         parts = [torch.empty_like(x) for _ in range(world)]
         dist.all_gather(parts, x.contiguous())
         same.append(all(bool(torch.equal(parts[0], q)) for q in parts))
+    # (c) the model's dispersion tables: rows sharded over the ranks + all-gather (RCCL) = the single-process call, bit for bit
+    from dazimsurftomo_amd.distributed import depthkernel_sharded
+    rng = np.random.default_rng(9)
+    depz = np.array([0.0, 5.0, 12.0, 25.0, 45.0, 70.0], np.float32)
+    periods = np.array([6.0, 10.0, 16.0, 25.0])
+    vel = (3.0 + 0.2 * np.arange(len(depz))[:, None, None] + 0.05 * rng.standard_normal((len(depz), 7, 5))).astype(np.float32)
+    d_vel = torch.from_numpy(vel).to(dev)
+    pv1, sen1, nf1 = ctx.depthkernel(d_vel, depz, periods, 2.0)
+    pv, sen, nf = depthkernel_sharded(ctx.depthkernel, d_vel, depz, periods, 2.0, world, rank, always_gather=True)
+    torch.cuda.synchronize()
+    disp_same = bool(torch.equal(pv, pv1)) and all(bool(torch.equal(a, b_)) for a, b_ in zip(sen, sen1)) and nf == nf1
+    flags = [None] * world
+    dist.all_gather_object(flags, disp_same)
     infos = [None] * world
     dist.all_gather_object(infos, (info_nat, info_py))
     if rank == 0:
         json.dump({"world": world, "rccl_nranks": nranks, "x_native": x_nat.cpu().numpy().tolist(),
                    "x_python": x_py.cpu().numpy().tolist(), "info_native": info_nat, "info_python": info_py,
-                   "same_x_native": same[0], "same_x_python": same[1],
+                   "same_x_native": same[0], "same_x_python": same[1], "disp_sharded_same": all(flags),
                    "same_info": all(i == infos[0] for i in infos)}, open(out_path, "w"))
     G.free()
     ctx.close()

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from dazimsurftomo_amd.distributed import lsmr_distributed, shard_fields, shard_rows
+from dazimsurftomo_amd.distributed import depthkernel_sharded, lsmr_distributed, shard_fields, shard_rows
 from tests.test_sparse_gpu import random_system
 
 
@@ -91,6 +91,50 @@ def test_lsmr_distributed_world2_gloo(orc, cfg):
     same_istop, ditn, rel, itn = out["ok"]
     assert same_istop and ditn <= 3 and rel <= 1e-3, (out["ok"],)
     assert out["same0"] and out["same1"]
+
+
+def _oracle_depthkernel(orc):
+    """test double of Context.depthkernel: the oracle on numpy, torch CPU tensors in and out"""
+    def f(vel, depz, periods, minthk, kernels=True):
+        out = orc.depthkernel(vel.numpy(), depz, periods, minthk, kernels=kernels)
+        pv, sen = (out[0], out[1]) if kernels else (out[0] if isinstance(out, tuple) else out, None)
+        nfail = int((pv == 0).sum())
+        return torch.from_numpy(pv), ([torch.from_numpy(a) for a in sen] if kernels else None), nfail
+    return f
+
+
+def _disp_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.pyoracle import Oracle
+        orc = Oracle()
+        rng = np.random.default_rng(4)
+        nz, ny, nx = 5, 5, 4                      # 5 rows over 3 ranks: blocks of 2, 2 and 1 rows (padding exercised)
+        depz = np.array([0.0, 5.0, 12.0, 25.0, 45.0], np.float32)
+        periods = np.array([6.0, 12.0, 20.0])
+        vel = (3.0 + 0.25 * np.arange(nz)[:, None, None] + 0.05 * rng.standard_normal((nz, ny, nx))).astype(np.float32)
+        f = _oracle_depthkernel(orc)
+        pv, sen, nf = depthkernel_sharded(f, torch.from_numpy(vel), depz, periods, 2.0, world, rank)
+        pv1, sen1, nf1 = f(torch.from_numpy(vel), depz, periods, 2.0)
+        out[f"ok{rank}"] = (torch.equal(pv, pv1) and all(torch.equal(a, b) for a, b in zip(sen, sen1)) and nf == nf1
+                            and bool((pv1 != 0).all()))
+        pvo, _, _ = depthkernel_sharded(f, torch.from_numpy(vel), depz, periods, 2.0, world, rank, kernels=False)
+        out[f"pv{rank}"] = torch.equal(pvo, pv1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_depthkernel_sharded_world3_gloo_is_bit_identical(orc):
+    """the model's columns sharded over three ranks + all-gather = the single-process tables, bit for bit, on every rank"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_disp_worker, args=(3, port, out), nprocs=3, join=True)
+    assert all(out[f"ok{r}"] and out[f"pv{r}"] for r in range(3)), dict(out)
 
 
 def test_lsmr_distributed_single_process_equals_oracle(orc):

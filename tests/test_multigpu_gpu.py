@@ -33,6 +33,7 @@ def check(res, orc, nproc):
     xo, io = orc.lsmr(m, n, irow, icol, rw, b, *CFG)
     assert res["world"] == nproc and res["rccl_nranks"] == nproc            # RCCL really spans all the ranks
     assert res["same_x_native"] and res["same_x_python"] and res["same_info"]
+    assert res["disp_sharded_same"]      # dispersion tables: model rows sharded + all-gather = the single-process tables on every rank
     for key in ("native", "python"):
         x, info = np.array(res["x_" + key], np.float32), res["info_" + key]
         assert info["istop"] == io["istop"] and abs(info["itn"] - io["itn"]) <= 3, (key, info, io)
