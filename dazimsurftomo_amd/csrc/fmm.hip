@@ -614,6 +614,9 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
 
 #endif
 
+#ifdef DZ_FMM_LAZYSTAT
+__device__ unsigned long long g_lazy_stat[4];
+#endif
 #ifdef DZ_FMM_PROF   // experiment-only build: per-phase shader-clock totals of the marching loop
 __device__ unsigned long long g_fmm_prof[8];
 #define PROF_DECL unsigned long long pt_ = __builtin_amdgcn_s_memtime(), pa_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -812,6 +815,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
       { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
       const bool isdrop = (int)uself == fin_node && fin_slot > 0;
+#ifdef DZ_FMM_LAZYSTAT   // experiment build: how often the first four ancestors do not hold the entry (lanes), and pops
+      if (q == 0 && band) atomicAdd(&g_lazy_stat[found == 64 && !isdrop ? 1 : 0], 1ull);
+      if (q == 0 && band && isdrop) atomicAdd(&g_lazy_stat[2], 1ull);
+#endif
       if (__ballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
 #pragma unroll
         for (int t = 1; t < LT; t++) {
@@ -1360,6 +1367,15 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
+#ifdef DZ_FMM_LAZYSTAT
+  {
+    unsigned long long h[4];
+    DZ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lazy_stat), sizeof h));
+    fprintf(stderr, "lazy look-ups: %llu within three levels, %llu higher (second round), %llu the dropped entry\n", h[0], h[1], h[2]);
+    unsigned long long z[4] = {0};
+    DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_lazy_stat), z, sizeof z));
+  }
+#endif
 #ifdef DZ_FMM_PROF
   {
     unsigned long long h[8];
