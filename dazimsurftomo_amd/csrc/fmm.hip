@@ -847,10 +847,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // done by the owner lanes.  A parent that is itself an earlier neighbour (m < nb) is compared with
       // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
       const bool owner = q == 0;
-      // Did the sift-down move this neighbour's heap entry?  The hole went from slot 1 down to fin_slot and every entry on
-      // that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its ancestors (except the
-      // root); the last entry of the old heap is the one that was dropped into the hole.
-      const bool act = stfix != 0, isnew = stfix < 0;
+      const bool act = stfix != 0, isnew = stfix < 0;          // (stfix: the neighbour's true slot, resolved above)
       const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
       const int cnt = __popc(newb);
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
