@@ -38,6 +38,20 @@ struct __align__(8) HEnt {
   int node;  // index of the node's record in the tiled layout (tile_x + tile_z below; the reference keeps int16 px,pz: inv/CalSurfG.f90:238)
 };
 
+// Coarse-grid node word (round 3): ONE 32-bit word per node instead of the {time, status} pair.  An alive node holds its time
+// (a non-negative float: sign bit clear); a band node holds 0x80000000 | heap slot -- its trial time is the heap key, and nothing
+// reads a band node's time from the grid (fouds2 replaces it, the stencil only uses alive neighbours, acceptance takes the key);
+// a far node holds 0xffffffff.  Between the refined and the coarse march a close node that waits to be put into the heap holds
+// its time with the sign bit set (-T; T = 0 gives 0x80000000, "slot 0", which never is a slot).  Same 4 x 4 tiles and indices as
+// the 8-byte records of the refined grid: two tiles that are neighbours in z share a 128-byte line, so a line covers 4 x 8 nodes.
+constexpr unsigned W_FAR = 0xffffffffu, W_BAND = 0x80000000u;
+__device__ __forceinline__ unsigned w_alive(float t) { return (unsigned)__float_as_int(t); }
+__device__ __forceinline__ unsigned w_band(int slot) { return W_BAND | (unsigned)slot; }
+__device__ __forceinline__ unsigned w_pending(float t) { return W_BAND | (unsigned)__float_as_int(t); }
+__device__ __forceinline__ bool w_is_alive(unsigned w) { return (int)w >= 0; }
+__device__ __forceinline__ bool w_is_pending(unsigned w) { return (int)w < 0 && w != W_FAR; }   // (before the coarse march only)
+__device__ __forceinline__ float w_time(unsigned w) { return __int_as_float((int)(w & 0x7fffffffu)); }
+
 struct FmmArgs {
   dazim_geom g;
   int nfield, kmax;
@@ -53,7 +67,7 @@ struct FmmArgs {
   int *nstsr;
   dazim_refbox *boxes;
   int *status;
-  Node *rec_c;   // [nwg][nnx*nnz]
+  unsigned *rec_c;   // [nwg][tiled nnx x nnz] node words of the coarse grid (see w_alive ...)
   Node *rec_r;   // [nwg][RM*RM]
   float *velnr;  // [nwg][RM*RM]
   float *slownr; // [nwg][tiled RM x RM]  1/velnr
@@ -73,7 +87,8 @@ __device__ __forceinline__ void bspl4(float u, float w[4]) {
   w[3] = u * u * u / 6.0f;
 }
 
-// Node records live in HBM in 4 x 4 tiles of 8-byte records (one 128-byte line per tile): node (ix0, iz0), 0-based, of a grid
+// Node records live in HBM in 4 x 4 tiles (8-byte {time, status} records on the refined grid: one 128-byte line per tile; 4-byte
+// node words on the coarse grid, see w_alive: two z-neighbouring tiles per line): node (ix0, iz0), 0-based, of a grid
 // with ntz tiles per column of tiles (ceil(nz/4) rounded up to a power of two) is record
 // ((ix0>>2)*ntz + (iz0>>2))*16 + (ix0&3)*4 + (iz0&3).  The stencil of a pop reaches +-3 nodes in both directions: in the
 // reference's column-major order that is 7 columns = 7-8 lines, tiled it is 4-6.  The two coordinates contribute separately, so
@@ -159,7 +174,12 @@ struct Heap {
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
-  Node *rec;   // node records of the grid being marched (4 x 4 tiles)
+  void *rec;   // node records (refined grid: Node) or node words (coarse grid: unsigned) of the grid being marched (4 x 4 tiles)
+  // back-pointer store: a band node's slot (W4: the whole word, see w_band)
+  template <bool W4> __device__ __forceinline__ void set_slot(unsigned node, int slot) {
+    if (W4) reinterpret_cast<unsigned *>(rec)[node] = w_band(slot);
+    else reinterpret_cast<Node *>(rec)[node].s = slot;
+  }
   int tsh;     // log2 of the record stride between columns of tiles of that grid
   int ntr;
   bool g0;     // lane 0 of the group
@@ -192,6 +212,7 @@ struct Heap {
   // All 16 lanes of the group hold the same (slot, key, node): the LDS entry is written by all of them
   // (same address, same value -- no exec-mask branch inside the sift loops); the HBM back-pointer
   // and spill stores are issued by lane 0 only.
+  template <bool W4>
   __device__ __forceinline__ void put(int slot, float key, int node) {
     if ((SPILL || HYB) && slot >= CAP) {
       if (g0) ovf[slot - CAP] = HEnt{key, node};
@@ -199,17 +220,17 @@ struct Heap {
       keys[slot] = key;
       nodes[slot] = (NT)node;
     }
-    if (g0) rec[node].s = slot;
+    if (g0) set_slot<W4>((unsigned)node, slot);
   }
   // sift (key,node) up from slot c.  If `track`, entries that move down are compared with the
   // pending neighbours' node ids so that their slots stay current (nbs[m] for m > from).
-  template <bool TRACK>
+  template <bool TRACK, bool W4>
   __device__ __forceinline__ void sift_up(int c, float key, int node, const int (&nbn)[4], int (&nbs)[4], int from) {
     while (c > 1) {
       const int p = c >> 1;
       const HEnt pe = get(p);
       if (key < pe.key) {
-        put(c, pe.key, pe.node);
+        put<W4>(c, pe.key, pe.node);
         if (TRACK) {
 #pragma unroll
           for (int m = 1; m < 4; m++)
@@ -219,7 +240,7 @@ struct Heap {
       } else
         break;
     }
-    put(c, key, node);
+    put<W4>(c, key, node);
   }
   // addtree / updtree (:738-783, :872-890) for the all-in-LDS heap in ONE LDS round instead of a loop over the levels: lane i of
   // the group reads ancestor c >> (i+1) of the rising entry (a heap of < 4096 slots has at most 11); the entry rises past the
@@ -227,6 +248,7 @@ struct Heap {
   // lane i writes its ancestor into slot c >> i and that node's back-pointer, lane L places the entry itself at c >> L.  Same
   // comparisons, same final array.  Returns L, the number of levels risen (the caller shifts the slots of pending neighbours
   // that sat on the path).  Groups with live == false read and write the dummy slot 0.
+  template <bool W4>
   __device__ __forceinline__ int rise_par(bool live, int gl, int gbase, int c, float key, int node) {
     const int a = c >> (gl + 1);
     const bool valid = live && a >= 1;
@@ -242,7 +264,7 @@ struct Heap {
     const int ldst = dhi ? 0 : dst;
     keys[ldst] = ak;
     nodes[ldst] = an;
-    if (mover) rec[(unsigned)an].s = dst;
+    if (mover) set_slot<W4>((unsigned)an, dst);
     const bool last = live && gl == L;
     const int fin = c >> L;
     const bool fhi = HYB && last && fin >= CAP;
@@ -250,7 +272,10 @@ struct Heap {
       keys[fin] = key;
       nodes[fin] = (NT)node;
     }
-    if (last) rec[node] = Node{key, fin};
+    if (last) {
+      if (W4) reinterpret_cast<unsigned *>(rec)[node] = w_band(fin);
+      else reinterpret_cast<Node *>(rec)[node] = Node{key, fin};
+    }
     if (HYB && __ballot(dhi || fhi) != 0) {
       if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
@@ -258,11 +283,12 @@ struct Heap {
     return L;
   }
   __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= TOT; }
+  template <bool W4>
   __device__ __forceinline__ void add(float key, int node) {
     const int nbn[4] = {0, 0, 0, 0};
     int nbs[4] = {0, 0, 0, 0};
     ntr++;
-    sift_up<false>(ntr, key, node, nbn, nbs, 0);
+    sift_up<false, W4>(ntr, key, node, nbn, nbs, 0);
   }
   // LDS-only write of a heap entry (the HBM back-pointer is deferred by the caller)
   __device__ __forceinline__ void put_lds(int slot, float key, int node) {
@@ -674,7 +700,18 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
-  Node *rec = H.rec;
+  constexpr bool W4 = !REFINED;                            // the coarse grid keeps one word per node (w_alive ...)
+  Node *rec = reinterpret_cast<Node *>(H.rec);              // (REFINED)
+  unsigned *recw = reinterpret_cast<unsigned *>(H.rec);     // (coarse)
+  // one node as the {time, status} pair the code below works with: status 0 alive, -1 far, > 0 heap slot
+  auto ldn = [&](unsigned idx) -> Node {
+    if (!W4) return ld_node(&rec[idx]);
+    const unsigned w = recw[idx];
+    Node n;
+    n.t = __int_as_float((int)w);
+    n.s = w_is_alive(w) ? 0 : (w == W_FAR ? -1 : (int)(w & 0x7fffffffu));
+    return n;
+  };
   const int tsh = H.tsh;
   bool overflow = false;
   PROF_DECL;
@@ -691,13 +728,16 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) rec[iroot].s = 0;
+        if (H.g0) rec[iroot].s = 0;                          // (REFINED only: 8-byte records)
         if (!SPILL && !HYB)   // lazy back-pointers (below): the records of entries that only moved up are behind; nstsr wants them exact
           for (int i = 2 + gl; i <= H.ntr; i += GP) rec[(unsigned)H.get(i).node].s = i;
         break;
       }
     }
-    if (H.g0) st_slot(&rec[iroot], 0);
+    if (H.g0) {
+      if (W4) recw[iroot] = w_alive(root.key);              // accepted: the word becomes the time (= the heap key, the trial time)
+      else st_slot(&rec[iroot], 0);
+    }
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
@@ -715,11 +755,11 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
     const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
     const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
-    Node nself = ld_node(&rec[uself]);
-    Node nj = ld_node(&rec[vj ? (unsigned)(xj + zn) : uroot]);
-    Node nj2 = ld_node(&rec[vj2 ? (unsigned)(xj2 + zn) : uroot]);
-    Node nk = ld_node(&rec[vk ? (unsigned)(xn + zk) : uroot]);
-    Node nk2 = ld_node(&rec[vk2 ? (unsigned)(xn + zk2) : uroot]);
+    Node nself = ldn(uself);
+    Node nj = ldn(vj ? (unsigned)(xj + zn) : uroot);
+    Node nj2 = ldn(vj2 ? (unsigned)(xj2 + zn) : uroot);
+    Node nk = ldn(vk ? (unsigned)(xn + zk) : uroot);
+    Node nk2 = ldn(vk2 ? (unsigned)(xn + zk2) : uroot);
     const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
     const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
@@ -758,15 +798,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
                  "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
                  : "memory");
     if (SPILL) {
-      if (gl < nmoves) rec[mynode].s = myslot;   // deferred back-pointers of the sift-down
+      if (gl < nmoves) H.template set_slot<W4>((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
     } else {
       // (LAZY: the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
       if (!LAZY) {
 #pragma unroll
         for (int b = 0; b < NCAP; b++)
-          if (cslot[b] > 0) st_slot(&rec[(unsigned)cnode[b]], cslot[b]);
+          if (cslot[b] > 0) H.template set_slot<W4>((unsigned)cnode[b], cslot[b]);
       }
-      if (H.g0 && fin_slot > 0) st_slot(&rec[(unsigned)fin_node], fin_slot);
+      if (H.g0 && fin_slot > 0) H.template set_slot<W4>((unsigned)fin_node, fin_slot);
     }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
@@ -897,10 +937,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         if (f2 && rise) {
           H.keys[pc] = trav;
           H.nodes[pc] = (NT)uself;
-          st_node(&rec[uself], Node{trav, pc});
+          if (W4) recw[uself] = w_band(pc); else st_node(&rec[uself], Node{trav, pc});
           H.keys[c] = pk;
           H.nodes[c] = pn;
-          st_slot(&rec[(unsigned)pn], c);
+          H.template set_slot<W4>((unsigned)pn, c);
         }
       }
       {
@@ -909,7 +949,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
-        if (wr) st_node(&rec[uself], Node{trav, c});
+        if (wr) {
+          if (W4) recw[uself] = w_band(c); else st_node(&rec[uself], Node{trav, c});
+        }
         if (HYB && __ballot(whi) != 0) {
           if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
@@ -960,7 +1002,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         for (int n = 0; n < 4; n++) {
           if (nbs[n] == 0 || n < n0) continue;
           const int node = nbn[n];
-          if (H.g0) rec[node].t = nbt[n];
+          if (!W4 && H.g0) rec[node].t = nbt[n];            // (W4: a band node's time lives in the heap only)
           int c = nbs[n];
           if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
             if (H.full()) {
@@ -970,7 +1012,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
             H.ntr++;
             c = H.ntr;
           }
-          H.template sift_up<true>(c, nbt[n], node, nbn, nbs, n);
+          H.template sift_up<true, W4>(c, nbt[n], node, nbn, nbs, n);
         }
       } else {
         // all-in-LDS heap: one parallel round per remaining neighbour, in the reference's order (the four groups of the
@@ -989,7 +1031,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
               c = H.ntr;
             }
           }
-          const int L = H.rise_par(live, gl, gbase, c, nbt[n], nbn[n]);
+          const int L = H.template rise_par<W4>(live, gl, gbase, c, nbt[n], nbn[n]);
           // a pending neighbour whose entry sat on the path moved down one level with it
 #pragma unroll
           for (int m = n + 1; m < 4; m++) {
@@ -1022,7 +1064,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
   const int tsh_c = tile_shift(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
-  Node *rec_c = A.rec_c + slot * nrec_c;
+  unsigned *rec_c = A.rec_c + slot * nrec_c;
   Node *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * NREC_R;
@@ -1159,7 +1201,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
               const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
               const int urid = tile_x(ux - 1, TSH_R) + tile_z(uz - 1);
               if (gl == 0) rec_r[urid].t = t0;
-              H.add(t0, urid);
+              H.template add<false>(t0, urid);
             }
         }
         // exit-rule quirk kept verbatim (inv/CalSurfG.f90:366-377): vnr/vnb (coarse indices) are
@@ -1180,7 +1222,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
               if (nstsr) nstsr[idx] = nd.s;
               if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
             }
-          for (int i = gl; i < nrec_c; i += GP) rec_c[i] = Node{0.0f, -1};
+          for (int i = gl; i < nrec_c; i += GP) rec_c[i] = W_FAR;
         }
         cbar();
         // ---- inject every sgdl-th refined node (inv/CalSurfG.f90:1252-1262) ----
@@ -1188,9 +1230,9 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         for (int i = gl; i < nbox; i += GP) {
           const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
           const Node nd = rec_r[tile_x(bxi * SGDL, TSH_R) + tile_z(bzi * SGDL)];
-          Node o{0.0f, nd.s};
-          if (nd.s >= 0) o.t = nd.t;
-          rec_c[tile_x(bx.vnl - 1 + bxi, tsh_c) + tile_z(bx.vnt - 1 + bzi)] = o;
+          // alive: its time; close (in the refined band when the march stopped): its time, to be put into the coarse heap; far
+          rec_c[tile_x(bx.vnl - 1 + bxi, tsh_c) + tile_z(bx.vnt - 1 + bzi)] =
+              nd.s == 0 ? w_alive(nd.t) : (nd.s > 0 ? w_pending(nd.t) : W_FAR);
         }
         cbar();
         // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only
@@ -1199,21 +1241,23 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         for (int base = 0; base < nbox; base += GP) {
           const int i = base + gl;
           bool promote = false;
-          Node *p = nullptr;
+          unsigned *p = nullptr;
+          unsigned w = W_FAR;
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
             const int tx = tile_x(cx - 1, tsh_c), tz = tile_z(cz - 1);
             p = &rec_c[tx + tz];
-            if (p->s == 0) {
-              if (cz - 1 >= 1 && rec_c[tx + tile_z(cz - 2)].s == -1) promote = true;
-              if (cz + 1 <= nnz && rec_c[tx + tile_z(cz)].s == -1) promote = true;
-              if (cx - 1 >= 1 && rec_c[tile_x(cx - 2, tsh_c) + tz].s == -1) promote = true;
-              if (cx + 1 <= nnx && rec_c[tile_x(cx, tsh_c) + tz].s == -1) promote = true;
+            w = *p;
+            if (w_is_alive(w)) {
+              if (cz - 1 >= 1 && rec_c[tx + tile_z(cz - 2)] == W_FAR) promote = true;
+              if (cz + 1 <= nnz && rec_c[tx + tile_z(cz)] == W_FAR) promote = true;
+              if (cx - 1 >= 1 && rec_c[tile_x(cx - 2, tsh_c) + tz] == W_FAR) promote = true;
+              if (cx + 1 <= nnx && rec_c[tile_x(cx, tsh_c) + tz] == W_FAR) promote = true;
             }
           }
           cbar();
-          if (promote) p->s = 1;
+          if (promote) *p = w_pending(w_time(w));               // alive -> close, same time
         }
         cbar();
         // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
@@ -1222,21 +1266,21 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         H.tsh = tsh_c;
         for (int base = 0; base < nbox; base += GP) {
           const int i = base + gl;
-          Node nd{0.0f, -1};
+          unsigned w = W_FAR;
           int node = 0;
           if (i < nbox) {
             const int bxi = i / bh, bzi = i - bxi * bh;
             const int cx = bx.vnl + bxi, cz = bx.vnt + bzi;
             node = tile_x(cx - 1, tsh_c) + tile_z(cz - 1);
-            nd = rec_c[node];
+            w = rec_c[node];
           }
-          unsigned m = (unsigned)((__ballot(nd.s > 0) >> (grp * GP)) & 0xffffull);
+          unsigned m = (unsigned)((__ballot(w_is_pending(w)) >> (grp * GP)) & 0xffffull);
           while (m) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
-            const float t0 = __shfl(nd.t, grp * GP + b);
+            const float t0 = __shfl(w_time(w), grp * GP + b);
             const int n0 = __shfl(node, grp * GP + b);
-            if (!H.full()) H.add(t0, n0); else ovf = true;
+            if (!H.full()) H.template add<true>(t0, n0); else ovf = true;
           }
         }
         if (!ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
@@ -1246,7 +1290,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         } else {
           for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
             const int tx = tile_x(cx, tsh_c);
-            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = rec_c[tx + tile_z(cz)].t;
+            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);   // all alive
           }
         }
       }
@@ -1276,8 +1320,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
   A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
-  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(Node), &p))) return rc;
-  A.rec_c = (Node *)p;
+  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(unsigned), &p))) return rc;
+  A.rec_c = (unsigned *)p;
   if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(Node), &p))) return rc;
   A.rec_r = (Node *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
