@@ -29,7 +29,7 @@ constexpr int GDX = 5, GDZ = 5, SGDL = 8, SGS = 8;  // inv/CalSurfG.f90:1005-101
 constexpr int RM = DAZIM_RMAX;
 constexpr float EARTH = 6371.0f;
 
-struct __align__(8) Node {
+struct Node {   // a node as the marching loop looks at it (decoded from its word in HBM, see w_alive)
   float t;
   int s;  // nsts of the reference: -1 far, 0 alive, >0 slot in the narrow-band heap
 };
@@ -38,12 +38,14 @@ struct __align__(8) HEnt {
   int node;  // index of the node's record in the tiled layout (tile_x + tile_z below; the reference keeps int16 px,pz: inv/CalSurfG.f90:238)
 };
 
-// Coarse-grid node word (round 3): ONE 32-bit word per node instead of the {time, status} pair.  An alive node holds its time
+// Node word (round 3): ONE 32-bit word per node instead of the reference's {time, status} pair.  An alive node holds its time
 // (a non-negative float: sign bit clear); a band node holds 0x80000000 | heap slot -- its trial time is the heap key, and nothing
 // reads a band node's time from the grid (fouds2 replaces it, the stencil only uses alive neighbours, acceptance takes the key);
 // a far node holds 0xffffffff.  Between the refined and the coarse march a close node that waits to be put into the heap holds
-// its time with the sign bit set (-T; T = 0 gives 0x80000000, "slot 0", which never is a slot).  Same 4 x 4 tiles and indices as
-// the 8-byte records of the refined grid: two tiles that are neighbours in z share a 128-byte line, so a line covers 4 x 8 nodes.
+// its time with the sign bit set (-T; T = 0 gives 0x80000000, "slot 0", which never is a slot).  The refined grid's band, which
+// nstsr / ttnr and the injection into the coarse grid want with slots AND trial times, is read back through the heap that is
+// still in LDS when the refined march stops (the key at the slot the word holds).  4 x 4 tiles: two tiles that are neighbours in
+// z share a 128-byte line, so a line covers 4 x 8 nodes.
 constexpr unsigned W_FAR = 0xffffffffu, W_BAND = 0x80000000u;
 __device__ __forceinline__ unsigned w_alive(float t) { return (unsigned)__float_as_int(t); }
 __device__ __forceinline__ unsigned w_band(int slot) { return W_BAND | (unsigned)slot; }
@@ -68,7 +70,7 @@ struct FmmArgs {
   dazim_refbox *boxes;
   int *status;
   unsigned *rec_c;   // [nwg][tiled nnx x nnz] node words of the coarse grid (see w_alive ...)
-  Node *rec_r;   // [nwg][RM*RM]
+  unsigned *rec_r;   // [nwg][tiled RM x RM] node words of the refined grid
   float *velnr;  // [nwg][RM*RM]
   float *slownr; // [nwg][tiled RM x RM]  1/velnr
   HEnt *ovf;     // [nwg][ovfcap]
@@ -87,8 +89,8 @@ __device__ __forceinline__ void bspl4(float u, float w[4]) {
   w[3] = u * u * u / 6.0f;
 }
 
-// Node records live in HBM in 4 x 4 tiles (8-byte {time, status} records on the refined grid: one 128-byte line per tile; 4-byte
-// node words on the coarse grid, see w_alive: two z-neighbouring tiles per line): node (ix0, iz0), 0-based, of a grid
+// Node words live in HBM in 4 x 4 tiles (16 words of 4 bytes, see w_alive: two z-neighbouring tiles per 128-byte line): node
+// (ix0, iz0), 0-based, of a grid
 // with ntz tiles per column of tiles (ceil(nz/4) rounded up to a power of two) is record
 // ((ix0>>2)*ntz + (iz0>>2))*16 + (ix0&3)*4 + (iz0&3).  The stencil of a pop reaches +-3 nodes in both directions: in the
 // reference's column-major order that is 7 columns = 7-8 lines, tiled it is 4-6.  The two coordinates contribute separately, so
@@ -174,12 +176,9 @@ struct Heap {
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
-  void *rec;   // node records (refined grid: Node) or node words (coarse grid: unsigned) of the grid being marched (4 x 4 tiles)
-  // back-pointer store: a band node's slot (W4: the whole word, see w_band)
-  template <bool W4> __device__ __forceinline__ void set_slot(unsigned node, int slot) {
-    if (W4) reinterpret_cast<unsigned *>(rec)[node] = w_band(slot);
-    else reinterpret_cast<Node *>(rec)[node].s = slot;
-  }
+  unsigned *rec;   // node words of the grid being marched (4 x 4 tiles, see w_alive)
+  // back-pointer store: a band node's word is its slot
+  __device__ __forceinline__ void set_slot(unsigned node, int slot) { rec[node] = w_band(slot); }
   int tsh;     // log2 of the record stride between columns of tiles of that grid
   int ntr;
   bool g0;     // lane 0 of the group
@@ -212,7 +211,6 @@ struct Heap {
   // All 16 lanes of the group hold the same (slot, key, node): the LDS entry is written by all of them
   // (same address, same value -- no exec-mask branch inside the sift loops); the HBM back-pointer
   // and spill stores are issued by lane 0 only.
-  template <bool W4>
   __device__ __forceinline__ void put(int slot, float key, int node) {
     if ((SPILL || HYB) && slot >= CAP) {
       if (g0) ovf[slot - CAP] = HEnt{key, node};
@@ -220,17 +218,17 @@ struct Heap {
       keys[slot] = key;
       nodes[slot] = (NT)node;
     }
-    if (g0) set_slot<W4>((unsigned)node, slot);
+    if (g0) set_slot((unsigned)node, slot);
   }
   // sift (key,node) up from slot c.  If `track`, entries that move down are compared with the
   // pending neighbours' node ids so that their slots stay current (nbs[m] for m > from).
-  template <bool TRACK, bool W4>
+  template <bool TRACK>
   __device__ __forceinline__ void sift_up(int c, float key, int node, const int (&nbn)[4], int (&nbs)[4], int from) {
     while (c > 1) {
       const int p = c >> 1;
       const HEnt pe = get(p);
       if (key < pe.key) {
-        put<W4>(c, pe.key, pe.node);
+        put(c, pe.key, pe.node);
         if (TRACK) {
 #pragma unroll
           for (int m = 1; m < 4; m++)
@@ -240,7 +238,7 @@ struct Heap {
       } else
         break;
     }
-    put<W4>(c, key, node);
+    put(c, key, node);
   }
   // addtree / updtree (:738-783, :872-890) for the all-in-LDS heap in ONE LDS round instead of a loop over the levels: lane i of
   // the group reads ancestor c >> (i+1) of the rising entry (a heap of < 4096 slots has at most 11); the entry rises past the
@@ -248,7 +246,6 @@ struct Heap {
   // lane i writes its ancestor into slot c >> i and that node's back-pointer, lane L places the entry itself at c >> L.  Same
   // comparisons, same final array.  Returns L, the number of levels risen (the caller shifts the slots of pending neighbours
   // that sat on the path).  Groups with live == false read and write the dummy slot 0.
-  template <bool W4>
   __device__ __forceinline__ int rise_par(bool live, int gl, int gbase, int c, float key, int node) {
     const int a = c >> (gl + 1);
     const bool valid = live && a >= 1;
@@ -264,7 +261,7 @@ struct Heap {
     const int ldst = dhi ? 0 : dst;
     keys[ldst] = ak;
     nodes[ldst] = an;
-    if (mover) set_slot<W4>((unsigned)an, dst);
+    if (mover) set_slot((unsigned)an, dst);
     const bool last = live && gl == L;
     const int fin = c >> L;
     const bool fhi = HYB && last && fin >= CAP;
@@ -272,10 +269,7 @@ struct Heap {
       keys[fin] = key;
       nodes[fin] = (NT)node;
     }
-    if (last) {
-      if (W4) reinterpret_cast<unsigned *>(rec)[node] = w_band(fin);
-      else reinterpret_cast<Node *>(rec)[node] = Node{key, fin};
-    }
+    if (last) set_slot((unsigned)node, fin);
     if (HYB && __ballot(dhi || fhi) != 0) {
       if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
@@ -283,12 +277,11 @@ struct Heap {
     return L;
   }
   __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= TOT; }
-  template <bool W4>
   __device__ __forceinline__ void add(float key, int node) {
     const int nbn[4] = {0, 0, 0, 0};
     int nbs[4] = {0, 0, 0, 0};
     ntr++;
-    sift_up<false, W4>(ntr, key, node, nbn, nbs, 0);
+    sift_up<false>(ntr, key, node, nbn, nbs, 0);
   }
   // LDS-only write of a heap entry (the HBM back-pointer is deferred by the caller)
   __device__ __forceinline__ void put_lds(int slot, float key, int node) {
@@ -656,37 +649,8 @@ __device__ unsigned long long g_fmm_prof[8];
 #define PROF_FLUSH
 #endif
 
-// experiment switch (tools/exp_fmm_nt.sh): cache-policy hints on the node-record accesses of the marching loop.
-// DZ_FMM_NT bit 0: loads non-temporal, bit 1: stores non-temporal.
-#ifndef DZ_FMM_NT
-#define DZ_FMM_NT 0
-#endif
-__device__ __forceinline__ Node ld_node(const Node *p) {
-#if DZ_FMM_NT & 1
-  const long long v = __builtin_nontemporal_load(reinterpret_cast<const long long *>(p));
-  Node n;
-  n.t = __int_as_float((int)(v & 0xffffffffll));
-  n.s = (int)(v >> 32);
-  return n;
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void st_node(Node *p, Node n) {
-#if DZ_FMM_NT & 2
-  const long long v = ((long long)n.s << 32) | (unsigned)__float_as_int(n.t);
-  __builtin_nontemporal_store(v, reinterpret_cast<long long *>(p));
-#else
-  *p = n;
-#endif
-}
-__device__ __forceinline__ void st_slot(Node *p, int s) {
-#if DZ_FMM_NT & 2
-  __builtin_nontemporal_store(s, &p->s);
-#else
-  p->s = s;
-#endif
-}
+// (Round 3 measured cache-policy hints on the node accesses of the marching loop -- non-temporal loads -17 %, stores -32 %,
+// both -51 %, tools/exp_fmm_nt.sh on the 8-byte records of that time: L2 / Infinity Cache residency carries them.)
 
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
@@ -700,12 +664,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
-  constexpr bool W4 = !REFINED;                            // the coarse grid keeps one word per node (w_alive ...)
-  Node *rec = reinterpret_cast<Node *>(H.rec);              // (REFINED)
-  unsigned *recw = reinterpret_cast<unsigned *>(H.rec);     // (coarse)
-  // one node as the {time, status} pair the code below works with: status 0 alive, -1 far, > 0 heap slot
+  unsigned *recw = H.rec;
+  // one node word as the {time, status} pair the code below works with: status 0 alive, -1 far, > 0 heap slot
   auto ldn = [&](unsigned idx) -> Node {
-    if (!W4) return ld_node(&rec[idx]);
     const unsigned w = recw[idx];
     Node n;
     n.t = __int_as_float((int)w);
@@ -728,16 +689,13 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == 1 && (ex & 4)) swrg = true;
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) rec[iroot].s = 0;                          // (REFINED only: 8-byte records)
-        if (!SPILL && !HYB)   // lazy back-pointers (below): the records of entries that only moved up are behind; nstsr wants them exact
-          for (int i = 2 + gl; i <= H.ntr; i += GP) rec[(unsigned)H.get(i).node].s = i;
+        if (H.g0) recw[iroot] = w_alive(root.key);            // (it stays at slot 1 of the heap; its time is its key)
+        if (!SPILL && !HYB)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
+          for (int i = 2 + gl; i <= H.ntr; i += GP) recw[(unsigned)H.get(i).node] = w_band(i);
         break;
       }
     }
-    if (H.g0) {
-      if (W4) recw[iroot] = w_alive(root.key);              // accepted: the word becomes the time (= the heap key, the trial time)
-      else st_slot(&rec[iroot], 0);
-    }
+    if (H.g0) recw[iroot] = w_alive(root.key);              // accepted: the word becomes the time (= the heap key, the trial time)
     cbar();
     // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
     // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
@@ -798,15 +756,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
                  "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
                  : "memory");
     if (SPILL) {
-      if (gl < nmoves) H.template set_slot<W4>((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
+      if (gl < nmoves) H.set_slot((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
     } else {
       // (LAZY: the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
       if (!LAZY) {
 #pragma unroll
         for (int b = 0; b < NCAP; b++)
-          if (cslot[b] > 0) H.template set_slot<W4>((unsigned)cnode[b], cslot[b]);
+          if (cslot[b] > 0) H.set_slot((unsigned)cnode[b], cslot[b]);
       }
-      if (H.g0 && fin_slot > 0) H.template set_slot<W4>((unsigned)fin_node, fin_slot);
+      if (H.g0 && fin_slot > 0) H.set_slot((unsigned)fin_node, fin_slot);
     }
     if (!nvalid) nself.s = 0;
     if (!vj) nj.s = -1;
@@ -937,10 +895,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         if (f2 && rise) {
           H.keys[pc] = trav;
           H.nodes[pc] = (NT)uself;
-          if (W4) recw[uself] = w_band(pc); else st_node(&rec[uself], Node{trav, pc});
+          recw[uself] = w_band(pc);
           H.keys[c] = pk;
           H.nodes[c] = pn;
-          H.template set_slot<W4>((unsigned)pn, c);
+          H.set_slot((unsigned)pn, c);
         }
       }
       {
@@ -949,9 +907,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
-        if (wr) {
-          if (W4) recw[uself] = w_band(c); else st_node(&rec[uself], Node{trav, c});
-        }
+        if (wr) recw[uself] = w_band(c);
         if (HYB && __ballot(whi) != 0) {
           if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
@@ -1002,7 +958,6 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         for (int n = 0; n < 4; n++) {
           if (nbs[n] == 0 || n < n0) continue;
           const int node = nbn[n];
-          if (!W4 && H.g0) rec[node].t = nbt[n];            // (W4: a band node's time lives in the heap only)
           int c = nbs[n];
           if (c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
             if (H.full()) {
@@ -1012,7 +967,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
             H.ntr++;
             c = H.ntr;
           }
-          H.template sift_up<true, W4>(c, nbt[n], node, nbn, nbs, n);
+          H.template sift_up<true>(c, nbt[n], node, nbn, nbs, n);
         }
       } else {
         // all-in-LDS heap: one parallel round per remaining neighbour, in the reference's order (the four groups of the
@@ -1031,7 +986,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
               c = H.ntr;
             }
           }
-          const int L = H.template rise_par<W4>(live, gl, gbase, c, nbt[n], nbn[n]);
+          const int L = H.rise_par(live, gl, gbase, c, nbt[n], nbn[n]);
           // a pending neighbour whose entry sat on the path moved down one level with it
 #pragma unroll
           for (int m = n + 1; m < 4; m++) {
@@ -1065,7 +1020,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   const int tsh_c = tile_shift(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
   unsigned *rec_c = A.rec_c + slot * nrec_c;
-  Node *rec_r = A.rec_r + slot * NREC_R;
+  unsigned *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * NREC_R;
   Heap<CAP, SPILL, NT, HYB> H;
@@ -1161,7 +1116,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             velnr[idx] = vr;
             const int ti = tile_x(idm2 - 1, TSH_R) + tile_z(idm1 - 1);
             slownr[ti] = 1.0f / vr;
-            rec_r[ti] = Node{0.0f, -1};
+            rec_r[ti] = W_FAR;
           }
         }
         cbar();
@@ -1200,8 +1155,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
               const float t0 = 2.0f * ds / (vss[i - 1][jj - 1] + vsrc);
               const int ux = rsx - 1 + i, uz = rsz - 1 + jj;
               const int urid = tile_x(ux - 1, TSH_R) + tile_z(uz - 1);
-              if (gl == 0) rec_r[urid].t = t0;
-              H.template add<false>(t0, urid);
+              H.add(t0, urid);
             }
         }
         // exit-rule quirk kept verbatim (inv/CalSurfG.f90:366-377): vnr/vnb (coarse indices) are
@@ -1217,10 +1171,17 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
           if (ttnr || nstsr)
             for (int idx = gl; idx < RM * RM; idx += GP) {
               const int c = idx / RM, r = idx - c * RM;
-              Node nd{0.0f, -9};
-              if (c < nnxr && r < nnzr) nd = rec_r[tile_x(c, TSH_R) + tile_z(r)];
-              if (nstsr) nstsr[idx] = nd.s;
-              if (ttnr) ttnr[idx] = nd.s >= 0 ? nd.t : 0.0f;
+              // (a band node's word is its slot; its trial time is the key at that slot of the heap, which is still in place)
+              int st = -9;
+              float tt = 0.0f;
+              if (c < nnxr && r < nnzr) {
+                const unsigned w = rec_r[tile_x(c, TSH_R) + tile_z(r)];
+                if (w_is_alive(w)) { st = 0; tt = __int_as_float((int)w); }
+                else if (w == W_FAR) st = -1;
+                else { st = (int)(w & 0x7fffffffu); tt = H.get(st).key; }
+              }
+              if (nstsr) nstsr[idx] = st;
+              if (ttnr) ttnr[idx] = tt;
             }
           for (int i = gl; i < nrec_c; i += GP) rec_c[i] = W_FAR;
         }
@@ -1229,10 +1190,11 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
         const int bw = bx.vnr - bx.vnl + 1, bh = bx.vnb - bx.vnt + 1, nbox = bw * bh;
         for (int i = gl; i < nbox; i += GP) {
           const int bxi = i / bh, bzi = i - bxi * bh;  // column-major inside the box
-          const Node nd = rec_r[tile_x(bxi * SGDL, TSH_R) + tile_z(bzi * SGDL)];
-          // alive: its time; close (in the refined band when the march stopped): its time, to be put into the coarse heap; far
+          const unsigned w = rec_r[tile_x(bxi * SGDL, TSH_R) + tile_z(bzi * SGDL)];
+          // alive: its time; close (in the refined band when the march stopped): its trial time = the key at its slot, to be put
+          // into the coarse heap; far
           rec_c[tile_x(bx.vnl - 1 + bxi, tsh_c) + tile_z(bx.vnt - 1 + bzi)] =
-              nd.s == 0 ? w_alive(nd.t) : (nd.s > 0 ? w_pending(nd.t) : W_FAR);
+              (w_is_alive(w) || w == W_FAR) ? w : w_pending(H.get((int)(w & 0x7fffffffu)).key);
         }
         cbar();
         // ---- alive nodes touching a far node rejoin the band (inv/CalSurfG.f90:1291-1308).  Only
@@ -1280,7 +1242,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             m &= m - 1;
             const float t0 = __shfl(w_time(w), grp * GP + b);
             const int n0 = __shfl(node, grp * GP + b);
-            if (!H.full()) H.template add<true>(t0, n0); else ovf = true;
+            if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
         if (!ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
@@ -1322,8 +1284,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
   if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(unsigned), &p))) return rc;
   A.rec_c = (unsigned *)p;
-  if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(Node), &p))) return rc;
-  A.rec_r = (Node *)p;
+  if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(unsigned), &p))) return rc;
+  A.rec_r = (unsigned *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;
   if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * 4, &p))) return rc;
