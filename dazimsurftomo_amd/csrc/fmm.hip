@@ -142,8 +142,8 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
 // One heap per 16-lane group.  "Hole" formulation: the moving element stays in registers while
 // displaced entries are copied; the comparisons, and hence the final array, are those of the
 // reference's swap formulation.  Like the reference, the node status in HBM carries a heap slot
-// for every band node (nsts>0) -- exact in the spill and hybrid kernels, written whenever an entry moves;
-// in the all-in-LDS kernel an ancestor-or-self relation of the true slot (lazy back-pointers, see march()).
+// for every band node (nsts>0) -- exact in the spill kernel, written whenever an entry moves; in the kernels with the parallel
+// sift-down (all-in-LDS and hybrid heaps) an ancestor-or-self relation of the true slot (lazy back-pointers, see march()).
 constexpr int GP = 16;   // lanes per field
 constexpr int FPW = 4;   // fields per wavefront
 
@@ -359,19 +359,14 @@ struct Heap {
   // it and all move (per-lane constant masks G/E/A) copies its smaller child into its own slot: same comparisons, same final
   // array as the sequential loop.  A missing child (slot > ntr) reads as +inf, which reproduces the reference's single-child
   // tail.  Two steps empty a heap below 512 slots (every refined grid, grids up to ~170 nodes a side), three one below 8192.
-  // Moves are captured per step (cnode/cslot[b], cslot==0: none) for the deferred back-pointer stores of the hybrid kernel
-  // (the all-in-LDS kernel leaves the records of entries that move up alone: lazy back-pointers, see march()); where a pending
-  // neighbour's entry went is reconstructed by the caller from the final hole position (fin_slot).
+  // The words of the entries that move up are left alone (lazy back-pointers, see march()); the caller stores the slot of the
+  // dropped entry (fin_node at fin_slot).
   static constexpr int NSTEP = CAP <= 32 ? 1 : (CAP <= 512 ? 2 : 3);
-  static constexpr int NCAP = NSTEP + (HYB ? 1 : 0);  // captured moves: one per parallel step (+ the HBM level's)
-  __device__ __forceinline__ void pop_root_par(int lane, const int (&nbn)[4], int (&cnode)[NCAP],
-                                               int (&cslot)[NCAP], int &fin_node, int &fin_slot) {
+  __device__ __forceinline__ void pop_root_par(int lane, int &fin_node, int &fin_slot) {
     static_assert(CAP <= 8192, "pop_root_par covers 13 levels");
     static_assert((CAP & 1) == 0, "pairs of children are read together");
     static_assert(!HYB || (CAP & (CAP - 1)) == 0, "HYB: the LDS part of the heap is whole levels");
     const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
-#pragma unroll
-    for (int b = 0; b < NCAP; b++) cslot[b] = 0;
     fin_slot = 0;
     fin_node = 0;
     if (ntr == 1) {
@@ -438,8 +433,6 @@ struct Heap {
       const int dst = mine ? s : 0;
       keys[dst] = ck;
       nodes[dst] = (NT)cn;
-      cnode[b] = cn;                                       // (the entry's node = its record index, for the back-pointer store)
-      cslot[b] = dst;
       const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
         const int qs = 32 - __clz(mb);                    // deepest parent whose child moved up: the hole is at that child now
@@ -467,10 +460,6 @@ struct Heap {
           if (ck < mvk) {
             keys[p] = ck;
             nodes[p] = (NT)cn;
-            if (g0) {
-              cnode[NSTEP] = cn;
-              cslot[NSTEP] = p;
-            }
             p = 2 * p + (right ? 1 : 0);
           }
         }
@@ -675,6 +664,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   };
   const int tsh = H.tsh;
   bool overflow = false;
+  // lazy back-pointers (see below) wherever the sift-down is the parallel one: the all-in-LDS heap and, since the late round 3,
+  // the hybrid heap of the 342..682-node grids too (S-512: 6 790 -> 7 530 fields/s in a same-box A/B, bit-identical; an entry of
+  // the HBM level that moves up into LDS is found one level above the slot its word holds, one that stays is not found and keeps it)
+  constexpr bool LAZY = !SPILL;
   PROF_DECL;
   while (H.ntr > 0 && !overflow) {
     cbar();
@@ -690,7 +683,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (iz == nnz && (ex & 8)) swrg = true;
       if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
         if (H.g0) recw[iroot] = w_alive(root.key);            // (it stays at slot 1 of the heap; its time is its key)
-        if (!SPILL && !HYB)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
+        if (LAZY)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
           for (int i = 2 + gl; i <= H.ntr; i += GP) recw[(unsigned)H.get(i).node] = w_band(i);
         break;
       }
@@ -734,17 +727,13 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
 #pragma unroll
     for (int n = 0; n < 4; n++) nbm[n] = 0;
     int mynode = 0, myslot = 0, nmoves = 0;
-    const int ntr_old = H.ntr;                               // slot of the entry the pop drops into the hole
-    constexpr int NCAP = Heap<CAP, SPILL, NT, HYB>::NCAP, TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
-    // lazy back-pointers (below) on the all-in-LDS heap; the hybrid heap of the 342..682-node grids keeps the eager stores: with
-    // five workgroups per CU that kernel waits on latencies, not on HBM traffic, and the look-up costs it 3 % (S-512, measured)
-    constexpr bool LAZY = !SPILL && !HYB;
-    int cnode[NCAP], cslot[NCAP], fin_node = 0, fin_slot = 0;
+    constexpr int TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
+    int fin_node = 0, fin_slot = 0;
     PROF(0);
     if (SPILL) {
       H.pop_root(gl, nbn, nbm, mynode, myslot, nmoves);
     } else {
-      H.pop_root_par(lane, nbn, cnode, cslot, fin_node, fin_slot);
+      H.pop_root_par(lane, fin_node, fin_slot);
       cbar();
     }
     PROF(1);
@@ -758,12 +747,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     if (SPILL) {
       if (gl < nmoves) H.set_slot((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
     } else {
-      // (LAZY: the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
-      if (!LAZY) {
-#pragma unroll
-        for (int b = 0; b < NCAP; b++)
-          if (cslot[b] > 0) H.set_slot((unsigned)cnode[b], cslot[b]);
-      }
+      // (the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
       if (H.g0 && fin_slot > 0) H.set_slot((unsigned)fin_node, fin_slot);
     }
     if (!nvalid) nself.s = 0;
@@ -796,14 +780,6 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     if (vj && vk && nself.s != 0) trav = quadrant_time(vel, risti, dnx, dnz, nj, nj2, nk, nk2, vj2, vk2);
     trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
     trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
-    if (!SPILL && !LAZY && stfix > 1 && fin_slot > 0) {
-      // eager back-pointers, loaded before the sift-down: did it move this neighbour's entry?  The hole went from slot 1 down to
-      // fin_slot and every entry on that path moved up one level, so an entry moved iff its old slot is fin_slot or one of its
-      // ancestors (except the root); the last entry of the old heap is the one that was dropped into the hole.
-      const int dP = 31 - __clz(fin_slot), ds = 31 - __clz(stfix);
-      if (stfix == ntr_old) stfix = fin_slot;
-      else if (ds <= dP && (fin_slot >> (dP - ds)) == stfix) stfix >>= 1;
-    }
     if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
       int found = 64;
       {

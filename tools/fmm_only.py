@@ -10,6 +10,13 @@ nx = ny = int(os.environ.get('NX','54')); kmax = 16; nsrc = int(sys.argv[1]) if 
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 pv = synth.phase_velocity_maps(nx, ny, kmax)
 lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc, shrink=float(os.environ.get('SHRINK','0.3')))
+mind = float(os.environ.get('MINDIST', '0'))   # keep only sources at least this far (Chebyshev, in grid sizes) from the centre
+if mind > 0:
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc * 20, shrink=float(os.environ.get('SHRINK','0.3')))
+    clat, clon = 30.0 - (nx - 3) * 0.125, 100.0 + (ny - 3) * 0.125
+    d = np.maximum(np.abs(lat - clat) / ((nx - 3) * 0.25), np.abs(lon - clon) / ((ny - 3) * 0.25))
+    keep = np.where(d >= mind)[0][:nsrc]
+    lat, lon = lat[keep], lon[keep]; nsrc = len(lat)
 sx, sz = synth.radians(lat, lon)
 scx = np.tile(sx, kmax); scz = np.tile(sz, kmax); per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
 nf = len(scx)
