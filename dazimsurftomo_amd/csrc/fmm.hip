@@ -78,6 +78,14 @@ struct FmmArgs {
   unsigned *counter;
   const int *flist;  // nullable: indirection used by the spill rerun
   int fpw;           // fields a wavefront takes per batch (1, 2 or FPW = 4 of its 16-lane groups are active): see run_fmm
+  // time slicing (see fmm_kernel): a field is marched in ts_nstage tasks -- stage 0 = refined march + injection, stages 1.. =
+  // ts_pops accepted nodes of the coarse march each (the last one: to the end) -- that may run on different workgroups
+  int ts_nstage;     // 1: the whole field in one task (rec_c / ovf are per resident slot); > 1: rec_c / ovf / the arrays below per field
+  int ts_pops;
+  unsigned *ts_flag; // [batches] stages of the batch that are complete
+  float *ts_keys;    // [nfield][CAP] heap image between two stages (LDS part)
+  int *ts_nodes;     // [nfield][CAP]
+  int *ts_ntr;       // [nfield] entries in that heap; <= 0: the field is finished
 };
 
 // cubic B-spline basis, inv/CalSurfG.f90:1472-1475
@@ -647,7 +655,7 @@ __device__ unsigned long long g_fmm_prof[8];
 template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED>
 __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
-                                      int ex, int lane) {
+                                      int ex, int lane, int maxpop = 0x7fffffff) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
   const int nb = gl >> 2, q = gl & 3;
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
@@ -669,7 +677,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   // the HBM level that moves up into LDS is found one level above the slot its word holds, one that stays is not found and keeps it)
   constexpr bool LAZY = !SPILL;
   PROF_DECL;
-  while (H.ntr > 0 && !overflow) {
+  int npop = 0;
+  while (H.ntr > 0 && !overflow && npop < maxpop) {
+    npop++;
     cbar();
     PROF(7);
     const HEnt root = H.get(1);
@@ -995,15 +1005,25 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
   const int tsh_c = tile_shift(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
-  unsigned *rec_c = A.rec_c + slot * nrec_c;
   unsigned *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * NREC_R;
   Heap<CAP, SPILL, NT, HYB> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
-  H.ovf = A.ovf + slot * A.ovfcap;
   H.g0 = gl == 0;
+  // Time slicing (round 3, late).  A field is one serial chain of pops and all fields are equally long, so a launch lasts a whole
+  // number of rounds of one field's latency at the occupancy of that round: S-256's 16 000 fields on 13 312 resident slots would
+  // run one full round and a second one with a fifth of the chip busy.  With ts_nstage > 1 a field is marched in stages that
+  // any workgroup may pick up -- stage 0 = refined march, injection and the coarse band; stages 1.. = ts_pops accepted nodes of
+  // the coarse march each, the last one to the end.  Between two stages the LDS part of the heap and its size go to HBM, node
+  // words and the heap's HBM level are per field anyway then.  Tasks are handed out stage-major inside each XCD range, so a
+  // task's predecessor (same batch, previous stage) was handed out a whole generation earlier and a workgroup only ever
+  // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
+  // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
+  const int nstage = SPILL ? 1 : A.ts_nstage;
+  const bool ts = nstage > 1;
+  unsigned &s_stage = *reinterpret_cast<unsigned *>(&s_keys[1][0]);   // (the dummy slot of the second field, like s_base)
 
   // Work queue: the field list (sorted by period on the host) is cut into eight contiguous ranges, one per XCD (workgroup b
   // runs on XCD b % 8), so that the fields an XCD marches share one or two velocity grids and these stay in that XCD's L2;
@@ -1017,9 +1037,16 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
       unsigned found = 0xffffffffu;
       for (int tried = 0; tried < 8; tried++) {
         const unsigned c0 = (nquad * (unsigned)chunk >> 3) * fpw, c1 = (nquad * (unsigned)(chunk + 1) >> 3) * fpw;
-        const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], fpw) : 0xffffffffu;
-        if (b < c1 - c0) {
-          found = c0 + b;
+        const unsigned nbr = (c1 - c0) / fpw;                       // batches of this range; tasks: stage-major
+        const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], 1u) : 0xffffffffu;
+        if (b < nbr * (unsigned)nstage) {
+          const unsigned stg = b / nbr;
+          found = c0 + (b - stg * nbr) * fpw;
+          s_stage = stg;
+          if (stg > 0) {   // its predecessor (same batch, previous stage) must have handed its state over
+            const unsigned *flag = A.ts_flag + found / fpw;
+            while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < stg) __builtin_amdgcn_s_sleep(20);
+          }
           break;
         }
         chunk = (chunk + 1) & 7;
@@ -1029,8 +1056,50 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
     __syncthreads();
     const unsigned fbase = s_base;
     if (fbase == 0xffffffffu) break;
+    const int stage = ts ? (int)s_stage : 0;
+    if (stage > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // acquire side for the lanes that did not spin
     const int q = (int)fbase + grp;
-    if (grp < (int)fpw && q < A.nfield) {
+    // node words of the coarse grid and the heap's HBM level: per resident slot, or per field when stages change hands
+    unsigned *rec_c = A.rec_c + (ts ? (size_t)q : slot) * nrec_c;
+    H.ovf = A.ovf + (ts ? (size_t)q : slot) * A.ovfcap;
+    if (grp < (int)fpw && q < A.nfield && stage > 0) {
+      // ---- a later stage: take the heap over, go on marching, hand it on or finish ----
+      const int f = A.flist ? A.flist[q] : q;
+      const int n0 = A.ts_ntr[q];
+      if (n0 > 0) {
+        const int per = A.period[f] - 1;
+        const int nl = n0 < CAP ? n0 : CAP - 1;
+        for (int i = 1 + gl; i <= nl; i += GP) {
+          H.keys[i] = A.ts_keys[(size_t)q * CAP + i];
+          H.nodes[i] = (NT)A.ts_nodes[(size_t)q * CAP + i];
+        }
+        H.ntr = n0;
+        H.rec = rec_c;
+        H.tsh = tsh_c;
+        cbar();
+        const bool ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane,
+                                                            stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
+        cbar();
+        if (ovf) {
+          if (gl == 0) { A.status[f] = -2; A.ts_ntr[q] = -1; }
+        } else if (H.ntr == 0) {
+          float *ttn = A.ttn + (size_t)f * nn;
+          for (int cx = 0; cx < nnx; cx++) {
+            const int tx = tile_x(cx, tsh_c);
+            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);
+          }
+          if (gl == 0) A.ts_ntr[q] = -1;
+        } else {
+          const int ns = H.ntr < CAP ? H.ntr : CAP - 1;
+          for (int i = 1 + gl; i <= ns; i += GP) {
+            A.ts_keys[(size_t)q * CAP + i] = H.keys[i];
+            A.ts_nodes[(size_t)q * CAP + i] = (int)H.nodes[i];
+          }
+          if (gl == 0) A.ts_ntr[q] = H.ntr;
+        }
+      }
+    }
+    if (grp < (int)fpw && q < A.nfield && stage == 0) {
       const int f = A.flist ? A.flist[q] : q;   // the four groups run the same phases on their own field (SIMT across groups)
       const float scx = A.scx[f], scz = A.scz[f];
       const int per = A.period[f] - 1;
@@ -1042,6 +1111,7 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
       if (gl == 0) A.status[f] = outside ? DAZIM_E_SOURCE_OUTSIDE : 0;
       if (outside) {
         for (int i = gl; i < nn; i += GP) ttn[i] = 0.0f;
+        if (ts && gl == 0) A.ts_ntr[q] = -1;
       } else {
         const double *pv = A.pv + (size_t)per * (g.nvz + 2) * (g.nvx + 2);
         const float *veln = A.veln + (size_t)per * nn;
@@ -1221,17 +1291,31 @@ __global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
             if (!H.full()) H.add(t0, n0); else ovf = true;
           }
         }
-        if (!ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (ts && !ovf) {   // the coarse band is built: hand the heap to stage 1
+          const int ns = H.ntr < CAP ? H.ntr : CAP - 1;
+          for (int i = 1 + gl; i <= ns; i += GP) {
+            A.ts_keys[(size_t)q * CAP + i] = H.keys[i];
+            A.ts_nodes[(size_t)q * CAP + i] = (int)H.nodes[i];
+          }
+          if (gl == 0) A.ts_ntr[q] = H.ntr;
+        }
+        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
-        } else {
+          if (ts && gl == 0) A.ts_ntr[q] = -1;
+        } else if (!ts || H.ntr == 0) {   // (time-sliced: only if the box left no band at all -- the later stages find nothing to do)
           for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
             const int tx = tile_x(cx, tsh_c);
             for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);   // all alive
           }
         }
       }
+    }
+    if (ts) {   // hand the batch to its next stage: everything this task stored, then the flag
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __syncthreads();
+      if (lane == 0) __hip_atomic_store(A.ts_flag + fbase / fpw, (unsigned)stage + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -1258,15 +1342,45 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
   A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
-  if ((rc = dz_scratch(ctx, "fmm.rec_c", (size_t)nslot * tile_records(A.g.nnx, A.g.nnz) * sizeof(unsigned), &p))) return rc;
+  // Time slicing (see fmm_kernel): on when the batch does not fit the resident slots (more than one round) and the per-field node
+  // words fit comfortably; option fmm.ts = 1 / 2 forces it on / off (0: this rule), fmm.ts_stages sets the number of coarse stages.
+  // Every hand-over costs two agent-scope fences (L2 write-back / invalidate on the XCD), so few stages are best: S-256's 16 000
+  // fields on the 512-slot hybrid heap take 0.240 / 0.253 / 0.248 / 0.249 / 0.252 s with 2 / 3 / 4 / 8 / 12 coarse stages
+  // (0.288 s unsliced on the 768-slot heap, same box), the 768-slot heap 0.292 / 0.264 / 0.262 s with 2 / 4 / 8-12.
+  bool ts = nfield > nslot;
+  if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 1) ts = true;
+  if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 2) ts = false;
+  const size_t rec_field_bytes = (size_t)tile_records(A.g.nnx, A.g.nnz) * sizeof(unsigned);
+  {
+    size_t mfree = 0, mtot = 0;
+    if (hipMemGetInfo(&mfree, &mtot) != hipSuccess || (size_t)nfield * rec_field_bytes > mfree / 4) ts = false;
+  }
+  int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (HYB ? 2 : 4);
+  A.ts_nstage = ts ? 1 + nseg : 1;
+  A.ts_pops = (int)((nn + nseg - 1) / nseg);
+  ctx->ksec["fmm.ts_stages"] = ts ? (double)nseg : 0.0;
+  const size_t nown = ts ? (size_t)nfield : (size_t)nslot;   // owners of node words / HBM heap levels: fields or resident slots
+  if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
   A.rec_c = (unsigned *)p;
+  A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr; A.ts_ntr = nullptr;
+  if (ts) {
+    if ((rc = dz_scratch(ctx, "fmm.ts_flag", ((size_t)nfield / A.fpw + 2) * 4, &p))) return rc;
+    A.ts_flag = (unsigned *)p;
+    DZ_HIP(hipMemsetAsync(A.ts_flag, 0, ((size_t)nfield / A.fpw + 2) * 4, ctx->stream));
+    if ((rc = dz_scratch(ctx, "fmm.ts_keys", (size_t)nfield * CAP * 4, &p))) return rc;
+    A.ts_keys = (float *)p;
+    if ((rc = dz_scratch(ctx, "fmm.ts_nodes", (size_t)nfield * CAP * 4, &p))) return rc;
+    A.ts_nodes = (int *)p;
+    if ((rc = dz_scratch(ctx, "fmm.ts_ntr", (size_t)nfield * 4 + 16, &p))) return rc;
+    A.ts_ntr = (int *)p;
+  }
   if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(unsigned), &p))) return rc;
   A.rec_r = (unsigned *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;
   if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * 4, &p))) return rc;
   A.slownr = (float *)p;
-  if ((rc = dz_scratch(ctx, "fmm.ovf", (size_t)nslot * A.ovfcap * sizeof(HEnt) + 64, &p))) return rc;
+  if ((rc = dz_scratch(ctx, "fmm.ovf", nown * A.ovfcap * sizeof(HEnt) + 64, &p))) return rc;
   A.ovf = (HEnt *)p;
   if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
   A.counter = (unsigned *)p;
@@ -1334,6 +1448,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     A.nfield = (int)redo.size();
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
     A.fpw = FPW;
+    A.ts_nstage = 1;
     int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
     if (nwg2 > nwg) nwg2 = nwg;
     // the spill kernel keeps every slot >= CAP in HBM: maxbt entries per resident field, allocated only when a field needs it
@@ -1460,8 +1575,16 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0) cap = ctx->opts["fmm.cap"];
     std::vector<int> hs(nfield);
     const bool small = g.nnx <= 256 && g.nnz <= 256;   // node id fits 16 bits
+    bool use_hyb512 = cap > 512 && nfield > ctx->num_cu * 8 * FPW;
+    if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 1) use_hyb512 = true;
+    if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 2) use_hyb512 = false;
     if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    // grids of 171 .. 256 nodes a side (S-256) with more fields than the 768-slot heaps hold at once (8 workgroups of 4 per CU):
+    // levels 1-9 in LDS + level 10 in HBM -- 12 workgroups per CU, a third wavefront per SIMD, and time slicing (run_fmm) keeps
+    // them all busy to the end.  The 13 % of the fields whose band outgrows 511 entries pay for the HBM level (-17 % at equal
+    // occupancy), so batches that fit the 768-slot heaps stay there.  Option fmm.hyb512 = 1 / 2 forces it on / off.
+    else if (cap <= 768 && small && use_hyb512) rc = run_fmm<512, unsigned short, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     // grids of 342 .. 682 nodes a side (S-512): levels 1-10 in LDS + level 11 in HBM, four instead of three workgroups per CU

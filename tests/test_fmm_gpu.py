@@ -178,3 +178,64 @@ def test_fmm_heap_spill_paths(ctx, orc):
         ctx.set_option("fmm.force_spill", 0)
     _run_case(ctx, orc, 17, 17, 1, 3, seed=10, goxd=26.5, gozd=101.25)
     assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+
+
+def test_fmm_time_sliced_marches(ctx, orc):
+    """time slicing (a field marched in stages that different workgroups pick up, heap and node words handed over through HBM)
+    is switched on by the library only for batches larger than the resident slots; forced here on small batches, with 1, 3 and
+    7 coarse stages, on the all-LDS heap (71 x 71, 126 x 126, 256 x 256), the 512-slot hybrid heap of large S-256 batches and
+    the 1024-slot hybrid heap of S-512 with central sources -- bit-exact fields throughout, refined outputs included"""
+    try:
+        ctx.set_option("fmm.ts", 1)
+        for stages in (1, 3, 7):
+            ctx.set_option("fmm.ts_stages", stages)
+            _run_case(ctx, orc, 17, 17, 3, 12, seed=3, goxd=26.5, gozd=101.25, edge_sources=True)
+            assert ctx.kernel_seconds("fmm.ts_stages") == stages
+        ctx.set_option("fmm.ts_stages", 0)
+        _run_case(ctx, orc, 28, 28, 3, 5, seed=13, edge_sources=True)
+        _run_case(ctx, orc, 54, 54, 2, 6, seed=5)
+        ctx.set_option("fmm.hyb512", 1)
+        _run_case(ctx, orc, 54, 54, 2, 6, seed=5)
+        _run_case(ctx, orc, 54, 54, 1, 6, seed=6, shrink=5.0)          # central sources: bands beyond the 511 LDS slots
+        _run_case(ctx, orc, 28, 28, 2, 6, seed=78, rough=True)
+        ctx.set_option("fmm.hyb512", 0)
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+        ctx.set_option("fmm.cap", 64)                                   # overflowing fields are flagged in stage 0 or later and redone
+        _run_case(ctx, orc, 17, 17, 2, 6, seed=8, goxd=26.5, gozd=101.25)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 12
+    finally:
+        ctx.set_option("fmm.cap", 0)
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.ts_stages", 0)
+        ctx.set_option("fmm.hyb512", 0)
+
+
+def test_fmm_large_batch_takes_the_time_sliced_hybrid_path(ctx, orc):
+    """a batch larger than the resident slots of the 768-slot heaps (S-256 with 12 288 + fields) is what the library time-slices
+    on the 512-slot hybrid heap by itself: sampled fields of such a batch against the oracle, and the whole batch against the
+    unsliced 768-slot kernel"""
+    nx = ny = 54
+    kmax, nsrc = 16, 800
+    pv = synth.phase_velocity_maps(nx, ny, kmax)
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc, seed=4)
+    sx, sz = synth.radians(lat, lon)
+    scx, scz = np.tile(sx, kmax), np.tile(sz, kmax)
+    per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
+    out = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx, scz, per, want_refined=False)
+    assert ctx.kernel_seconds("fmm.ts_stages") > 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 12
+    try:
+        ctx.set_option("fmm.ts", 2)
+        ctx.set_option("fmm.hyb512", 2)
+        ref = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx, scz, per, want_refined=False)
+        assert ctx.kernel_seconds("fmm.ts_stages") == 0
+    finally:
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.hyb512", 0)
+    assert np.array_equal(out["ttn"], ref["ttn"])
+    g = orc.geometry(nx, ny, 30.0, 100.0, 0.25, 0.25)
+    for f in (0, 799, 6400, 12799):
+        k = f // nsrc
+        veln = orc.gridder(g, pv[k])
+        rc, ttn, *_ = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
+        assert rc == 0 and np.array_equal(out["ttn"][f], ttn)
