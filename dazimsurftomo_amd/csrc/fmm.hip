@@ -991,8 +991,13 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
   return overflow;
 }
 
+#ifdef DZ_FMM_WPE   // experiment: register budget for DZ_FMM_WPE wavefronts per SIMD
+#define FMM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(DZ_FMM_WPE, DZ_FMM_WPE)))
+#else
+#define FMM_WPE_ATTR
+#endif
 template <int CAP, bool SPILL, class NT, bool HYB>
-__global__ __launch_bounds__(64) void fmm_kernel(FmmArgs A) {
+__global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
   // (rows padded so that the four fields sit eight LDS banks apart -- they are walked in step, and CAP is a multiple of the 32
