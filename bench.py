@@ -475,6 +475,7 @@ def main():
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
         lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
+        stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
@@ -555,16 +556,18 @@ def main():
                                    f"{'per GPU' if a.scaling == 'weak' else 'in total, sharded'} x "
                                    f"{rays_per_field} receivers (rank 0: {nfield} fields, {nray} rays), "
                                    f"{a.lsmr_iters} LSMR iterations", "fields_per_gpu": nfield, "rays_per_gpu": nray},
-            # the dominant kernel.  It is bound by the serial heap order of fast marching (instruction issue + small random record
-            # accesses), not by HBM bandwidth: `bound` says so; the HBM fraction of its algorithmic bytes is still reported
+            # the dominant kernel.  It is bound by the serial heap order of fast marching (VALU instruction issue), not by HBM
+            # bandwidth; the HBM fraction of its algorithmic bytes is still reported
             # (achieved / peak / frac) because the metric asks for it, next to what the kernel is really limited by (pops/s).
             "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fmm_gbs / HBM_PEAK_GBS, "traffic": traffic["fmm"],
                          "node_acceptances_per_s": pops / stats["fmm_s"],
                          "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
                          "traffic_source": traffic_src,
-                         "note": "bound by the rate of cache-missing 64-128-byte accesses to the node records (a serial chain of heap "
-                                 "pops per field, all parallelism across fields; `traffic` is what really moves, DESIGN.md 4); "
+                         "note": "VALU-issue bound since the time-sliced marches keep three wavefronts per SIMD busy to the end of the "
+                                 "batch (SQ_ACTIVE_INST_VALU ~ every SIMD cycle, profiles/r3_sq_counters.md): a serial chain of heap "
+                                 "pops per field, ~410 VALU instructions per pop of four fields, all parallelism across fields; "
+                                 "`traffic` is what really moves (DESIGN.md 4); "
                                  f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
                                  "FETCH_SIZE + WRITE_SIZE per launch (8-byte accesses: raw counter values, the gfx950 x2 read "
                                  "correction is only calibrated for 16-byte streams)"},
@@ -588,6 +591,8 @@ def main():
                            else ("every rank computes the whole model's tables" if use_dist else "single GPU")),
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
+            "fmm_schedule": {"workgroups_per_cu": int(stats["fmm_wg_per_cu"]), "time_sliced_coarse_stages": int(stats["fmm_ts_stages"]),
+                             "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],
         }
         if not a.no_cpu and world == 1:      # the CPU baseline is timed on rank 0 of the single-GPU run only

@@ -496,6 +496,9 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
 // so every chunk boundary adds the wait for the slowest lane (+15 % at one round's worth of work) and eats what the shorter
 // tail saves.  The default is therefore one chunk (pchunk = kmax); option "disp.pchunk" selects shorter ones (bit-identical
 // results: tests/test_disp_gpu.py).
+#ifdef DZ_DISP_STAT
+__device__ unsigned long long g_disp_stat[4];
+#endif
 template <int RDEN>
 __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
@@ -599,7 +602,14 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     double ceval = c1;
     bool failed = false;
 
+#ifdef DZ_DISP_STAT
+    unsigned long long st_iter = 0, st_act = 0;
+#endif
     while (__any(phase != P_DONE)) {
+#ifdef DZ_DISP_STAT
+      st_iter++;
+      if (phase != P_DONE) st_act++;
+#endif
       const double del = dltar4<RDEN>(K, s_lay, mmax, nz, fast, omega / ceval, omega, A.exp3 != 0);
       if (phase == P_DONE) continue;
       bool advance_bracket = false, nev_top = false, nev_body = false, finish = false, fail = false;
@@ -773,6 +783,17 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
         phase = P_DONE;
       }
     }
+#ifdef DZ_DISP_STAT
+    {   // lane-evaluations done / offered by the wavefront / offered by the workgroup (its slowest wavefront)
+      __shared__ unsigned long long s_wmax;
+      if (tid == 0) s_wmax = 0;
+      __syncthreads();
+      atomicAdd(&g_disp_stat[0], st_act);
+      if ((tid & 63) == 0) { atomicAdd(&g_disp_stat[1], st_iter * 64ull); atomicMax(&s_wmax, st_iter); }
+      __syncthreads();
+      if (tid == 0) atomicAdd(&g_disp_stat[2], s_wmax * (unsigned long long)DT);
+    }
+#endif
     if (active && kend < kmax && !(chunk > 0 && A.st_f[wi])) {   // hand the chain to the next chunk
       A.st_c[wi] = cprev;
       A.st_d[wi] = del1st;
@@ -986,6 +1007,16 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   int nfail = 0;
   unsigned hst[4] = {0, 0, 0, 0};
   DZ_HIP(hipMemcpyAsync(&nfail, d_nfail, 4, hipMemcpyDeviceToHost, ctx->stream));
+#ifdef DZ_DISP_STAT
+  {
+    unsigned long long h[4];
+    DZ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_disp_stat), sizeof h));
+    fprintf(stderr, "disp stat: lane-evaluations done %llu, offered by the wavefronts %llu (%.3f used), by the workgroups %llu (%.3f used)\n", h[0], h[1],
+            (double)h[0] / (double)h[1], h[2], (double)h[0] / (double)h[2]);
+    unsigned long long z[4] = {0};
+    DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_disp_stat), z, sizeof z));
+  }
+#endif
   DZ_HIP(hipMemcpyAsync(hst, A.ff_stat, 16, hipMemcpyDeviceToHost, ctx->stream));
   if ((rc = pv.finish()) || (rc = svs.finish()) || (rc = svp.finish()) || (rc = srho.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
