@@ -81,11 +81,13 @@ struct FmmArgs {
   // time slicing (see fmm_kernel): a field is marched in ts_nstage tasks -- stage 0 = refined march + injection, stages 1.. =
   // ts_pops accepted nodes of the coarse march each (the last one: to the end) -- that may run on different workgroups
   int ts_nstage;     // 1: the whole field in one task (rec_c / ovf are per resident slot); > 1: rec_c / ovf / the arrays below per field
-  int ts_pops;
+  int ts_pops;       // accepted nodes per coarse stage (the last stage runs to the end)
   unsigned *ts_flag; // [batches] stages of the batch that are complete
   float *ts_keys;    // [nfield][CAP] heap image between two stages (LDS part)
-  int *ts_nodes;     // [nfield][CAP]
-  int *ts_ntr;       // [nfield] entries in that heap; <= 0: the field is finished
+  int *ts_nodes;     // [nfield][CAP]; [..][0] = entries in that heap, <= 0: the field is finished.  (Everything a stage hands over
+                     // lives in lines that belong to ONE field: fields change hands between XCDs, each with its own L2, and a
+                     // line that two of them write -- a packed array of sizes was the first form -- can sit partly dirty in one L2
+                     // while the other's update is in memory: a stale size, one wrong field in 10^5 hand-overs)
 };
 
 // cubic B-spline basis, inv/CalSurfG.f90:1472-1475
@@ -783,7 +785,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     int lz_id0 = 0;
     if (LAZY) {   // k = q first: an entry rarely moves up more than three levels between two stores of its slot
       const int a = band ? (srec >> q) : 0;
-      lz_id0 = (int)H.nodes[(a >= 1 && (!HYB || a < CAP)) ? a : 0];
+      // (only slots 1 .. ntr are entries: a recorded slot may lie beyond the heap's present end, and what sits there is stale --
+      // after a time-sliced hand-over even another field's entries, whose ids can coincide with this neighbour's)
+      lz_id0 = (int)H.nodes[((unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP)) ? a : 0];
     }
     float trav = INFINITY;
     PROF(3);
@@ -794,7 +798,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       int found = 64;
       {
         const int a = band ? (srec >> q) : 0;
-        if (a >= 1 && (!HYB || a < CAP) && lz_id0 == (int)uself) found = q;
+        if ((unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP) && lz_id0 == (int)uself) found = q;
       }
       { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
       { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
@@ -808,7 +812,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         for (int t = 1; t < LT; t++) {
           const int k = q + 4 * t;
           const int a = band ? (srec >> k) : 0;
-          const bool ok = a >= 1 && (!HYB || a < CAP);
+          const bool ok = (unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP);
           const int id = (int)H.nodes[ok ? a : 0];
           if (ok && id == (int)uself) found = found < k ? found : k;
         }
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
     if (grp < (int)fpw && q < A.nfield && stage > 0) {
       // ---- a later stage: take the heap over, go on marching, hand it on or finish ----
       const int f = A.flist ? A.flist[q] : q;
-      const int n0 = A.ts_ntr[q];
+      const int n0 = A.ts_nodes[(size_t)q * CAP];
       if (n0 > 0) {
         const int per = A.period[f] - 1;
         const int nl = n0 < CAP ? n0 : CAP - 1;
@@ -1086,21 +1090,21 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
                                                             stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
         cbar();
         if (ovf) {
-          if (gl == 0) { A.status[f] = -2; A.ts_ntr[q] = -1; }
+          if (gl == 0) { A.status[f] = -2; A.ts_nodes[(size_t)q * CAP] = -1; }
         } else if (H.ntr == 0) {
           float *ttn = A.ttn + (size_t)f * nn;
           for (int cx = 0; cx < nnx; cx++) {
             const int tx = tile_x(cx, tsh_c);
             for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);
           }
-          if (gl == 0) A.ts_ntr[q] = -1;
+          if (gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
         } else {
           const int ns = H.ntr < CAP ? H.ntr : CAP - 1;
           for (int i = 1 + gl; i <= ns; i += GP) {
             A.ts_keys[(size_t)q * CAP + i] = H.keys[i];
             A.ts_nodes[(size_t)q * CAP + i] = (int)H.nodes[i];
           }
-          if (gl == 0) A.ts_ntr[q] = H.ntr;
+          if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
       }
     }
@@ -1116,7 +1120,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
       if (gl == 0) A.status[f] = outside ? DAZIM_E_SOURCE_OUTSIDE : 0;
       if (outside) {
         for (int i = gl; i < nn; i += GP) ttn[i] = 0.0f;
-        if (ts && gl == 0) A.ts_ntr[q] = -1;
+        if (ts && gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
       } else {
         const double *pv = A.pv + (size_t)per * (g.nvz + 2) * (g.nvx + 2);
         const float *veln = A.veln + (size_t)per * nn;
@@ -1302,13 +1306,13 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
             A.ts_keys[(size_t)q * CAP + i] = H.keys[i];
             A.ts_nodes[(size_t)q * CAP + i] = (int)H.nodes[i];
           }
-          if (gl == 0) A.ts_ntr[q] = H.ntr;
+          if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
         if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
-          if (ts && gl == 0) A.ts_ntr[q] = -1;
+          if (ts && gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
         } else if (!ts || H.ntr == 0) {   // (time-sliced: only if the box left no band at all -- the later stages find nothing to do)
           for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
             const int tx = tile_x(cx, tsh_c);
@@ -1362,12 +1366,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   }
   int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (HYB ? 2 : 4);
   A.ts_nstage = ts ? 1 + nseg : 1;
+  // (stage lengths that shrink towards the end -- a shorter tail -- were measured and lose: 0.251-0.265 s against 0.247 s)
   A.ts_pops = (int)((nn + nseg - 1) / nseg);
   ctx->ksec["fmm.ts_stages"] = ts ? (double)nseg : 0.0;
   const size_t nown = ts ? (size_t)nfield : (size_t)nslot;   // owners of node words / HBM heap levels: fields or resident slots
   if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
   A.rec_c = (unsigned *)p;
-  A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr; A.ts_ntr = nullptr;
+  A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr;
   if (ts) {
     if ((rc = dz_scratch(ctx, "fmm.ts_flag", ((size_t)nfield / A.fpw + 2) * 4, &p))) return rc;
     A.ts_flag = (unsigned *)p;
@@ -1376,8 +1381,6 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     A.ts_keys = (float *)p;
     if ((rc = dz_scratch(ctx, "fmm.ts_nodes", (size_t)nfield * CAP * 4, &p))) return rc;
     A.ts_nodes = (int *)p;
-    if ((rc = dz_scratch(ctx, "fmm.ts_ntr", (size_t)nfield * 4 + 16, &p))) return rc;
-    A.ts_ntr = (int *)p;
   }
   if ((rc = dz_scratch(ctx, "fmm.rec_r", (size_t)nslot * NREC_R * sizeof(unsigned), &p))) return rc;
   A.rec_r = (unsigned *)p;

@@ -239,3 +239,49 @@ def test_fmm_large_batch_takes_the_time_sliced_hybrid_path(ctx, orc):
         veln = orc.gridder(g, pv[k])
         rc, ttn, *_ = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
         assert rc == 0 and np.array_equal(out["ttn"][f], ttn)
+
+
+def test_fmm_time_sliced_many_hand_overs(ctx):
+    """the S-256 bench batch (16 000 fields) through the 512-slot hybrid heap in 16 stages each -- a quarter of a million
+    hand-overs between workgroups whose LDS still holds other fields' heaps -- three times, and once through the 768-slot
+    heaps, against the unsliced 768-slot kernel: every traveltime identical (compared on the device).  (The slot look-up of
+    the lazy back-pointers must not take a stale LDS slot beyond the heap's end for an entry -- after a hand-over such slots hold
+    another field's node ids, which can coincide with the neighbour looked for: before the bound on the look-up about one field
+    in 40 000 came out wrong, 7 runs of 18 in tools/stress_ts.sh.)"""
+    import torch
+    nx = ny = 54
+    kmax, nsrc = 16, 1000
+    dev = torch.device("cuda:0")
+    pv = synth.phase_velocity_maps(nx, ny, kmax)
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc, seed=9)
+    sx, sz = synth.radians(lat, lon)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_pv, d_scx, d_scz = t(pv), t(np.tile(sx, kmax)), t(np.tile(sz, kmax))
+    d_per = t(np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc))
+    nf = kmax * nsrc
+
+    def run():
+        ttn = torch.empty((nf, 256, 256), dtype=torch.float32, device=dev)
+        st = torch.empty((nf,), dtype=torch.int32, device=dev)
+        ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, d_pv, d_scx, d_scz, d_per, ttn=ttn, status=st)
+        assert int(st.abs().sum()) == 0
+        return ttn
+    try:
+        ctx.set_option("fmm.ts", 2)
+        ctx.set_option("fmm.hyb512", 2)
+        ref = run()
+        assert ctx.kernel_seconds("fmm.ts_stages") == 0
+        ctx.set_option("fmm.ts", 1)
+        ctx.set_option("fmm.ts_stages", 15)
+        for hyb in (1, 1, 1, 2):
+            ctx.set_option("fmm.hyb512", hyb)
+            out = run()
+            assert ctx.kernel_seconds("fmm.ts_stages") == 15
+            if not torch.equal(out, ref):
+                bad = torch.nonzero((out != ref).reshape(nf, -1).any(dim=1)).flatten()[:10].tolist()
+                raise AssertionError(f"hyb512={hyb}: fields {bad} differ from the unsliced kernel")
+            del out
+    finally:
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.ts_stages", 0)
+        ctx.set_option("fmm.hyb512", 0)
