@@ -85,6 +85,10 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * that the rays a wavefront traces in lockstep have similar lengths; results do not depend on it).
  * "fmm.sort": 0 = fields of a period marched in input order (default: by how central the source is; speed only).
  * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
+ * "fmm.ts": 1 / 2 = march every batch in stages that any workgroup may continue (time slicing) / never
+ * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
+ * the 512-slot hybrid heap, 4 elsewhere).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
+ * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  Speed only, all three.
  * "fmm.wg_per_cu": resident eikonal workgroups per CU (measurement).  "disp.ffwd": 0 = the first period's bracket search goes
  * step by step from its start value like the reference's (default: it jumps to the bracket that a parallel evaluation of the
  * same grid points found for the column's model; identical results).  "disp.pchunk": periods per
