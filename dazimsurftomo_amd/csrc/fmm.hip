@@ -1066,7 +1066,11 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
     const unsigned fbase = s_base;
     if (fbase == 0xffffffffu) break;
     const int stage = ts ? (int)s_stage : 0;
+#ifdef DZ_TS_LIGHT_ACQ   // measurement only (not coherent across XCDs): what the L2 invalidate of the acquire costs
+    if (stage > 0) asm volatile("buffer_inv sc0" ::: "memory");
+#else
     if (stage > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // acquire side for the lanes that did not spin
+#endif
     const int q = (int)fbase + grp;
     // node words of the coarse grid and the heap's HBM level: per resident slot, or per field when stages change hands
     unsigned *rec_c = A.rec_c + (ts ? (size_t)q : slot) * nrec_c;
@@ -1322,7 +1326,11 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
       }
     }
     if (ts) {   // hand the batch to its next stage: everything this task stored, then the flag
+#ifdef DZ_TS_LIGHT_REL   // measurement only (not coherent across XCDs): what the L2 write-back of the release costs
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
       __syncthreads();
       if (lane == 0) __hip_atomic_store(A.ts_flag + fbase / fpw, (unsigned)stage + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1353,7 +1361,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
   // Time slicing (see fmm_kernel): on when the batch does not fit the resident slots (more than one round) and the per-field node
   // words fit comfortably; option fmm.ts = 1 / 2 forces it on / off (0: this rule), fmm.ts_stages sets the number of coarse stages.
-  // Every hand-over costs two agent-scope fences (L2 write-back / invalidate on the XCD), so few stages are best: S-256's 16 000
+  // Few stages are best (not because of the hand-over fences: tools/exp_ts_fences.sh; with many short stages handed out
+  // stage-major the fields march in step again and the mixture of phases on a CU is lost): S-256's 16 000
   // fields on the 512-slot hybrid heap take 0.240 / 0.253 / 0.248 / 0.249 / 0.252 s with 2 / 3 / 4 / 8 / 12 coarse stages
   // (0.288 s unsliced on the 768-slot heap, same box), the 768-slot heap 0.292 / 0.264 / 0.262 s with 2 / 4 / 8-12; S-512's
   // 32 000 fields (1024-slot hybrid heap) 4.29 s unsliced, 4.03 / 3.96 / 3.97 s with 2 / 4 / 8.  Defaults: 2 on the 512-slot hybrid
