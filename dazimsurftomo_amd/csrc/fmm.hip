@@ -1000,6 +1000,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
 #else
 #define FMM_WPE_ATTR
 #endif
+#ifdef DZ_TS_WAITSTAT   // experiment build: clocks the workgroups spend waiting for the previous stage of their task
+__device__ unsigned long long g_ts_wait[2];
+#endif
 template <int CAP, bool SPILL, class NT, bool HYB>
 __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
@@ -1054,7 +1057,14 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
           s_stage = stg;
           if (stg > 0) {   // its predecessor (same batch, previous stage) must have handed its state over
             const unsigned *flag = A.ts_flag + found / fpw;
+#ifdef DZ_TS_WAITSTAT
+            const unsigned long long w0_ = __builtin_amdgcn_s_memtime();
+#endif
             while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < stg) __builtin_amdgcn_s_sleep(20);
+#ifdef DZ_TS_WAITSTAT
+            atomicAdd(&g_ts_wait[0], __builtin_amdgcn_s_memtime() - w0_);
+            atomicAdd(&g_ts_wait[1], 1ull);
+#endif
           }
           break;
         }
@@ -1379,6 +1389,10 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.ts_nstage = ts ? 1 + nseg : 1;
   // (stage lengths that shrink towards the end -- a shorter tail -- were measured and lose: 0.251-0.265 s against 0.247 s)
   A.ts_pops = (int)((nn + nseg - 1) / nseg);
+  // (stages of unequal length -- odd batches longer, even ones shorter, to put the batches out of step -- lose badly: +19 % of
+  // the time at +-20 %, +44 % at +-40 %: the stage-major hand-out relies on equal tasks, a workgroup that takes a task whose
+  // predecessor is still running waits; with equal stages that wait is 0.15 % of the workgroups' time at 2 stages, 2 % at 8:
+  // tools/exp_ts_wait.sh)
   ctx->ksec["fmm.ts_stages"] = ts ? (double)nseg : 0.0;
   const size_t nown = ts ? (size_t)nfield : (size_t)nslot;   // owners of node words / HBM heap levels: fields or resident slots
   if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
@@ -1480,6 +1494,15 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
+#ifdef DZ_TS_WAITSTAT
+  {
+    unsigned long long h[2];
+    DZ_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts_wait), sizeof h));
+    fprintf(stderr, "ts wait: %llu clocks (100 MHz) in %llu waits of later-stage tasks; %d workgroups\n", h[0], h[1], nwg);
+    unsigned long long z[2] = {0, 0};
+    DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ts_wait), z, sizeof z));
+  }
+#endif
 #ifdef DZ_FMM_LAZYSTAT
   {
     unsigned long long h[4];
