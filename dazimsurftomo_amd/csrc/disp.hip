@@ -21,6 +21,7 @@ constexpr int NL = 200;       // inv/surfdisp96.f:57
 constexpr int NP = 60;        // inv/surfdisp96.f:59
 constexpr int NZMAX = 64;     // knots per column we accept
 constexpr int DT = 256;       // threads per workgroup
+constexpr int TW = 64;        // work items per task: one wavefront's (see disp_kernel)
 constexpr int NEVN = 11;      // Neville points kept (x(1..11), inv/surfdisp96.f:569,655)
 
 struct Layer {   // per refined layer, geometry only
@@ -503,35 +504,39 @@ template <int RDEN>
 __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
-  extern __shared__ __attribute__((aligned(16))) float s_knot[];  // [cpb][3][nz]
+  extern __shared__ __attribute__((aligned(16))) float s_knots[];  // [DT / 64][cpb][3][nz]
   __shared__ double s_x[NEVN][DT], s_y[NEVN][DT];
-  __shared__ unsigned s_task;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int nz = A.nz, kmax = A.kmax, mmax = A.mmax, nvar = A.nvar;
   const long nwork = (long)A.ncol * nvar;
   for (int i = tid; i < mmax; i += DT) s_lay[i] = A.lay[i];
   for (int i = tid; i < kmax; i += DT) s_t[i] = A.t[i];
-  const int cpb = (DT + nvar - 1) / nvar + 1;  // columns the work items of one group may span
+  __syncthreads();
+  // Tasks are taken per WAVEFRONT (round 3, late): groups of TW = 64 items.  The four wavefronts of a workgroup share the layer
+  // table and the periods, nothing else, and with 256-item tasks each waited for the slowest of the four at every task
+  // boundary -- 8.3 % of the lane-evaluations a workgroup offered went unused, 3.4 % of those a wavefront offers
+  // (tools/disp_stat.sh).  No barrier inside the loop: a wavefront's LDS accesses execute in order.
+  const int cpb = (TW + nvar - 1) / nvar + 1;  // columns the work items of one group may span
+  float *s_knot = s_knots + (size_t)(tid >> 6) * cpb * 3 * nz;
   const unsigned ntask = (unsigned)A.ngroup * (unsigned)A.nchunk;
   for (;;) {
-    __syncthreads();   // (the previous task's LDS reads are over)
-    if (tid == 0) {
-      const unsigned t = atomicAdd(A.counter, 1u);
-      s_task = t;
-      if (t < ntask && t >= (unsigned)A.ngroup) {   // chunk c > 0: its predecessor (same group, chunk c-1) must have published its state
-        const int *flag = A.ready + (t - (unsigned)A.ngroup);
+    __builtin_amdgcn_wave_barrier();   // (the previous task's LDS reads are over)
+    unsigned task = 0;
+    if (lane == 0) {
+      task = atomicAdd(A.counter, 1u);
+      if (task < ntask && task >= (unsigned)A.ngroup) {   // chunk c > 0: its predecessor (same group, chunk c-1) must have published its state
+        const int *flag = A.ready + (task - (unsigned)A.ngroup);
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(20);
       }
     }
-    __syncthreads();
-    const unsigned task = s_task;
+    task = (unsigned)__shfl((int)task, 0);
     if (task >= ntask) break;
     __threadfence();   // acquire side for the lanes that did not spin: the state written by another workgroup is visible
     const int chunk = (int)(task / (unsigned)A.ngroup), grp = (int)(task - (unsigned)chunk * (unsigned)A.ngroup);
     const int kbeg = chunk * A.pchunk, kend = min(kbeg + A.pchunk, kmax);
-    const long w0 = (long)grp * DT;
+    const long w0 = (long)grp * TW;
     const int col0 = (int)(w0 / nvar);
-    for (int i = tid; i < cpb * nz; i += DT) {
+    for (int i = lane; i < cpb * nz; i += TW) {
       const int c = i / nz, k = i - c * nz, col = col0 + c;
       if (col < A.ncol) {
         const float vs = A.vel[(size_t)k * A.ncol + col];
@@ -542,8 +547,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
         s_knot[(c * 3 + 2) * nz + k] = rho;
       }
     }
-    __syncthreads();
-    const long w = w0 + tid;
+    __builtin_amdgcn_wave_barrier();
+    const long w = w0 + lane;
     const bool active = w < nwork;
     const int col = active ? (int)(w / nvar) : col0;
     const int var = active ? (int)(w - (long)col * nvar) : 0;
@@ -784,14 +789,9 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
       }
     }
 #ifdef DZ_DISP_STAT
-    {   // lane-evaluations done / offered by the wavefront / offered by the workgroup (its slowest wavefront)
-      __shared__ unsigned long long s_wmax;
-      if (tid == 0) s_wmax = 0;
-      __syncthreads();
+    {   // lane-evaluations done / offered by the wavefront (tasks are per wavefront: a workgroup offers what its wavefronts do)
       atomicAdd(&g_disp_stat[0], st_act);
-      if ((tid & 63) == 0) { atomicAdd(&g_disp_stat[1], st_iter * 64ull); atomicMax(&s_wmax, st_iter); }
-      __syncthreads();
-      if (tid == 0) atomicAdd(&g_disp_stat[2], s_wmax * (unsigned long long)DT);
+      if (lane == 0) { atomicAdd(&g_disp_stat[1], st_iter * 64ull); atomicAdd(&g_disp_stat[2], st_iter * 64ull); }
     }
 #endif
     if (active && kend < kmax && !(chunk > 0 && A.st_f[wi])) {   // hand the chain to the next chunk
@@ -800,8 +800,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
       A.st_f[wi] = failed ? 1 : 0;
     }
     __threadfence();   // release: the state above before the flag below
-    __syncthreads();
-    if (tid == 0 && kend < kmax) __hip_atomic_store(A.ready + task, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0 && kend < kmax) __hip_atomic_store(A.ready + task, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -928,15 +928,15 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   int *d_nfail = (int *)p;
   DZ_HIP(hipMemsetAsync(d_nfail, 0, 4, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  const int cpb = (DT + nvar - 1) / nvar + 1;
-  const size_t dyn_lds = (size_t)cpb * 3 * nz * sizeof(float);
+  const int cpb = (TW + nvar - 1) / nvar + 1;
+  const size_t dyn_lds = (size_t)(DT / TW) * cpb * 3 * nz * sizeof(float);
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
   {
     const long nwork = (long)ncol * nvar;
     // task queue: groups of DT items x chunks of pchunk periods (see disp_kernel); persistent workgroups, as many as are resident
-    A.ngroup = (int)((nwork + DT - 1) / DT);
+    A.ngroup = (int)((nwork + TW - 1) / TW);
     A.pchunk = kmax;
     if (ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0) A.pchunk = ctx->opts["disp.pchunk"];
     if (A.pchunk > kmax) A.pchunk = kmax;
@@ -958,7 +958,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     // option disp.occ: at most that many workgroups per CU (room for a kernel of another stream on the same CUs)
     if (ctx->opts.count("disp.occ") && ctx->opts["disp.occ"] >= 1 && ctx->opts["disp.occ"] < occ) occ = ctx->opts["disp.occ"];
     long nwg = (long)ctx->num_cu * occ;
-    if (nwg > (long)ntask) nwg = (long)ntask;
+    if (nwg > ((long)ntask + DT / TW - 1) / (DT / TW)) nwg = ((long)ntask + DT / TW - 1) / (DT / TW);
     // first-period fast-forward (disp_bracket_kernel); off with option disp.ffwd = 0 and when the periods are handed from task to task
     // Option disp.ffwd: 1 (default) = the jump for the column's own model only, which is exact -- disp_bracket_kernel evaluated
     // every skipped grid point with the same function; 2 = the 6*nz perturbed copies jump as well, behind the gates described at
