@@ -458,6 +458,11 @@ def main():
     # N > 1: the dispersion tables belong to the model every rank shares -- each rank computes a block of its rows and one
     # all-gather (RCCL) joins them (dazimsurftomo_amd.distributed.depthkernel_sharded; DAZIM_SHARD_DISP=0: every rank all of it)
     shard_disp = use_dist and os.environ.get("DAZIM_SHARD_DISP", "1") != "0"
+    # The perturbed copies of the dispersion kernel (72/73 of its work, wanted by the G rows only) on the library's auxiliary
+    # stream: the eikonal kernel shares the chip with their last, partly filled round.  DAZIM_DISP_ASYNC=0: one stream.
+    disp_async = not shard_disp and os.environ.get("DAZIM_DISP_ASYNC", "1") != "0"
+    if disp_async:
+        ctx.set_option("disp.async", 1)
 
     def step():
         tw[0] = time.perf_counter()
@@ -469,7 +474,7 @@ def main():
             stats["disp_s"] = time.perf_counter() - t_d     # local curves + all-gather
         else:
             pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
-            stats["disp_s"] = ctx.kernel_seconds("disp")
+            stats["disp_s"] = ctx.kernel_seconds("disp")            # (disp.async: the column curves; the copies overlap what follows)
         lap("depthkernel")
         fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
@@ -479,6 +484,8 @@ def main():
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
+        if disp_async:
+            stats["disp_copies_s"] = ctx.kernel_seconds("disp.copies")   # (finished long ago: rays_build_G joined that stream)
         lap("rays_build_G")
         stats["nnz_data"] = G.nnz
         G.append_coo(c3, t_ir, t_ic, t_rw)
@@ -590,6 +597,10 @@ def main():
             "dispersion": ("model rows sharded over the ranks, tables joined by one all-gather (RCCL)" if shard_disp
                            else ("every rank computes the whole model's tables" if use_dist else "single GPU")),
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
+            "dispersion_streams": ({"async": True, "column_curves_s": stats["disp_s"], "perturbed_copies_s": stats.get("disp_copies_s"),
+                                    "note": "disp_s = the column curves on the main stream; the perturbed copies run on the "
+                                            "auxiliary stream beside the eikonal kernel (start to end of that stream's work)"}
+                                   if disp_async else {"async": False}),
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "fmm_schedule": {"workgroups_per_cu": int(stats["fmm_wg_per_cu"]), "time_sliced_coarse_stages": int(stats["fmm_ts_stages"]),
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},

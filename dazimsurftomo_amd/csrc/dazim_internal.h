@@ -30,12 +30,19 @@ struct dazim_ctx {
   // outer iteration, and a hipMalloc + hipFree pair of that size costs about a millisecond each -- freed arrays are kept
   // (a few, best fit) and handed out again
   std::vector<StageBlock> big;
+  // auxiliary stream (option disp.async): the perturbed copies of the dispersion kernel run there while the main stream goes on
+  // with the column's own curves, the gridder and the eikonal fields; whoever consumes the depth kernels joins first (dz_join_aux)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_a0 = nullptr, ev_a1 = nullptr;
+  bool aux_pending = false, aux_timed = false;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
 };
 
 int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
+int dz_aux_init(dazim_ctx *ctx);                  // creates the auxiliary stream and its events on first use
+int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what the auxiliary stream was given (no host wait)
 
 #define DZ_HIP(call)                                                                           \
   do {                                                                                         \

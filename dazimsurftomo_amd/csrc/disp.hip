@@ -35,6 +35,8 @@ struct Layer {   // per refined layer, geometry only
 
 struct DispArgs {
   int ncol, nz, kmax, nvar, mmax;
+  int var0, nvarp;     // the variants this launch works on: var0 .. var0 + nvarp - 1 of every column (all of them: 0, nvar; with
+                       // option disp.async the column's own curve, 0 / 1, and its perturbed copies, 1 / nvar - 1, are two launches)
   const float *vel;  // [nz][ncol]
   const Layer *lay;  // [mmax]
   const double *t;   // [kmax]
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   extern __shared__ __attribute__((aligned(16))) float s_knots[];  // [DT / 64][cpb][3][nz]
   __shared__ double s_x[NEVN][DT], s_y[NEVN][DT];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int nz = A.nz, kmax = A.kmax, mmax = A.mmax, nvar = A.nvar;
-  const long nwork = (long)A.ncol * nvar;
+  const int nz = A.nz, kmax = A.kmax, mmax = A.mmax, nvar = A.nvar, nvarp = A.nvarp;
+  const long nwork = (long)A.ncol * nvarp;
   for (int i = tid; i < mmax; i += DT) s_lay[i] = A.lay[i];
   for (int i = tid; i < kmax; i += DT) s_t[i] = A.t[i];
   __syncthreads();
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   // table and the periods, nothing else, and with 256-item tasks each waited for the slowest of the four at every task
   // boundary -- 8.3 % of the lane-evaluations a workgroup offered went unused, 3.4 % of those a wavefront offers
   // (tools/disp_stat.sh).  No barrier inside the loop: a wavefront's LDS accesses execute in order.
-  const int cpb = (TW + nvar - 1) / nvar + 1;  // columns the work items of one group may span
+  const int cpb = (TW + nvarp - 1) / nvarp + 1;  // columns the work items of one group may span
   float *s_knot = s_knots + (size_t)(tid >> 6) * cpb * 3 * nz;
   const unsigned ntask = (unsigned)A.ngroup * (unsigned)A.nchunk;
   for (;;) {
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     const int chunk = (int)(task / (unsigned)A.ngroup), grp = (int)(task - (unsigned)chunk * (unsigned)A.ngroup);
     const int kbeg = chunk * A.pchunk, kend = min(kbeg + A.pchunk, kmax);
     const long w0 = (long)grp * TW;
-    const int col0 = (int)(w0 / nvar);
+    const int col0 = (int)(w0 / nvarp);
     for (int i = lane; i < cpb * nz; i += TW) {
       const int c = i / nz, k = i - c * nz, col = col0 + c;
       if (col < A.ncol) {
@@ -550,8 +552,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     __builtin_amdgcn_wave_barrier();
     const long w = w0 + lane;
     const bool active = w < nwork;
-    const int col = active ? (int)(w / nvar) : col0;
-    const int var = active ? (int)(w - (long)col * nvar) : 0;
+    const int col = active ? (int)(w / nvarp) : col0;
+    const int var = active ? A.var0 + (int)(w - (long)col * nvarp) : 0;
     Knots K;
     K.vs = s_knot + ((col - col0) * 3 + 0) * nz;
     K.vp = s_knot + ((col - col0) * 3 + 1) * nz;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     const float ddc = 0.005f, sone = 1.5f;
     const double onea = (double)sone, TWOPI = 2.0 * 3.141592653589793;
     const double cc = (double)cc1, dc = fabs((double)ddc), cm = cc;
-    const size_t wi = (size_t)(active ? w : 0);
+    const size_t wi = active ? (size_t)col * nvar + var : 0;   // the item's place among all (column, variant) pairs
     float *cg = A.cg + wi * kmax;
 
     // ---- per-lane root-search state (getsol :384-476, nevill :551-668) ----
@@ -813,9 +815,11 @@ __global__ void disp_finalize(int ncol, int nz, int kmax, int nvar, const float 
   if (tid >= (long)ncol * kmax) return;
   const int k = (int)(tid / ncol), col = (int)(tid - (long)k * ncol);
   const float *c = cg + (size_t)col * nvar * kmax;
-  const float c0 = c[k];
-  pv[(size_t)k * ncol + col] = (double)c0;
-  if (c0 == 0.0f) atomicAdd(nfail, 1);
+  if (pv) {
+    const float c0 = c[k];
+    pv[(size_t)k * ncol + col] = (double)c0;
+    if (c0 == 0.0f) atomicAdd(nfail, 1);
+  }
   if (!svs) return;
   const float dln = 0.01f;
   for (int i = 0; i < nz; i++) {
@@ -900,6 +904,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DzBuf<float> vel;
   DzBuf<double> pv, svs, svp, srho;
   int rc;
+  if ((rc = dz_join_aux(ctx))) return rc;   // (an earlier call's perturbed copies may still be running on the auxiliary stream)
   const size_t nk = (size_t)nz * kmax * ncol;
   if ((rc = vel.init(ctx, vel_u, (size_t)nz * ncol, true, false))) return rc;
   if ((rc = pv.init(ctx, pv_u, (size_t)kmax * ncol, false, true))) return rc;
@@ -914,6 +919,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   A.nz = nz;
   A.kmax = kmax;
   A.nvar = nvar;
+  A.var0 = 0;
+  A.nvarp = nvar;
   A.mmax = mmax;
   A.vel = vel.dev;
   if ((rc = dz_scratch(ctx, "disp.lay", sizeof(Layer) * NL, &p))) return rc;
@@ -928,11 +935,23 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   int *d_nfail = (int *)p;
   DZ_HIP(hipMemsetAsync(d_nfail, 0, 4, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  const int cpb = (TW + nvar - 1) / nvar + 1;
-  const size_t dyn_lds = (size_t)(DT / TW) * cpb * 3 * nz * sizeof(float);
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds));
+  auto knot_lds = [&](int nvarp) { return (size_t)(DT / TW) * ((TW + nvarp - 1) / nvarp + 1) * 3 * nz * sizeof(float); };
+  // Option disp.async (device-resident outputs, depth kernels wanted, one period chunk): the column's own curves -- all the
+  // eikonal solve needs -- are one launch on the context's stream, the 6*nz perturbed copies (72/73 of the work, wanted only by
+  // the G rows) another one on the auxiliary stream, and the call returns when the first is done.  dazim_rays_build_G*, the next
+  // dazim_dispersion_kernels, dazim_sync and dazim_free join the auxiliary stream; anybody else who reads sen_* (or overwrites
+  // vel) before one of these calls dazim_sync first.  What it buys: the dispersion kernel's last, partly filled round of
+  // workgroups (S-256: 64 of 832) and the eikonal kernel share the chip (tools/exp_overlap.py: 293 against 306 ms), and on
+  // small batches (S-128) the two kernels, neither of which fills it, run side by side.
+  bool async = kernels && ctx->opts.count("disp.async") && ctx->opts["disp.async"] && !vel.staged && !pv.staged && !svs.staged &&
+               !svp.staged && !srho.staged && !(ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0 && ctx->opts["disp.pchunk"] < kmax);
+  const size_t dyn_lds = knot_lds(nvar), dyn_lds_base = knot_lds(1);
+  if (dyn_lds_base + 56 * 1024 > 160 * 1024) async = false;   // (very many knots: the 64 columns of a base task would not fit the LDS)
+  const size_t dyn_max = async && dyn_lds_base > dyn_lds ? dyn_lds_base : dyn_lds;
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  if (async && (rc = dz_aux_init(ctx))) return rc;
   {
     const long nwork = (long)ncol * nvar;
     // task queue: groups of DT items x chunks of pchunk periods (see disp_kernel); persistent workgroups, as many as are resident
@@ -980,6 +999,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     A.ff_c = (double *)p;
     if ((rc = dz_scratch(ctx, "disp.ff_v", (size_t)ncol * 4 + 16, &p))) return rc;
     A.ff_v = (int *)p;
+    ctx->ksec["disp.async"] = async ? 1.0 : 0.0;
+    ctx->aux_timed = false;
     DzTimer t(ctx, "disp");
     if (A.ffwd) {
       if (rden == 1)
@@ -990,18 +1011,57 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
         hipLaunchKernelGGL(disp_bracket_kernel<0>, dim3((unsigned)ncol), dim3(64), 0, ctx->stream, A);
       DZ_HIP(hipGetLastError());
     }
-    if (rden == 1)
-      hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
-    else if (rden == 2)
-      hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
-    else
-      hipLaunchKernelGGL(disp_kernel<0>, dim3((unsigned)nwg), dim3(DT), dyn_lds, ctx->stream, A);
-    DZ_HIP(hipGetLastError());
+    auto launch = [&](const DispArgs &B, long nwgB, size_t lds, hipStream_t st) {
+      if (rden == 1)
+        hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+      else if (rden == 2)
+        hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+      else
+        hipLaunchKernelGGL(disp_kernel<0>, dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+    };
     const long nf = (long)ncol * kmax;
-    hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,
-                       vel.dev, A.cg, pv.dev, kernels ? svs.dev : nullptr, kernels ? svp.dev : nullptr,
-                       kernels ? srho.dev : nullptr, d_nfail);
-    DZ_HIP(hipGetLastError());
+    if (!async) {
+      launch(A, nwg, dyn_lds, ctx->stream);
+      DZ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,
+                         vel.dev, A.cg, pv.dev, kernels ? svs.dev : nullptr, kernels ? svp.dev : nullptr,
+                         kernels ? srho.dev : nullptr, d_nfail);
+      DZ_HIP(hipGetLastError());
+    } else {
+      // the copies: auxiliary stream, behind everything enqueued so far (tables, counters, the bracket kernel)
+      DispArgs C = A;
+      C.var0 = 1;
+      C.nvarp = nvar - 1;
+      C.ngroup = (int)(((long)ncol * C.nvarp + TW - 1) / TW);
+      long nwgC = (long)ctx->num_cu * occ, needC = ((long)C.ngroup + DT / TW - 1) / (DT / TW);
+      if (nwgC > needC) nwgC = needC;
+      // the column's own curves: a handful of workgroups on the main stream, their own task counter
+      DispArgs B = A;
+      B.var0 = 0;
+      B.nvarp = 1;
+      B.ngroup = (ncol + TW - 1) / TW;
+      if ((rc = dz_scratch(ctx, "disp.ready_b", (size_t)B.ngroup * 4 + 64, &p))) return rc;
+      B.ready = (int *)p;
+      B.counter = (unsigned *)((char *)p + (size_t)B.ngroup * 4 + 16 - ((size_t)B.ngroup * 4) % 16);
+      DZ_HIP(hipMemsetAsync(p, 0, (size_t)B.ngroup * 4 + 64, ctx->stream));
+      DZ_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+      const long nwgB = ((long)B.ngroup + DT / TW - 1) / (DT / TW);
+      launch(B, nwgB, dyn_lds_base, ctx->stream);   // (first: its workgroups want a CU's LDS before the copies' have filled them)
+      DZ_HIP(hipGetLastError());
+      DZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+      DZ_HIP(hipEventRecord(ctx->ev_a0, ctx->stream2));
+      launch(C, nwgC, dyn_lds, ctx->stream2);
+      DZ_HIP(hipGetLastError());
+      hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream2, ncol, nz, kmax, nvar,
+                         vel.dev, A.cg, (double *)nullptr, svs.dev, svp.dev, srho.dev, d_nfail);
+      DZ_HIP(hipGetLastError());
+      DZ_HIP(hipEventRecord(ctx->ev_a1, ctx->stream2));
+      ctx->aux_pending = true;
+      ctx->aux_timed = true;
+      hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,
+                         vel.dev, A.cg, pv.dev, (double *)nullptr, (double *)nullptr, (double *)nullptr, d_nfail);
+      DZ_HIP(hipGetLastError());
+    }
     t.stop();
   }
   int nfail = 0;
@@ -1017,7 +1077,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_disp_stat), z, sizeof z));
   }
 #endif
-  DZ_HIP(hipMemcpyAsync(hst, A.ff_stat, 16, hipMemcpyDeviceToHost, ctx->stream));
+  if (!ctx->aux_pending) DZ_HIP(hipMemcpyAsync(hst, A.ff_stat, 16, hipMemcpyDeviceToHost, ctx->stream));   // (async: the copies' statistics are not waited for)
   if ((rc = pv.finish()) || (rc = svs.finish()) || (rc = svp.finish()) || (rc = srho.finish())) return rc;
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   if (n_failed) *n_failed = nfail;

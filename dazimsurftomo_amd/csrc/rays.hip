@@ -687,6 +687,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       !srho_u || !dsurf_u || (nray > 0 && (!field_u || !rcx_u || !rcz_u)))
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "dazim_rays_build_G: NULL array (the refined fields ttnr, nstsr and boxes of dazim_fmm_batch are required)");
   DZ_HIP(hipSetDevice(ctx->device));
+  {   // the depth kernels may still be in the making on the auxiliary stream (dazim_dispersion_kernels with disp.async)
+    const int rcj = dz_join_aux(ctx);
+    if (rcj) return rcj;
+  }
   const size_t nn = (size_t)g.nnx * g.nnz, nr = (size_t)RM * RM, ncol = (size_t)nx * ny;
   DzBuf<float> vels, scx, scz, veln, ttn, ttnr, rcx, rcz, dsurf;
   DzBuf<int> period, kidx, nstsr, field;

@@ -287,3 +287,65 @@ def test_three_exponentials_option(ctx, orc):
         at_least(f"pvRc bit-equal share ({tag})", (pv == pvo).mean(), PV_EQUAL_SHARE)
         for a, b in zip(sen, seno):
             within(f"sen max |d| ({tag})", np.abs(a - b).max(), SEN_REL * np.abs(b).max() + SEN_ABS)
+
+
+def test_two_stream_dispersion_is_bit_identical_and_joined_by_its_consumers():
+    """option disp.async (device-resident arrays): the column curves on the context's stream, the 6*nz perturbed copies on the
+    auxiliary stream, the call returns when the curves are there.  pvRc must be complete at once (the eikonal solve is next),
+    the depth kernels after dazim_sync -- bit-identical to the one-stream call -- and dazim_rays_build_G must join the auxiliary
+    stream by itself: the G built right after an asynchronous call equals the G of the one-stream call, entry for entry."""
+    import torch
+    import dazimsurftomo_amd as dz
+    import bench
+    from tests import synth
+    dev = torch.device("cuda:0")
+    nx = ny = 28
+    old = (bench.NX, bench.NY)
+    bench.NX = bench.NY = nx
+    try:
+        vel = bench.s256_model()
+    finally:
+        bench.NX, bench.NY = old
+    depz, periods, minthk = bench.DEPZ, np.asarray(bench.PERIODS, np.float64)[:8], bench.MINTHK
+    kmax, nsrc, nrcv = len(periods), 12, 8
+    lat, lon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nsrc, seed=3)
+    sx, sz = synth.radians(lat, lon)
+    rlat, rlon = synth.stations(nx, ny, 30.0, 100.0, 0.25, 0.25, nrcv, seed=4)
+    rx, rz = synth.radians(rlat, rlon)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_vel = T(vel)
+    d_scx, d_scz = T(np.tile(sx, kmax)), T(np.tile(sz, kmax))
+    d_per = T(np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc))
+    nfield = kmax * nsrc
+    d_fray = T(np.repeat(np.arange(nfield, dtype=np.int32), nrcv))
+    d_rcx, d_rcz = T(np.tile(rx, nfield)), T(np.tile(rz, nfield))
+    res = {}
+    for mode in (0, 1, 1):
+        c = dz.Context(0)
+        c.set_option("disp.async", mode)
+        pv, sen, nf = c.depthkernel(d_vel, depz, periods, minthk)
+        assert c.kernel_seconds("disp.async") == mode
+        pv_now = pv.clone()                                   # (on torch's stream, after the call returned: complete by contract)
+        fields = c.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, d_scx, d_scz, d_per,
+                             veln=torch.empty((kmax, 126, 126), dtype=torch.float32, device=dev),
+                             ttn=torch.empty((nfield, 126, 126), dtype=torch.float32, device=dev),
+                             ttnr=torch.empty((nfield, 129, 129), dtype=torch.float32, device=dev),
+                             nstsr=torch.empty((nfield, 129, 129), dtype=torch.int32, device=dev),
+                             boxes=torch.empty((nfield, 12), dtype=torch.int32, device=dev),
+                             status=torch.empty((nfield,), dtype=torch.int32, device=dev))
+        G, tpred, nb = c.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, d_vel, fields, d_scx, d_scz, d_per, d_fray, d_rcx, d_rcz, sen)
+        rowptr, col, val = G.to_coo()
+        c.sync()
+        if mode:
+            assert c.kernel_seconds("disp.copies") > 0
+        out = (pv_now.cpu().numpy(), [s.cpu().numpy() for s in sen], nf, rowptr, col, val, tpred.cpu().numpy())
+        G.free()
+        c.close()
+        if mode == 0:
+            res = out
+        else:
+            assert out[2] == res[2] and np.array_equal(out[0], res[0])
+            for a, b in zip(out[1], res[1]):
+                assert np.array_equal(a, b)
+            for a, b in zip(out[3:], res[3:]):
+                assert np.array_equal(a, b)

@@ -38,12 +38,17 @@ def main():
     disp(ca, d_pv, d_sen); fmm(ca); disp(cb, d_pv2, d_sen2)
     def wall(f):
         torch.cuda.synchronize(); t = time.perf_counter(); f(); torch.cuda.synchronize(); return time.perf_counter() - t
-    for occ in (3, 2, 1):
+    for occ in ((3, 2, 1) if not os.environ.get("DISP_FIRST") else (3,)):
         cb.set_option("disp.occ", occ)
         td = min(wall(lambda: disp(cb, d_pv2, d_sen2)) for _ in range(2))
         tf = min(wall(lambda: fmm(ca)) for _ in range(2))
-        for delay in (0.0, 0.005):
+        for delay in ((0.0, 0.005) if not os.environ.get("DISP_FIRST") else (0.0, 0.02, 0.04, 0.05, 0.056, 0.062)):
             def both():
+                if os.environ.get("DISP_FIRST"):   # the dispersion kernel first, the eikonal kernel `delay` later (its tail overlapped)
+                    th = threading.Thread(target=lambda: disp(cb, d_pv2, d_sen2)); th.start()
+                    if delay: time.sleep(delay)
+                    fmm(ca); th.join()
+                    return
                 th = threading.Thread(target=lambda: fmm(ca)); th.start()
                 if delay: time.sleep(delay)
                 disp(cb, d_pv2, d_sen2); th.join()
