@@ -484,7 +484,8 @@ def main():
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
-        if disp_async:
+        stats["disp_two_streams"] = disp_async and ctx.kernel_seconds("disp.async") > 0   # (the library declines where it does not pay)
+        if stats["disp_two_streams"]:
             stats["disp_copies_s"] = ctx.kernel_seconds("disp.copies")   # (finished long ago: rays_build_G joined that stream)
         lap("rays_build_G")
         stats["nnz_data"] = G.nnz
@@ -600,7 +601,7 @@ def main():
             "dispersion_streams": ({"async": True, "column_curves_s": stats["disp_s"], "perturbed_copies_s": stats.get("disp_copies_s"),
                                     "note": "disp_s = the column curves on the main stream; the perturbed copies run on the "
                                             "auxiliary stream beside the eikonal kernel (start to end of that stream's work)"}
-                                   if disp_async else {"async": False}),
+                                   if stats.get("disp_two_streams") else {"async": False}),
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
             "fmm_schedule": {"workgroups_per_cu": int(stats["fmm_wg_per_cu"]), "time_sliced_coarse_stages": int(stats["fmm_ts_stages"]),
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},

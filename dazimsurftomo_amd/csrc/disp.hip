@@ -999,6 +999,13 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     A.ff_c = (double *)p;
     if ((rc = dz_scratch(ctx, "disp.ff_v", (size_t)ncol * 4 + 16, &p))) return rc;
     A.ff_v = (int *)p;
+    if (async && ctx->opts["disp.async"] == 1) {
+      // 1 = two streams where they pay: what the eikonal kernel can share the chip with is the copies' last, partly filled round
+      // (or a launch that never fills it); over many rounds that is a small part of the launch and the two kernels only take
+      // each other's LDS (S-512, four rounds: eikonal kernel +0.31 s for 0.25 s of dispersion).  2 = always.
+      const double rounds = (double)(((long)ncol * (nvar - 1) + DT - 1) / DT) / (double)((long)ctx->num_cu * occ);
+      if (rounds > 2.0) async = false;
+    }
     ctx->ksec["disp.async"] = async ? 1.0 : 0.0;
     ctx->aux_timed = false;
     DzTimer t(ctx, "disp");

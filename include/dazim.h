@@ -89,7 +89,8 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
  * the 512-slot hybrid heap, 4 elsewhere).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
  * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  Speed only, all three.
- * "disp.async": 1 = dazim_dispersion_kernels (device-resident arrays, depth kernels wanted) returns when pvRc is complete and
+ * "disp.async": 1 (where it pays: at most two rounds of workgroups) or 2 (always) = dazim_dispersion_kernels (device-resident
+ * arrays, depth kernels wanted) returns when pvRc is complete and
  * leaves the 6*nz perturbed copies of every column -- which only sen_* need -- running on the context's auxiliary stream, beside
  * whatever is called next (the eikonal fields); dazim_rays_build_G*, the next dazim_dispersion_kernels, dazim_free and
  * dazim_sync join that stream.  Until one of them has been called sen_* are incomplete and vel must not be overwritten.

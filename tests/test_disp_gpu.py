@@ -322,7 +322,7 @@ def test_two_stream_dispersion_is_bit_identical_and_joined_by_its_consumers():
     res = {}
     for mode in (0, 1, 1):
         c = dz.Context(0)
-        c.set_option("disp.async", mode)
+        c.set_option("disp.async", 2 * mode)
         pv, sen, nf = c.depthkernel(d_vel, depz, periods, minthk)
         assert c.kernel_seconds("disp.async") == mode
         pv_now = pv.clone()                                   # (on torch's stream, after the call returned: complete by contract)
