@@ -936,14 +936,15 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DZ_HIP(hipMemsetAsync(d_nfail, 0, 4, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   auto knot_lds = [&](int nvarp) { return (size_t)(DT / TW) * ((TW + nvarp - 1) / nvarp + 1) * 3 * nz * sizeof(float); };
-  // Option disp.async (device-resident outputs, depth kernels wanted, one period chunk): the column's own curves -- all the
+  // Option disp.async (device-resident vel and sen_* -- pvRc may be a host array, it is complete and copied when the call
+  // returns --, depth kernels wanted, one period chunk): the column's own curves -- all the
   // eikonal solve needs -- are one launch on the context's stream, the 6*nz perturbed copies (72/73 of the work, wanted only by
   // the G rows) another one on the auxiliary stream, and the call returns when the first is done.  dazim_rays_build_G*, the next
   // dazim_dispersion_kernels, dazim_sync and dazim_free join the auxiliary stream; anybody else who reads sen_* (or overwrites
   // vel) before one of these calls dazim_sync first.  What it buys: the dispersion kernel's last, partly filled round of
   // workgroups (S-256: 64 of 832) and the eikonal kernel share the chip (tools/exp_overlap.py: 293 against 306 ms), and on
   // small batches (S-128) the two kernels, neither of which fills it, run side by side.
-  bool async = kernels && ctx->opts.count("disp.async") && ctx->opts["disp.async"] && !vel.staged && !pv.staged && !svs.staged &&
+  bool async = kernels && ctx->opts.count("disp.async") && ctx->opts["disp.async"] && !vel.staged && !svs.staged &&
                !svp.staged && !srho.staged && !(ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0 && ctx->opts["disp.pchunk"] < kmax);
   const size_t dyn_lds = knot_lds(nvar), dyn_lds_base = knot_lds(1);
   if (dyn_lds_base + 56 * 1024 > 160 * 1024) async = false;   // (very many knots: the 64 columns of a base task would not fit the LDS)

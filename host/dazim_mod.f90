@@ -37,8 +37,8 @@ module dazim_mod
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
   logical, save :: dazim_fill_dense = .true.
   ! device buffers of the eikonal fields, kept between calls of dazim_assemble_G (one per outer iteration, same sizes)
-  type(c_ptr), save :: fld_ptr(5) = c_null_ptr
-  integer(c_size_t), save :: fld_bytes(5) = 0
+  type(c_ptr), save :: fld_ptr(9) = c_null_ptr
+  integer(c_size_t), save :: fld_bytes(9) = 0
 
   type, bind(C) :: dazim_refbox
     integer(c_int) :: vnl, vnr, vnt, vnb, nnxr, nnzr, isx, isz
@@ -127,6 +127,9 @@ module dazim_mod
       real(c_double) :: svs(*), svp(*), srho(*)
       type(c_ptr) :: G
       integer(c_int64_t) :: nnz
+    end function
+    integer(c_int) function dazim_memcpy_h2d(ctx, dst, src, bytes) bind(C, name="dazim_memcpy_h2d")
+      import; type(c_ptr), value :: ctx, dst, src; integer(c_size_t), value :: bytes
     end function
     integer(c_int) function dazim_malloc(ctx, p, bytes) bind(C, name="dazim_malloc")
       import; type(c_ptr), value :: ctx; type(c_ptr) :: p; integer(c_size_t), value :: bytes
@@ -258,7 +261,7 @@ contains
     integer(c_int) :: rc
     if (c_associated(dazim_handle)) then
       call dazim_aprod_forget()
-      do q = 1, 5
+      do q = 1, size(fld_ptr)
         if (c_associated(fld_ptr(q))) rc = dazim_free(dazim_handle, fld_ptr(q))
         fld_ptr(q) = c_null_ptr; fld_bytes(q) = 0
       end do
@@ -453,13 +456,20 @@ contains
     logical :: joint
     logical, optional :: ti_here
     integer :: nx, ny, nz, kmaxRc, kmax, nsrcsurf, nrcf, nar
-    real :: vels(nx, ny, nz), dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
+    real, target :: vels(nx, ny, nz)
+    real :: dsurf(*), lsen(*), goxdf, gozdf, dvxdf, dvzdf, depz(nz), minthk
     real*8 :: tRc(*)
     integer :: periods(nsrcsurf, kmax), nrc1(nsrcsurf, kmax), nsrcsurf1(kmax)
     real :: scxf(nsrcsurf, kmax), sczf(nsrcsurf, kmax), rcxf(nrcf, nsrcsurf, kmax), rczf(nrcf, nsrcsurf, kmax)
     type(c_ptr) :: G
     real*8 :: pv(nx*ny, kmaxRc)
-    real*8, allocatable, target :: svs(:, :, :), svp(:, :, :), srho(:, :, :)
+    ! the model and the depth kernels stay on the device: the kernels are only ever multiplied into the rows of G, and with
+    ! device-resident arrays the library computes them on its auxiliary stream beside the eikonal fields (option disp.async).
+    ! dvel / dsvs ... are Fortran names for device addresses (never dereferenced here), so that the interfaces above serve
+    type(c_ptr) :: p_vel, p_svs, p_svp, p_srho
+    real(c_float), pointer :: dvel(:)
+    real(c_double), pointer :: dsvs(:), dsvp(:), dsrho(:)
+    integer(c_size_t) :: nkb
     real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
     integer, allocatable :: per(:), kidx(:), fray(:)
     type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box
@@ -468,9 +478,19 @@ contains
     integer(c_int64_t) :: nnz64
     integer(c_size_t) :: nn
     call dazim_init(0)
-    allocate (svs(nx*ny, kmaxRc, nz), svp(nx*ny, kmaxRc, nz), srho(nx*ny, kmaxRc, nz))
-    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, c_loc(svs), c_loc(svp), &
-                                        c_loc(srho), nfail), 'CalSurfG/depthkernel')
+    nkb = int(nx, c_size_t)*ny*kmaxRc*nz*8
+    call field_buffer(6, int(nx, c_size_t)*ny*nz*4, p_vel)
+    call field_buffer(7, nkb, p_svs)
+    call field_buffer(8, nkb, p_svp)
+    call field_buffer(9, nkb, p_srho)
+    call c_f_pointer(p_vel, dvel, [nx*ny*nz])
+    call c_f_pointer(p_svs, dsvs, [nx*ny*kmaxRc*nz])
+    call c_f_pointer(p_svp, dsvp, [nx*ny*kmaxRc*nz])
+    call c_f_pointer(p_srho, dsrho, [nx*ny*kmaxRc*nz])
+    call check(dazim_memcpy_h2d(dazim_handle, p_vel, c_loc(vels), int(nx, c_size_t)*ny*nz*4), 'CalSurfG/model')
+    call check(dazim_set_option(dazim_handle, 'disp.async'//c_null_char, 1_c_int), 'option')
+    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, dvel, depz, minthk, kmaxRc, tRc, pv, p_svs, p_svp, &
+                                        p_srho, nfail), 'CalSurfG/depthkernel')
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
     if (joint .and. present(ti_here)) then
       if (ti_here) call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
@@ -504,13 +524,13 @@ contains
     call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, pv, nfield, scx, scz, per, &
                                d_veln, d_ttn, d_ttnr, d_nstsr, d_box, c_null_ptr), 'CalSurfG/travel')
     if (joint) then
-      call check(dazim_rays_build_G_joint(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
+      call check(dazim_rays_build_G_joint(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, scx, scz, &
                                     per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
-                                    svs, svp, srho, lsen, dsurf, G, nnz64, nb), 'CalSurfGAnisoJoint/rpathsAzim')
+                                    dsvs, dsvp, dsrho, lsen, dsurf, G, nnz64, nb), 'CalSurfGAnisoJoint/rpathsAzim')
     else
-      call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, vels, nfield, scx, scz, &
+      call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, scx, scz, &
                                     per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
-                                    svs, svp, srho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+                                    dsvs, dsvp, dsrho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
     end if
     nar = int(nnz64)
     if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
