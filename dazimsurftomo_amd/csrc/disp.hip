@@ -22,6 +22,7 @@ constexpr int NP = 60;        // inv/surfdisp96.f:59
 constexpr int NZMAX = 64;     // knots per column we accept
 constexpr int DT = 256;       // threads per workgroup
 constexpr int TW = 64;        // work items per task: one wavefront's (see disp_kernel)
+constexpr int TEAM = 16;      // lanes of a work item in the wide bracket search (DispArgs::team)
 constexpr int NEVN = 11;      // Neville points kept (x(1..11), inv/surfdisp96.f:569,655)
 
 struct Layer {   // per refined layer, geometry only
@@ -35,6 +36,7 @@ struct Layer {   // per refined layer, geometry only
 
 struct DispArgs {
   int ncol, nz, kmax, nvar, mmax;
+  int team;            // lanes per work item: 1, or TEAM when an item's bracket search visits TEAM grid points at a time (see disp_kernel)
   int var0, nvarp;     // the variants this launch works on: var0 .. var0 + nvarp - 1 of every column (all of them: 0, nvar; with
                        // option disp.async the column's own curve, 0 / 1, and its perturbed copies, 1 / nvar - 1, are two launches)
   const float *vel;  // [nz][ncol]
@@ -321,7 +323,7 @@ __device__ __forceinline__ void brocher(float vs, float &vp, float &rho) {  // i
   rho = 1.6612f * p - 0.4721f * p2 + 0.0671f * p3 - 0.0043f * p4 + 0.000106f * p5;
 }
 
-enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_GV, P_DONE };
+enum { P_G1, P_G2, P_N0, P_NA, P_NB, P_GV, P_GW, P_DONE };
 
 // start-up of surfdisp96 (:134-216): extremal velocities of the layer stack and the start value of the first period's search
 template <int RDEN>
@@ -502,7 +504,7 @@ __global__ __launch_bounds__(64) void disp_bracket_kernel(DispArgs A) {
 #ifdef DZ_DISP_STAT
 __device__ unsigned long long g_disp_stat[4];
 #endif
-template <int RDEN>
+template <int RDEN, bool TEAMS = false>
 __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   __shared__ Layer s_lay[NL];
   __shared__ double s_t[NP];
@@ -518,7 +520,16 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
   // table and the periods, nothing else, and with 256-item tasks each waited for the slowest of the four at every task
   // boundary -- 8.3 % of the lane-evaluations a workgroup offered went unused, 3.4 % of those a wavefront offers
   // (tools/disp_stat.sh).  No barrier inside the loop: a wavefront's LDS accesses execute in order.
-  const int cpb = (TW + nvarp - 1) / nvarp + 1;  // columns the work items of one group may span
+  // Teams (the column curves of a launch that leaves most of the chip idle: small batches with disp.async).  An item's chain is
+  // ~33 secular evaluations per period one after the other, and two thirds of them are the bracket search walking up from below
+  // the last root in steps of dc -- a sequence of points that does not depend on the function values (c2 = c1 +- dc, turned round
+  // at clow, :437-452), only its END does.  With team = TEAM an item is held by TEAM lanes with identical state; when the search
+  // advances, lane t evaluates the t-th point of that sequence, the first sign change (or bound violation) among them is taken
+  // exactly as the step-by-step search would have met it, the rest is discarded, and the Neville iteration runs redundantly on
+  // all lanes.  ~12 instead of ~33 evaluation latencies per period; bit-identical curves (tests/test_disp_gpu.py).
+  const int team = TEAMS ? TEAM : 1, tw = TW / team;       // lanes per item, items per task (A.team says which instantiation runs)
+  const int tl = lane & (team - 1), tsh = lane & ~(team - 1);
+  const int cpb = (tw + nvarp - 1) / nvarp + 1;  // columns the work items of one group may span
   float *s_knot = s_knots + (size_t)(tid >> 6) * cpb * 3 * nz;
   const unsigned ntask = (unsigned)A.ngroup * (unsigned)A.nchunk;
   for (;;) {
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     __threadfence();   // acquire side for the lanes that did not spin: the state written by another workgroup is visible
     const int chunk = (int)(task / (unsigned)A.ngroup), grp = (int)(task - (unsigned)chunk * (unsigned)A.ngroup);
     const int kbeg = chunk * A.pchunk, kend = min(kbeg + A.pchunk, kmax);
-    const long w0 = (long)grp * TW;
+    const long w0 = (long)grp * tw;
     const int col0 = (int)(w0 / nvarp);
     for (int i = lane; i < cpb * nz; i += TW) {
       const int c = i / nz, k = i - c * nz, col = col0 + c;
@@ -550,7 +561,7 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const long w = w0 + lane;
+    const long w = w0 + (team > 1 ? lane / team : lane);
     const bool active = w < nwork;
     const int col = active ? (int)(w / nvarp) : col0;
     const int var = active ? A.var0 + (int)(w - (long)col * nvarp) : 0;
@@ -608,6 +619,8 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     double omega = TWOPI / s_t[kbeg];
     double ceval = c1;
     bool failed = false;
+    double wc1 = 0.0, wc2 = 0.0;   // team mode: this lane's step of the wide bracket search (its c1 and c2)
+    int wid = 1;                   // ... and the direction after it
 
 #ifdef DZ_DISP_STAT
     unsigned long long st_iter = 0, st_act = 0;
@@ -672,6 +685,36 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
               advance_bracket = true;
           }
           break;
+        case P_GW: if (TEAMS) {   // TEAM points of the bracket search at once (see above): the first event among them, in the search's order
+          const unsigned neg = (unsigned)(__ballot(sgn(del) < 0.0) >> tsh) & ((1u << TEAM) - 1u);
+          const unsigned prevneg = ((neg << 1) | (sgn(del1) < 0.0 ? 1u : 0u)) & ((1u << TEAM) - 1u);
+          const unsigned chg = neg ^ prevneg;                                     // bit j: sgn(del1) != sgn(del2) at step j
+          const unsigned bad = (unsigned)(__ballot(wc2 < cm || wc2 >= ((double)betmx + dc)) >> tsh) & ((1u << TEAM) - 1u);
+          const int jchg = chg ? __builtin_ctz(chg) : TEAM, jbad = bad ? __builtin_ctz(bad) : TEAM;
+          if (jchg < TEAM && jchg <= jbad) {      // step jchg brackets the root (its bound test is never reached) -> nevill
+            const double dprev = __shfl(del, tsh + (jchg > 0 ? jchg - 1 : 0));
+            if (jchg > 0) del1 = dprev;
+            c1 = __shfl(wc1, tsh + jchg);
+            c2 = __shfl(wc2, tsh + jchg);
+            del2 = __shfl(del, tsh + jchg);
+            idir = __shfl(wid, tsh + jchg);
+            c3 = 0.5 * (c1 + c2);
+            ceval = c3;
+            phase = P_N0;
+            nev = 1;
+            nctrl = 1;
+            mm = 1;
+          } else if (jbad < TEAM) {               // step jbad moved c1 out of bounds before any sign change
+            c1 = __shfl(wc2, tsh + jbad);
+            fail = true;
+          } else {                                // no event: go on from the last point
+            c1 = __shfl(wc2, tsh + TEAM - 1);
+            del1 = __shfl(del, tsh + TEAM - 1);
+            idir = __shfl(wid, tsh + TEAM - 1);
+            advance_bracket = true;
+          }
+        }
+          break;
         case P_N0:
         case P_NB:
           del3 = del;
@@ -682,7 +725,26 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
           nev_body = true;
           break;
       }
-      if (advance_bracket) {
+      if (TEAMS && advance_bracket) {   // lane tl of the team: the (tl+1)-th point the step-by-step search would visit from here
+        double a = c1;
+        int id = idir;
+        for (int i = 0; i <= tl; i++) {
+          for (;;) {
+            wc2 = (id > 0) ? a + dc : a - dc;
+            if (wc2 <= clow) {
+              id = 1;
+              a = clow;
+              continue;
+            }
+            break;
+          }
+          wc1 = a;          // the c1 this step works with (clow if the search was turned round in it)
+          a = wc2;          // c1 = c2 for the next step
+        }
+        wid = id;
+        ceval = wc2;
+        phase = P_GW;
+      } else if (!TEAMS && advance_bracket) {
         for (;;) {
           c2 = (idir > 0) ? c1 + dc : c1 - dc;
           if (c2 <= clow) {
@@ -921,6 +983,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   A.nvar = nvar;
   A.var0 = 0;
   A.nvarp = nvar;
+  A.team = 1;
   A.mmax = mmax;
   A.vel = vel.dev;
   if ((rc = dz_scratch(ctx, "disp.lay", sizeof(Layer) * NL, &p))) return rc;
@@ -935,7 +998,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   int *d_nfail = (int *)p;
   DZ_HIP(hipMemsetAsync(d_nfail, 0, 4, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
-  auto knot_lds = [&](int nvarp) { return (size_t)(DT / TW) * ((TW + nvarp - 1) / nvarp + 1) * 3 * nz * sizeof(float); };
+  auto knot_lds = [&](int nvarp, int items = TW) { return (size_t)(DT / TW) * ((items + nvarp - 1) / nvarp + 1) * 3 * nz * sizeof(float); };
   // Option disp.async (device-resident vel and sen_* -- pvRc may be a host array, it is complete and copied when the call
   // returns --, depth kernels wanted, one period chunk): the column's own curves -- all the
   // eikonal solve needs -- are one launch on the context's stream, the 6*nz perturbed copies (72/73 of the work, wanted only by
@@ -946,12 +1009,20 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   // small batches (S-128) the two kernels, neither of which fills it, run side by side.
   bool async = kernels && ctx->opts.count("disp.async") && ctx->opts["disp.async"] && !vel.staged && !svs.staged &&
                !svp.staged && !srho.staged && !(ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0 && ctx->opts["disp.pchunk"] < kmax);
-  const size_t dyn_lds = knot_lds(nvar), dyn_lds_base = knot_lds(1);
+  // the column curves of an asynchronous call in teams (disp_kernel: TEAM grid points of the bracket search at a time) when the
+  // copies leave room for the extra wavefronts -- less than a round of workgroups; option disp.team = 1 / 2 forces them on / off
+  bool teams = (double)(((long)ncol * (nvar - 1) + DT - 1) / DT) + (double)((ncol * TEAM + DT - 1) / DT) <= 0.98 * (double)((long)ctx->num_cu * 3);   // (test4_Yunnan, 1.01 of a round with teams: 62 -> 25 ms of column curves, but the copies beside them 139 -> 163 ms: no gain)
+  if (ctx->opts.count("disp.team") && ctx->opts["disp.team"] == 1) teams = true;
+  if (ctx->opts.count("disp.team") && ctx->opts["disp.team"] == 2) teams = false;
+  const size_t dyn_lds = knot_lds(nvar), dyn_lds_base = teams ? knot_lds(1, TW / TEAM) : knot_lds(1);
   if (dyn_lds_base + 56 * 1024 > 160 * 1024) async = false;   // (very many knots: the 64 columns of a base task would not fit the LDS)
   const size_t dyn_max = async && dyn_lds_base > dyn_lds ? dyn_lds_base : dyn_lds;
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
   DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+  DZ_HIP(hipFuncSetAttribute((const void *)disp_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
   if (async && (rc = dz_aux_init(ctx))) return rc;
   {
     const long nwork = (long)ncol * nvar;
@@ -1020,7 +1091,14 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       DZ_HIP(hipGetLastError());
     }
     auto launch = [&](const DispArgs &B, long nwgB, size_t lds, hipStream_t st) {
-      if (rden == 1)
+      if (B.team > 1) {
+        if (rden == 1)
+          hipLaunchKernelGGL((disp_kernel<1, true>), dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+        else if (rden == 2)
+          hipLaunchKernelGGL((disp_kernel<2, true>), dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+        else
+          hipLaunchKernelGGL((disp_kernel<0, true>), dim3((unsigned)nwgB), dim3(DT), lds, st, B);
+      } else if (rden == 1)
         hipLaunchKernelGGL(disp_kernel<1>, dim3((unsigned)nwgB), dim3(DT), lds, st, B);
       else if (rden == 2)
         hipLaunchKernelGGL(disp_kernel<2>, dim3((unsigned)nwgB), dim3(DT), lds, st, B);
@@ -1047,7 +1125,9 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       DispArgs B = A;
       B.var0 = 0;
       B.nvarp = 1;
-      B.ngroup = (ncol + TW - 1) / TW;
+      B.team = teams ? TEAM : 1;
+      B.ngroup = (ncol + TW / B.team - 1) / (TW / B.team);
+      ctx->ksec["disp.team"] = B.team;
       if ((rc = dz_scratch(ctx, "disp.ready_b", (size_t)B.ngroup * 4 + 64, &p))) return rc;
       B.ready = (int *)p;
       B.counter = (unsigned *)((char *)p + (size_t)B.ngroup * 4 + 16 - ((size_t)B.ngroup * 4) % 16);

@@ -95,6 +95,8 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * whatever is called next (the eikonal fields); dazim_rays_build_G*, the next dazim_dispersion_kernels, dazim_free and
  * dazim_sync join that stream.  Until one of them has been called sen_* are incomplete and vel must not be overwritten.
  * dazim_last_kernel_seconds("disp") is then the main stream's part, ("disp.copies") the auxiliary stream's (waits for it).
+ * "disp.team": 1 / 2 = the column curves of such a call are / are not searched by 16 lanes per column, 16 grid points of the
+ * bracket search at a time (default 0: when curves and copies together leave the chip under-filled; identical results).
  * "fmm.wg_per_cu": resident eikonal workgroups per CU (measurement).  "disp.ffwd": 0 = the first period's bracket search goes
  * step by step from its start value like the reference's (default: it jumps to the bracket that a parallel evaluation of the
  * same grid points found for the column's model; identical results).  "disp.pchunk": periods per

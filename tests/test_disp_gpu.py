@@ -349,3 +349,49 @@ def test_two_stream_dispersion_is_bit_identical_and_joined_by_its_consumers():
                 assert np.array_equal(a, b)
             for a, b in zip(out[3:], res[3:]):
                 assert np.array_equal(a, b)
+
+
+def test_column_curves_in_teams_are_bit_identical():
+    """disp.async with the columns' own curves searched in teams (16 lanes per column, 16 grid points of the bracket search at
+    a time, disp.team = 1) against the one-stream, one-lane-per-item search: pvRc, failures and depth kernels bit for bit on
+    ordinary columns, a deep 18-knot model with 36 periods, a low-velocity zone with reversed dispersion (the search runs
+    downwards and is turned round at its lower bound), a column without a root (bound violation before any sign change), and
+    columns whose knots are drawn independently at random"""
+    import torch
+    import dazimsurftomo_amd as dz
+    dev = torch.device("cuda:0")
+    cases = []
+    depz = np.arange(12, dtype=np.float32) * 5.0
+    cases.append((model(9, 7, depz, 5), depz, np.arange(5, 37, 2, dtype=np.float64), 3.0))
+    depz = np.array([0, 3, 6, 9, 12, 16, 20, 25, 30, 35, 40, 50, 60, 70, 80, 100, 120, 150], np.float32)
+    cases.append((model(6, 5, depz, 6), depz, np.arange(5, 41, dtype=np.float64), 4.0))
+    depz = np.array([0.0, 5.0, 10.0, 20.0, 35.0, 60.0], np.float32)
+    vel = np.zeros((6, 2, 3), np.float32)
+    vel[:] = np.array([3.4, 3.6, 2.9, 3.2, 3.9, 4.4], np.float32)[:, None, None]
+    vel[:, 1, :] *= np.float32(1.03)
+    cases.append((vel, depz, np.arange(4, 44, 2, dtype=np.float64), 3.0))
+    depz = np.array([0.0, 10.0, 20.0, 40.0], np.float32)
+    vel = np.zeros((4, 1, 2), np.float32)
+    vel[:, 0, 0] = [3.0, 3.5, 3.9, 4.3]
+    vel[:, 0, 1] = [4.6, 4.4, 3.0, 2.6]
+    cases.append((vel, depz, np.array([5.0, 10.0, 20.0, 40.0, 60.0]), 2.0))
+    rng = np.random.default_rng(4242)
+    cases.append((rng.uniform(2.6, 4.7, (len(ROUGH_DEPZ), 20, 30)).astype(np.float32), ROUGH_DEPZ, ROUGH_T, 2.0))
+    for vel, depz, t, minthk in cases:
+        d_vel = torch.from_numpy(np.ascontiguousarray(vel)).to(dev)
+        out = {}
+        for mode in (0, 1):
+            c = dz.Context(0)
+            if mode:
+                c.set_option("disp.async", 2)
+                c.set_option("disp.team", 1)
+            pv, sen, nf = c.depthkernel(d_vel, depz, t, minthk)
+            if mode:
+                assert c.kernel_seconds("disp.async") == 1 and c.kernel_seconds("disp.team") == 16
+            pv_now = pv.clone()
+            c.sync()
+            out[mode] = (pv_now.cpu().numpy(), [s.cpu().numpy() for s in sen], nf)
+            c.close()
+        assert out[0][2] == out[1][2] and np.array_equal(out[0][0], out[1][0]), (vel.shape, np.abs(out[0][0] - out[1][0]).max())
+        for a, b in zip(out[0][1], out[1][1]):
+            assert np.array_equal(a, b)
