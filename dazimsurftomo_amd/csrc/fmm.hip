@@ -182,7 +182,10 @@ constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 // 511 x 511 grid, and only while the front is near its largest), so the common path pays a few wave-uniform tests.
 template <int CAP, bool SPILL, class NT, bool HYB = false>
 struct Heap {
-  static constexpr int TOT = HYB ? 2 * CAP : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
+  // HBM levels of the hybrid heap: one, or two below 512 LDS slots with 32-bit node ids (grids of 257..682 nodes a side: levels
+  // 1-9 in LDS, levels 10 and 11 in HBM -- see run_fmm's dispatch)
+  static constexpr int NH = (HYB && sizeof(NT) == 4 && CAP == 512) ? 2 : 1;
+  static constexpr int TOT = HYB ? (CAP << NH) : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
@@ -259,14 +262,22 @@ struct Heap {
   __device__ __forceinline__ int rise_par(bool live, int gl, int gbase, int c, float key, int node) {
     const int a = c >> (gl + 1);
     const bool valid = live && a >= 1;
-    const int rs = valid ? a : 0;
-    const float ak = keys[rs];
-    const NT an = nodes[rs];
+    const bool ahi = HYB && NH > 1 && valid && a >= CAP;   // (two HBM levels: the parent of a slot of the lower one lies in the upper one)
+    const int rs = (valid && !ahi) ? a : 0;
+    float ak = keys[rs];
+    NT an = nodes[rs];
+    if (HYB && NH > 1 && __ballot(ahi) != 0) {
+      if (ahi) {
+        const HEnt e = ovf[a - CAP];
+        ak = e.key;
+        an = (NT)e.node;
+      }
+    }
     const unsigned mb = (unsigned)(__ballot(valid && key < ak) >> gbase) & 0xffffu;
     const int L = __builtin_ctz(~mb);                      // (bit 16 of ~mb is set: L <= 16, and <= 11 by the heap depth)
     const bool mover = live && gl < L;
     const int dst = mover ? (c >> gl) : 0;
-    // (HYB: only slot c itself can lie in the HBM level -- lane 0's destination, or the entry's own if it does not rise)
+    // (HYB: slot c itself -- lane 0's destination, or the entry's own if it does not rise -- and, with two HBM levels, its parent)
     const bool dhi = HYB && dst >= CAP;
     const int ldst = dhi ? 0 : dst;
     keys[ldst] = ak;
@@ -457,8 +468,13 @@ struct Heap {
     }
     if (HYB) {
       // the hole reached the last level of the LDS part and has children: they live in HBM.  One sequential step of downtree
-      // (:857-866): the smaller child, ties to the left, moves up if it is smaller than the moving key.
-      if (__ballot(deep) != 0) {
+      // (:857-866) per HBM level: the smaller child, ties to the left, moves up if it is smaller than the moving key.  A child
+      // that moves up INTO the LDS part keeps its word (lazy, like every move of the parallel steps: march() finds it one level
+      // above the recorded slot); one that moves from the lower to the upper HBM level stores its slot, so that the words of the
+      // entries in the HBM levels are exact -- march() cannot search there.
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        if (__ballot(deep) == 0) break;
         if (deep) {
           const HEnt *ch = ovf + (2 * p - CAP);
           const HEnt c0 = ch[0];
@@ -467,10 +483,17 @@ struct Heap {
           const bool right = c0.key > c1.key;
           const float ck = right ? c1.key : c0.key;
           const int cn = right ? c1.node : c0.node;
+          deep = false;
           if (ck < mvk) {
-            keys[p] = ck;
-            nodes[p] = (NT)cn;
+            if (h == 0) {
+              keys[p] = ck;
+              nodes[p] = (NT)cn;
+            } else if (g0) {
+              ovf[p - CAP] = HEnt{ck, cn};
+              set_slot((unsigned)cn, p);
+            }
             p = 2 * p + (right ? 1 : 0);
+            deep = NH > h + 1 && 2 * p <= ntr;
           }
         }
       }
@@ -822,6 +845,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (band) {
         if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
         else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
+        // (... unless THIS pop's sift-down took it from the lower HBM level up to the upper one: the word was loaded before)
+        else if (HYB && Heap<CAP, SPILL, NT, HYB>::NH > 1 && srec >= 2 * CAP && srec == fin_slot) stfix = srec >> 1;
       }
     }
     PROF(4);
@@ -841,12 +866,21 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
       const bool room = H.ntr + cnt < TOT;
       const int pc = c >> 1;
-      float pk = H.keys[(act && room) ? pc : 0];
+      constexpr int NH = Heap<CAP, SPILL, NT, HYB>::NH;
+      const bool pchi = HYB && NH > 1 && act && room && pc >= CAP;   // (two HBM levels: the parent of a slot of the lower one)
+      float pk = H.keys[(act && room && !pchi) ? pc : 0];
       // (for the one-level rise below: the grandparent's key and the parent's node, requested with the parent's key so that
       // they cost no LDS round trip of their own)
       const int gp = pc >> 1;
       const float gk = H.keys[(act && room && gp >= 1) ? gp : 0];
-      const NT pn = H.nodes[(act && room) ? pc : 0];
+      NT pn = H.nodes[(act && room && !pchi) ? pc : 0];
+      if (HYB && NH > 1 && __ballot(pchi) != 0) {
+        if (pchi) {
+          const HEnt e = H.ovf[pc - CAP];
+          pk = e.key;
+          pn = (NT)e.node;
+        }
+      }
       const int cact = act ? c : 0;
       const int c0 = dpp_i<DPP_BCAST0 + 0>(cact), c1 = dpp_i<DPP_BCAST0 + 4>(cact), c2 = dpp_i<DPP_BCAST0 + 8>(cact);
       const float t0 = dpp_f<DPP_BCAST0 + 0>(trav), t1 = dpp_f<DPP_BCAST0 + 4>(trav), t2 = dpp_f<DPP_BCAST0 + 8>(trav);
@@ -1368,7 +1402,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   if (nwg > (nfield + A.fpw - 1) / A.fpw) nwg = (nfield + A.fpw - 1) / A.fpw;
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
-  A.ovfcap = HYB ? CAP : 0;                                // the fast kernel: only the HYB heap has an HBM level (CAP slots per field)
+  A.ovfcap = HYB ? Heap<CAP, false, NT, HYB>::TOT - CAP : 0;   // the fast kernel: only the HYB heap has HBM levels
   // Time slicing (see fmm_kernel): on when the batch does not fit the resident slots (more than one round) and the per-field node
   // words fit comfortably; option fmm.ts = 1 / 2 forces it on / off (0: this rule), fmm.ts_stages sets the number of coarse stages.
   // Few stages are best (not because of the hand-over fences: tools/exp_ts_fences.sh; with many short stages handed out
@@ -1376,7 +1410,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // fields on the 512-slot hybrid heap take 0.240 / 0.253 / 0.248 / 0.249 / 0.252 s with 2 / 3 / 4 / 8 / 12 coarse stages
   // (0.288 s unsliced on the 768-slot heap, same box), the 768-slot heap 0.292 / 0.264 / 0.262 s with 2 / 4 / 8-12; S-512's
   // 32 000 fields (1024-slot hybrid heap) 4.29 s unsliced, 4.03 / 3.96 / 3.97 s with 2 / 4 / 8.  Defaults: 2 on the 512-slot hybrid
-  // heap, 4 elsewhere.
+  // heap with 16-bit ids, 8 on the one with two HBM levels (S-512: 2.68 / 2.63 / 2.61 s with 2 / 4 / 8), 4 elsewhere.
   bool ts = nfield > nslot;
   if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 1) ts = true;
   if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 2) ts = false;
@@ -1385,7 +1419,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     size_t mfree = 0, mtot = 0;
     if (hipMemGetInfo(&mfree, &mtot) != hipSuccess || (size_t)nfield * rec_field_bytes > mfree / 4) ts = false;
   }
-  int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (HYB && CAP <= 512 ? 2 : 4);
+  int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (HYB && CAP <= 512 ? (sizeof(NT) == 2 ? 2 : 8) : 4);
   A.ts_nstage = ts ? 1 + nseg : 1;
   // (stage lengths that shrink towards the end -- a shorter tail -- were measured and lose: 0.251-0.265 s against 0.247 s)
   A.ts_pops = (int)((nn + nseg - 1) / nseg);
@@ -1620,6 +1654,9 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     bool use_hyb512 = cap > 512 && nfield > ctx->num_cu * 8 * FPW;
     if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 1) use_hyb512 = true;
     if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 2) use_hyb512 = false;
+    // (fmm.hyb2 = 2, fmm.no_hybrid = 1 or an explicit fmm.cap: the one-level hybrid / all-LDS heaps of the branches below)
+    bool use_hyb2 = !(ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 2) && cap > 768;
+    if ((ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"]) || (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0)) use_hyb2 = false;
     if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     // grids of 171 .. 256 nodes a side (S-256) with more fields than the 768-slot heaps hold at once (8 workgroups of 4 per CU):
@@ -1628,6 +1665,12 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     // occupancy), so batches that fit the 768-slot heaps stay there.  Option fmm.hyb512 = 1 / 2 forces it on / off.
     else if (cap <= 768 && small && use_hyb512) rc = run_fmm<512, unsigned short, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    // grids of 257 .. 682 nodes a side (S-512): levels 1-9 in LDS, levels 10 and 11 in HBM -- 16 KB of LDS per workgroup, ten
+    // workgroups per CU instead of five.  These kernels wait on latencies (1.25 wavefronts per SIMD with 1024 LDS slots), so twice
+    // the wavefronts for one or two more dependent memory accesses per pop is a good trade: 341 x 341 nodes 20.2 -> 31.3 k
+    // fields/s against the all-LDS 1024-slot heap, S-512 7 950 -> 11 300 against levels 1-10 in LDS (same box, bit-identical).
+    // (option fmm.hyb2 = 2: the forms below)
+    else if (cap <= 2048 && use_hyb2) rc = run_fmm<512, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     // grids of 342 .. 682 nodes a side (S-512): levels 1-10 in LDS + level 11 in HBM, four instead of three workgroups per CU
     else if (cap <= 2048 && !(ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"])) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);

@@ -74,9 +74,13 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
     """sources far from every edge of a 511x511 grid: the narrow band outgrows the 1023 LDS slots of the hybrid heap and lives
     partly in its HBM level -- still bit-exact and without a rerun; that the band really gets that large is shown by the plain
     1024-slot heap, which has to hand the same fields to the spill kernel; the all-LDS 1536-slot heap gives the same fields"""
-    _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
-    assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+    _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)            # (default: 511 LDS slots + TWO HBM levels)
+    assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
     try:
+        ctx.set_option("fmm.hyb2", 2)                                    # 1023 LDS slots + one HBM level
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") == 5
+        ctx.set_option("fmm.hyb2", 0)
         ctx.set_option("fmm.no_hybrid", 1)
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
         assert ctx.kernel_seconds("fmm.spilled_fields") == 0
@@ -86,6 +90,23 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
     finally:
         ctx.set_option("fmm.cap", 0)
         ctx.set_option("fmm.no_hybrid", 0)
+        ctx.set_option("fmm.hyb2", 0)
+
+
+def test_fmm_341_two_hbm_levels_below_a_small_lds_part(ctx, orc):
+    """71x71 -> 341x341 nodes (bands up to 1023 entries: the all-LDS 1024-slot heap's size class) on the 511-slot LDS heap with
+    two HBM levels, plain and time-sliced, against the oracle; central and corner sources, and a rough map"""
+    _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
+    assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+    _run_case(ctx, orc, 71, 71, 1, 5, seed=32, edge_sources=True)
+    _run_case(ctx, orc, 71, 71, 1, 3, seed=33, shrink=6.0, rough=True)
+    try:
+        ctx.set_option("fmm.ts", 1)
+        ctx.set_option("fmm.ts_stages", 5)
+        _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
+    finally:
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.ts_stages", 0)
 
 
 def test_fmm_701(ctx, orc):
