@@ -175,11 +175,13 @@ constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 // both grids of a field have at most 65 536 record slots (sides <= 256, the S-256 case: 6 bytes per entry, a third more fields
 // in flight per CU), NT = int otherwise.
 
-// HYB (grids above 341 nodes a side, where 3*max(nnx,nnz) slots of LDS would leave three workgroups per CU): levels 1..10 of
-// the heap (slots < CAP = 1024) live in LDS and are sifted by the parallel routines exactly as in the all-LDS heap; level 11
-// (slots CAP .. 2*CAP-1) lives in the HBM array `ovf` and is reached by one extra sequential step of the sift-down and by the
-// owner lanes' direct writes.  Only fields whose band outgrows 1023 entries ever touch it (sources far from every edge of a
-// 511 x 511 grid, and only while the front is near its largest), so the common path pays a few wave-uniform tests.
+// HYB: the upper levels of the heap (slots < CAP, a power of two) live in LDS and are sifted by the parallel routines exactly as in
+// the all-LDS heap; the NH levels below (slots CAP .. (CAP << NH) - 1) live in the HBM array `ovf` and are reached by one
+// sequential step of the sift-down per level, by the owner lanes' direct writes and by rising entries.  Three uses (run_fmm's
+// dispatch): 512 slots + one HBM level with 16-bit ids on 171..256-node grids when the batch is large (S-256: a third wavefront
+// per SIMD), 512 slots + TWO HBM levels with 32-bit ids on 257..682-node grids (S-512: ten workgroups per CU; these grids wait
+// on latencies, and twice the wavefronts are worth one or two more dependent memory accesses per pop), 1024 slots + one level
+// (the round-2 form of S-512, option fmm.hyb2 = 2).
 template <int CAP, bool SPILL, class NT, bool HYB = false>
 struct Heap {
   // HBM levels of the hybrid heap: one, or two below 512 LDS slots with 32-bit node ids (grids of 257..682 nodes a side: levels
