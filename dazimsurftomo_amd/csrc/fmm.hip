@@ -184,9 +184,9 @@ constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 // (the round-2 form of S-512, option fmm.hyb2 = 2).
 template <int CAP, bool SPILL, class NT, bool HYB = false>
 struct Heap {
-  // HBM levels of the hybrid heap: one, or two below 512 LDS slots with 32-bit node ids (grids of 257..682 nodes a side: levels
-  // 1-9 in LDS, levels 10 and 11 in HBM -- see run_fmm's dispatch)
-  static constexpr int NH = (HYB && sizeof(NT) == 4 && CAP == 512) ? 2 : 1;
+  // HBM levels of the hybrid heap: one with 16-bit node ids, two with 32-bit ids (grids of 257..682 nodes a side: levels 1-9 in
+  // LDS, levels 10 and 11 in HBM; above that levels 1-10 in LDS, 11 and 12 in HBM -- see run_fmm's dispatch)
+  static constexpr int NH = (HYB && sizeof(NT) == 4) ? 2 : 1;
   static constexpr int TOT = HYB ? (CAP << NH) : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
@@ -1656,8 +1656,15 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     bool use_hyb512 = cap > 512 && nfield > ctx->num_cu * 8 * FPW;
     if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 1) use_hyb512 = true;
     if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 2) use_hyb512 = false;
-    // (fmm.hyb2 = 2, fmm.no_hybrid = 1 or an explicit fmm.cap: the one-level hybrid / all-LDS heaps of the branches below)
-    bool use_hyb2 = !(ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 2) && cap > 768;
+    // (fmm.no_hybrid = 1 or an explicit fmm.cap: the one-level hybrid / all-LDS heaps of the branches below)
+    // The small-LDS forms trade latency for wavefronts: a batch that leaves the chip half empty anyway (fewer than 2.5 workgroups
+    // per CU) marches faster on the heaps with more levels in LDS -- 1 600 fields: 511 x 511 nodes 0.60 against 0.71 s, 341 x 341
+    // 0.21 against 0.29 s, 701 x 701 0.86 against 1.33 s; 4 800 fields: 1.08 / 0.82 s and 0.40 / 0.33 s the other way round --
+    // unless the bands would outgrow those (grids above 768 nodes a side: the all-LDS 2048-slot heap hands them to the spill kernel).
+    // fmm.hyb2 = 1 / 2 forces the small-LDS forms on / off.
+    bool use_hyb2 = cap > 768 && ((long)nfield > (long)ctx->num_cu * 10 || cap > 2304);
+    if (ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 1) use_hyb2 = cap > 768;
+    if (ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 2) use_hyb2 = false;
     if ((ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"]) || (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0)) use_hyb2 = false;
     if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
@@ -1674,8 +1681,11 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     // (option fmm.hyb2 = 2: the forms below)
     else if (cap <= 2048 && use_hyb2) rc = run_fmm<512, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
-    // grids of 342 .. 682 nodes a side (S-512): levels 1-10 in LDS + level 11 in HBM, four instead of three workgroups per CU
+    // (fmm.hyb2 = 2) grids of 342 .. 682 nodes a side: levels 1-10 in LDS + levels 11 (and, never reached there, 12) in HBM
     else if (cap <= 2048 && !(ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"])) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
+    // grids above 682 nodes a side: levels 1-10 in LDS, 11 and 12 in HBM (bands up to 4 095 entries = 1 365 nodes a side without
+    // the spill kernel, five workgroups per CU instead of the two of the all-LDS 2048-slot heap)
+    else if (use_hyb2) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 1536) rc = run_fmm<1536, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else rc = run_fmm<2048, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     if (rc) return rc;

@@ -88,9 +88,9 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * "fmm.ts": 1 / 2 = march every batch in stages that any workgroup may continue (time slicing) / never
  * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
  * the 512-slot hybrid heap, 4 elsewhere).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
- * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  "fmm.hyb2": 2 = on
- * grids of 257..682 nodes a side the round-2 heaps (1024 slots in LDS, on 342..682 + one HBM level) instead of 512 LDS slots +
- * two HBM levels.  Speed only, all four.
+ * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  "fmm.hyb2": 1 / 2 =
+ * on grids above 256 nodes a side the heaps with few levels in LDS and two in HBM (512 slots up to 682 nodes, 1024 above) always /
+ * never (default 0: for batches of more than 2.5 workgroups per CU, and above 768 nodes).  Speed only, all four.
  * "disp.async": 1 (where it pays: at most two rounds of workgroups) or 2 (always) = dazim_dispersion_kernels (device-resident
  * arrays, depth kernels wanted) returns when pvRc is complete and
  * leaves the 6*nz perturbed copies of every column -- which only sen_* need -- running on the context's auxiliary stream, beside

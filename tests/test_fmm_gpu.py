@@ -74,9 +74,10 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
     """sources far from every edge of a 511x511 grid: the narrow band outgrows the 1023 LDS slots of the hybrid heap and lives
     partly in its HBM level -- still bit-exact and without a rerun; that the band really gets that large is shown by the plain
     1024-slot heap, which has to hand the same fields to the spill kernel; the all-LDS 1536-slot heap gives the same fields"""
-    _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)            # (default: 511 LDS slots + TWO HBM levels)
-    assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
     try:
+        ctx.set_option("fmm.hyb2", 1)                                    # 511 LDS slots + TWO HBM levels (large batches' default)
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
         ctx.set_option("fmm.hyb2", 2)                                    # 1023 LDS slots + one HBM level
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
         assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") == 5
@@ -96,17 +97,22 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
 def test_fmm_341_two_hbm_levels_below_a_small_lds_part(ctx, orc):
     """71x71 -> 341x341 nodes (bands up to 1023 entries: the all-LDS 1024-slot heap's size class) on the 511-slot LDS heap with
     two HBM levels, plain and time-sliced, against the oracle; central and corner sources, and a rough map"""
-    _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
-    assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10
-    _run_case(ctx, orc, 71, 71, 1, 5, seed=32, edge_sources=True)
-    _run_case(ctx, orc, 71, 71, 1, 3, seed=33, shrink=6.0, rough=True)
     try:
+        ctx.set_option("fmm.hyb2", 1)
+        _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
+        assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+        _run_case(ctx, orc, 71, 71, 1, 5, seed=32, edge_sources=True)
+        _run_case(ctx, orc, 71, 71, 1, 3, seed=33, shrink=6.0, rough=True)
         ctx.set_option("fmm.ts", 1)
         ctx.set_option("fmm.ts_stages", 5)
         _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
+        ctx.set_option("fmm.ts", 0)
+        _run_case(ctx, orc, 143, 143, 1, 3, seed=17, shrink=12.0)       # 701 x 701: levels 1-10 in LDS, 11 and 12 in HBM
+        assert ctx.kernel_seconds("fmm.wg_per_cu") == 5
     finally:
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
+        ctx.set_option("fmm.hyb2", 0)
 
 
 def test_fmm_701(ctx, orc):
@@ -220,8 +226,12 @@ def test_fmm_time_sliced_marches(ctx, orc):
         _run_case(ctx, orc, 54, 54, 1, 6, seed=6, shrink=5.0)          # central sources: bands beyond the 511 LDS slots
         _run_case(ctx, orc, 28, 28, 2, 6, seed=78, rough=True)
         ctx.set_option("fmm.hyb512", 0)
-        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)     # 1023 LDS slots + HBM levels (the small batches' form)
         assert ctx.kernel_seconds("fmm.spilled_fields") == 0
+        ctx.set_option("fmm.hyb2", 1)                                   # 511 LDS slots + two HBM levels (the large batches')
+        _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+        ctx.set_option("fmm.hyb2", 0)
         ctx.set_option("fmm.cap", 64)                                   # overflowing fields are flagged in stage 0 or later and redone
         _run_case(ctx, orc, 17, 17, 2, 6, seed=8, goxd=26.5, gozd=101.25)
         assert ctx.kernel_seconds("fmm.spilled_fields") == 12
@@ -230,6 +240,7 @@ def test_fmm_time_sliced_marches(ctx, orc):
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
         ctx.set_option("fmm.hyb512", 0)
+        ctx.set_option("fmm.hyb2", 0)
 
 
 def test_fmm_large_batch_takes_the_time_sliced_hybrid_path(ctx, orc):
