@@ -29,10 +29,6 @@ constexpr int GDX = 5, GDZ = 5, SGDL = 8, SGS = 8;  // inv/CalSurfG.f90:1005-101
 constexpr int RM = DAZIM_RMAX;
 constexpr float EARTH = 6371.0f;
 
-struct Node {   // a node as the marching loop looks at it (decoded from its word in HBM, see w_alive)
-  float t;
-  int s;  // nsts of the reference: -1 far, 0 alive, >0 slot in the narrow-band heap
-};
 struct __align__(8) HEnt {
   float key;
   int node;  // index of the node's record in the tiled layout (tile_x + tile_z below; the reference keeps int16 px,pz: inv/CalSurfG.f90:238)
@@ -77,6 +73,8 @@ struct FmmArgs {
   int ovfcap;
   unsigned *counter;
   const int *flist;  // nullable: indirection used by the spill rerun
+  int fastm;         // grid steps within the range in which the short exact division / square root may run (see div_exact)
+  const int *vflag;  // [1] set by gridder_kernel when a phase velocity lies outside that range
   int fpw;           // fields a wavefront takes per batch (1, 2 or FPW = 4 of its 16-lane groups are active): see run_fmm
   // time slicing (see fmm_kernel): a field is marched in ts_nstage tasks -- stage 0 = refined march + injection, stages 1.. =
   // ts_pops accepted nodes of the coarse march each (the last one: to the end) -- that may run on different workgroups
@@ -118,8 +116,11 @@ constexpr int TSH_R = tile_shift(DAZIM_RMAX);                       // refined g
 constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 33 792 record slots per refined field
 
 // ---- gridder: inv/CalSurfG.f90:1423-1516, one thread per propagation node -------------------
+// FAST_V*: the velocities between which fmm_kernel may use the short exact division / square root (div_exact); veln and velnr are
+// convex combinations of the pv values (the cubic B-spline weights are non-negative and sum to one)
+constexpr float FAST_VMIN = 0.125f, FAST_VMAX = 16.0f, FAST_STEP_MIN = 2.0f, FAST_STEP_MAX = 4096.0f;
 __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict__ pv,
-                               float *__restrict__ veln, float *__restrict__ slown) {
+                               float *__restrict__ veln, float *__restrict__ slown, int *__restrict__ vflag) {
   const int nn = g.nnx * g.nnz;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nn * kmax) return;
@@ -136,14 +137,19 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
   bspl4((float)(l - 1) / (float)GDZ, vi);
   const double *p = pv + (size_t)k * (g.nvz + 2) * (g.nvx + 2);
   float sumi = 0.0f;
+  bool bad = false;
 #pragma unroll
   for (int i1 = 1; i1 <= 4; i1++) {
     float sumj = 0.0f;
 #pragma unroll
-    for (int j1 = 1; j1 <= 4; j1++)
-      sumj = sumj + ui[j1 - 1] * (float)p[(i - 2 + i1) * (g.nvx + 2) + (j - 2 + j1)];
+    for (int j1 = 1; j1 <= 4; j1++) {
+      const float pf = (float)p[(i - 2 + i1) * (g.nvx + 2) + (j - 2 + j1)];
+      if (!(pf >= FAST_VMIN && pf <= FAST_VMAX)) bad = true;
+      sumj = sumj + ui[j1 - 1] * pf;
+    }
     sumi = sumi + vi[i1 - 1] * sumj;
   }
+  if (bad) *vflag = 1;
   veln[tid] = sumi;
   slown[(size_t)k * tile_records(g.nnx, g.nnz) + tile_x(stx - 1, tile_shift(g.nnz)) + tile_z(stz - 1)] = 1.0f / sumi;   // 4 x 4 tiles
 }
@@ -156,6 +162,10 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
 // sift-down (all-in-LDS and hybrid heaps) an ancestor-or-self relation of the true slot (lazy back-pointers, see march()).
 constexpr int GP = 16;   // lanes per field
 constexpr int FPW = 4;   // fields per wavefront
+
+// __ballot(int) of the HIP headers turns its predicate into 0/1 and compares it with zero again (two VALU instructions per ballot
+// whenever the predicate is a combination of lane masks); the builtin takes the lane mask as it stands.
+__device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier:
 // same-wave LDS/VMEM operations execute in program order, so no s_waitcnt is needed for lane 0's
@@ -268,14 +278,14 @@ struct Heap {
     const int rs = (valid && !ahi) ? a : 0;
     float ak = keys[rs];
     NT an = nodes[rs];
-    if (HYB && NH > 1 && __ballot(ahi) != 0) {
+    if (HYB && NH > 1 && wballot(ahi) != 0) {
       if (ahi) {
         const HEnt e = ovf[a - CAP];
         ak = e.key;
         an = (NT)e.node;
       }
     }
-    const unsigned mb = (unsigned)(__ballot(valid && key < ak) >> gbase) & 0xffffu;
+    const unsigned mb = (unsigned)(wballot(valid && key < ak) >> gbase) & 0xffffu;
     const int L = __builtin_ctz(~mb);                      // (bit 16 of ~mb is set: L <= 16, and <= 11 by the heap depth)
     const bool mover = live && gl < L;
     const int dst = mover ? (c >> gl) : 0;
@@ -293,7 +303,7 @@ struct Heap {
       nodes[fin] = (NT)node;
     }
     if (last) set_slot((unsigned)node, fin);
-    if (HYB && __ballot(dhi || fhi) != 0) {
+    if (HYB && wballot(dhi || fhi) != 0) {
       if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
     }
@@ -400,7 +410,7 @@ struct Heap {
     const int mls = mhi ? 0 : ntr;
     float mvk = keys[mls];
     NT mvc = nodes[mls];
-    if (HYB && __ballot(mhi) != 0) {
+    if (HYB && wballot(mhi) != 0) {
       if (mhi) {
         const HEnt e = ovf[ntr - CAP];
         mvk = e.key;
@@ -426,7 +436,7 @@ struct Heap {
     bool active = true, deep = false;
 #pragma unroll
     for (int b = 0; b < NSTEP; b++) {
-      if (b > 0 && __ballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
+      if (b > 0 && wballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
       // straight-line code: lanes with nothing to read use the pair at slot 0 (slot 0 is never a heap entry, slot 1 is only
       // read), lanes with nothing to move write their entry to slot 0
       const int s = (p << dq) + oq;                        // this lane's parent slot
@@ -449,14 +459,14 @@ struct Heap {
       const bool right = k0 > k1;                          // left child strictly greater -> the hole goes right
       const float ck = right ? k1 : k0;
       const int cn = right ? n1 : n0;
-      const unsigned long long gtm = __ballot(right);
-      const unsigned long long ltm = __ballot(ck < mvk);
+      const unsigned long long gtm = wballot(right);
+      const unsigned long long ltm = wballot(ck < mvk);
       const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & 0xffffu;
       const bool mine = (gt & G) == E && (lt & A) == A;    // (an inactive group has ck = +inf everywhere: nobody moves)
       const int dst = mine ? s : 0;
       keys[dst] = ck;
       nodes[dst] = (NT)cn;
-      const unsigned mb = (unsigned)(__ballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
+      const unsigned mb = (unsigned)(wballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
         const int qs = 32 - __clz(mb);                    // deepest parent whose child moved up: the hole is at that child now
         const int rt = 2 * qs + (int)((gt >> (qs - 1)) & 1u);
@@ -476,7 +486,7 @@ struct Heap {
       // entries in the HBM levels are exact -- march() cannot search there.
 #pragma unroll
       for (int h = 0; h < NH; h++) {
-        if (__ballot(deep) == 0) break;
+        if (wballot(deep) == 0) break;
         if (deep) {
           const HEnt *ch = ovf + (2 * p - CAP);
           const HEnt c0 = ch[0];
@@ -504,7 +514,7 @@ struct Heap {
     const int lp = phi ? 0 : p;
     keys[lp] = mvk;
     nodes[lp] = mvc;
-    if (HYB && __ballot(phi) != 0) {
+    if (HYB && wballot(phi) != 0) {
       if (phi && g0) ovf[p - CAP] = HEnt{mvk, (int)mvc};
     }
     fin_node = (int)mvc;
@@ -537,13 +547,46 @@ struct Heap {
 // (tests/test_fmm_gpu.py against the oracle on every grid size; option-free, so the old form is kept below for reference only
 // under DZ_FMM_QUADRANT_BRANCHES).
 #ifndef DZ_FMM_QUADRANT_BRANCHES
-__device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, Node nj, Node nj2,
-                                               Node nk, Node nk2, bool vj2, bool vk2) {
+// Exact fp32 division and square root without the range handling the compiler wraps around them (round 4).  x / y is compiled as
+// v_div_scale x 2, v_rcp, the Newton / residual steps below, v_div_fmas, v_div_fixup: the two scale instructions and the fixup only
+// act on operands near the ends of the exponent range (|y| or |x / y| below 2^-126 or above 2^126, |x| < 2^-103), zeros, infinities
+// and NaNs; in between they pass their operands through and the quotient is the one of the FMA steps, which are repeated here as
+// they stand.  run_fmm only lets this form run when the grid's steps and velocities keep every operand within 2^+-30 of one
+// (`fast` false: the compiler's sequences).  Division by three: q = RN(x / 3), then one residual step -- equal to x / 3.0f for every
+// finite float (2^32 cases, tools/check_div3.c).  Square root: v_sqrt_f32 is within one ulp; the two residual tests pick the
+// correctly rounded neighbour (the compiler's own sequence minus its rescaling of arguments below 2^-96 and its class test).
+__device__ __forceinline__ float div_exact(float x, float y, bool fast) {
+  if (!fast) return x / y;
+  float r = __builtin_amdgcn_rcpf(y);
+  const float e = __builtin_fmaf(-y, r, 1.0f);
+  r = __builtin_fmaf(e, r, r);
+  float q = x * r;
+  const float e2 = __builtin_fmaf(-y, q, x);
+  q = __builtin_fmaf(e2, r, q);
+  const float e3 = __builtin_fmaf(-y, q, x);
+  return __builtin_fmaf(e3, r, q);
+}
+__device__ __forceinline__ float div3_exact(float x) {
+  const float third = 1.0f / 3.0f;
+  const float q = x * third;
+  return __builtin_fmaf(__builtin_fmaf(-3.0f, q, x), third, q);
+}
+__device__ __forceinline__ float sqrt_exact(float x, bool fast) {
+  if (!fast) return sqrtf(x);
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
+  const float rm = __builtin_fmaf(-sm, s, x), rp = __builtin_fmaf(-sp, s, x);
+  float o = rm <= 0.0f ? sm : s;
+  o = rp > 0.0f ? sp : o;
+  return o;
+}
+
+// tj, tj2, tk, tk2: the words of the four nodes read as floats (the time, when the node is alive); aj .. ak2: alive and inside the grid
+__device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, float tj, float tj2, float tk,
+                                               float tk2, bool aj, bool aj2, bool ak, bool ak2, bool fast) {
   const float ri = EARTH;
-  const bool aj = nj.s == 0, ak = nk.s == 0;
-  const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
-  const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
-  const float tj = nj.t, tj2 = nj2.t, tk = nk.t, tk2 = nk2.t;
+  const bool so2j = aj2 && aj && tj > tj2;
+  const bool so2k = ak2 && ak && tk > tk2;
   const bool two = aj && ak, both2 = so2j && so2k, mixed = so2j != so2k, onlyj = aj && !ak;
   const float U1 = ri * dnx, U2 = U1 + U1, V1 = risti * dnz, V2 = V1 + V1;
   const float fourtj = 4.0f * tj, fourtk = 4.0f * tk;
@@ -574,87 +617,12 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   const bool third = two ? both2 : so1;            // tdiv = 3 (else 1)
   float rd1 = b * b - 4.0f * a * c;
   if (rd1 < 0.0f) rd1 = 0.0f;
-  const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
+  const float tdsh = div_exact(-b + sqrt_exact(rd1, fast), 2.0f * a, fast);
   const float tsum = tref + tdsh;
-  // (tsum / 3 as convert - multiply by RN(1/3) in double - convert is exact too, tools/check_divr.c 3, but measured 0.5 % slower
-  // than the IEEE fp32 sequence in a same-box A/B: fp64 instructions issue at half rate here)
-  const float t3 = tsum / 3.0f;
+  const float t3 = div3_exact(tsum);
   const float t = third ? t3 : tsum;
   return (aj || ak) ? t : INFINITY;
 }
-#else
-__device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, Node nj, Node nj2,
-                                               Node nk, Node nk2, bool vj2, bool vk2) {
-  const float ri = EARTH;
-  const bool aj = nj.s == 0, ak = nk.s == 0;
-  const bool so2j = vj2 && nj2.s == 0 && aj && nj.t > nj2.t;
-  const bool so2k = vk2 && nk2.s == 0 && ak && nk.t > nk2.t;
-  const float tj = nj.t, tj2 = nj2.t, tk = nk.t, tk2 = nk2.t;
-  float a = 1.0f, b = 0.0f, c = 0.0f, tref = 0.0f, tdiv = 1.0f, u, v, em;
-  if (so2j) {
-    if (so2k) {
-      u = 2.0f * ri * dnx;
-      v = 2.0f * risti * dnz;
-      em = 4.0f * tj - tj2 - 4.0f * tk;
-      em = em + tk2;
-      a = v * v + u * u;
-      b = 2.0f * em * (u * u);
-      c = (u * u) * (em * em - (slown * slown) * (v * v));
-      tref = 4.0f * tj - tj2;
-      tdiv = 3.0f;
-    } else if (ak) {
-      u = risti * dnz;
-      v = 2.0f * ri * dnx;
-      em = 3.0f * tk - 4.0f * tj + tj2;
-      a = v * v + 9.0f * (u * u);
-      b = 6.0f * em * (u * u);
-      c = (u * u) * (em * em - (slown * slown) * (v * v));
-      tref = tk;
-    } else {
-      u = 2.0f * ri * dnx;
-      c = -(u * u) * (slown * slown);
-      tref = 4.0f * tj - tj2;
-      tdiv = 3.0f;
-    }
-  } else if (aj) {
-    if (so2k) {
-      u = ri * dnx;
-      v = 2.0f * risti * dnz;
-      em = 3.0f * tj - 4.0f * tk + tk2;
-      a = v * v + 9.0f * (u * u);
-      b = 6.0f * em * (u * u);
-      c = (u * u) * (em * em - (v * v) * (slown * slown));
-      tref = tj;
-    } else if (ak) {
-      u = ri * dnx;
-      v = risti * dnz;
-      em = tk - tj;
-      a = u * u + v * v;
-      b = -2.0f * (u * u) * em;
-      c = (u * u) * (em * em - (v * v) * (slown * slown));
-      tref = tj;
-    } else {
-      c = -(slown * slown) * (ri * ri) * (dnx * dnx);
-      tref = tj;
-    }
-  } else {
-    if (so2k) {
-      u = 2.0f * risti * dnz;
-      c = -(u * u) * (slown * slown);
-      tref = 4.0f * tk - tk2;
-      tdiv = 3.0f;
-    } else if (ak) {
-      c = -(slown * slown) * (risti * risti) * (dnz * dnz);
-      tref = tk;
-    } else
-      return INFINITY;
-  }
-  float rd1 = b * b - 4.0f * a * c;
-  if (rd1 < 0.0f) rd1 = 0.0f;
-  const float tdsh = (-b + sqrtf(rd1)) / (2.0f * a);
-  return (tref + tdsh) / tdiv;
-}
-
 #endif
 
 #ifdef DZ_FMM_LAZYSTAT
@@ -682,21 +650,13 @@ __device__ unsigned long long g_fmm_prof[8];
 template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED>
 __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
-                                      int ex, int lane, int maxpop = 0x7fffffff) {
+                                      int ex, int lane, bool fastm, int maxpop = 0x7fffffff) {
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
   const int nb = gl >> 2, q = gl & 3;
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
   unsigned *recw = H.rec;
-  // one node word as the {time, status} pair the code below works with: status 0 alive, -1 far, > 0 heap slot
-  auto ldn = [&](unsigned idx) -> Node {
-    const unsigned w = recw[idx];
-    Node n;
-    n.t = __int_as_float((int)w);
-    n.s = w_is_alive(w) ? 0 : (w == W_FAR ? -1 : (int)(w & 0x7fffffffu));
-    return n;
-  };
   const int tsh = H.tsh;
   bool overflow = false;
   // lazy back-pointers (see below) wherever the sift-down is the parallel one: the all-in-LDS heap and, since the late round 3,
@@ -743,11 +703,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
     const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
     const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
-    Node nself = ldn(uself);
-    Node nj = ldn(vj ? (unsigned)(xj + zn) : uroot);
-    Node nj2 = ldn(vj2 ? (unsigned)(xj2 + zn) : uroot);
-    Node nk = ldn(vk ? (unsigned)(xn + zk) : uroot);
-    Node nk2 = ldn(vk2 ? (unsigned)(xn + zk2) : uroot);
+    // (the node words as they are: an alive node's word is its time, sign bit clear; see w_alive)
+    unsigned wself = recw[uself];
+    unsigned wj = recw[vj ? (unsigned)(xj + zn) : uroot];
+    unsigned wj2 = recw[vj2 ? (unsigned)(xj2 + zn) : uroot];
+    unsigned wk = recw[vk ? (unsigned)(xn + zk) : uroot];
+    unsigned wk2 = recw[vk2 ? (unsigned)(xn + zk2) : uroot];
     const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
     const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
@@ -778,21 +739,18 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     PROF(2);
     // keep the compiler from sinking the loads behind a test of the first one and from hoisting
     // the deferred stores above this point: all results are "used" here, together
-    asm volatile("" ::"v"(nself.t), "v"(nself.s), "v"(nj.t), "v"(nj.s), "v"(nj2.t), "v"(nj2.s), "v"(nk.t), "v"(nk.s),
-                 "v"(nk2.t), "v"(nk2.s), "v"(vel), "v"(risti)
-                 : "memory");
+    asm volatile("" : "+v"(wself), "+v"(wj), "+v"(wj2), "+v"(wk), "+v"(wk2) : "v"(vel), "v"(risti) : "memory");
     if (SPILL) {
       if (gl < nmoves) H.set_slot((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
     } else {
       // (the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
       if (H.g0 && fin_slot > 0) H.set_slot((unsigned)fin_node, fin_slot);
     }
-    if (!nvalid) nself.s = 0;
-    if (!vj) nj.s = -1;
-    if (!vj2) nj2.s = -1;
-    if (!vk) nk.s = -1;
-    if (!vk2) nk2.s = -1;
-    int stfix = nself.s;                                   // -1 far, 0 alive / outside, >0 heap slot
+    // status of the neighbour: -1 far, 0 alive / outside, > 0 heap slot.  A word that is not alive has its sign bit set, and its low
+    // 31 bits sign-extended are the status: 0xffffffff -> -1, 0x80000000 | slot -> slot
+    const bool nopen = nvalid && !w_is_alive(wself);
+    int stfix = nopen ? ((int)(wself << 1) >> 1) : 0;
+    const bool aj = vj && w_is_alive(wj), aj2 = vj2 && w_is_alive(wj2), ak = vk && w_is_alive(wk), ak2 = vk2 && w_is_alive(wk2);
     // Lazy back-pointers (round 3).  A sift-down moves ~9 entries up one level each, and the reference stores the new slot of
     // every one of them in its node's status -- nine 4-byte writes into nine random lines per pop, half of this kernel's HBM
     // traffic.  Here the record of an entry that moves UP (child slot -> parent slot) is left alone, so a band node's record
@@ -816,7 +774,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     }
     float trav = INFINITY;
     PROF(3);
-    if (vj && vk && nself.s != 0) trav = quadrant_time(vel, risti, dnx, dnz, nj, nj2, nk, nk2, vj2, vk2);
+    if (vj && vk && nopen)
+      trav = quadrant_time(vel, risti, dnx, dnz, __int_as_float((int)wj), __int_as_float((int)wj2), __int_as_float((int)wk),
+                           __int_as_float((int)wk2), aj, aj2, ak, ak2, fastm);
     trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
     trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
     if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
@@ -832,7 +792,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (q == 0 && band) atomicAdd(&g_lazy_stat[found == 64 && !isdrop ? 1 : 0], 1ull);
       if (q == 0 && band && isdrop) atomicAdd(&g_lazy_stat[2], 1ull);
 #endif
-      if (__ballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
+      if (wballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
 #pragma unroll
         for (int t = 1; t < LT; t++) {
           const int k = q + 4 * t;
@@ -863,7 +823,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
       const bool owner = q == 0;
       const bool act = stfix != 0, isnew = stfix < 0;          // (stfix: the neighbour's true slot, resolved above)
-      const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
+      const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & 0x1111u;
       const int cnt = __popc(newb);
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
       const bool room = H.ntr + cnt < TOT;
@@ -876,7 +836,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       const int gp = pc >> 1;
       const float gk = H.keys[(act && room && gp >= 1) ? gp : 0];
       NT pn = H.nodes[(act && room && !pchi) ? pc : 0];
-      if (HYB && NH > 1 && __ballot(pchi) != 0) {
+      if (HYB && NH > 1 && wballot(pchi) != 0) {
         if (pchi) {
           const HEnt e = H.ovf[pc - CAP];
           pk = e.key;
@@ -890,7 +850,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (nb > 1 && pc == c1) pk = t1;
       if (nb > 2 && pc == c2) pk = t2;
       const bool rise = owner && act && c > 1 && trav < pk;
-      const unsigned riseb = (unsigned)(__ballot(rise) >> gbase) & 0xffffu;
+      const unsigned riseb = (unsigned)(wballot(rise) >> gbase) & 0xffffu;
       // neighbours before the first rising one (n < n0) are written directly; from n0 on, sequentially
       n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) >> 2) : 4);
       // One-level rise in place (round 3).  41 % of the wave-pops have a rising entry in some group, and in 92 % of those every
@@ -904,20 +864,20 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       //     entry, neighbours after r see slots r did not touch), and r's own comparisons see no slot an earlier neighbour wrote;
       //   * (hybrid heap) the riser's slot lies in the LDS part.
       bool f2 = false;
-      if (__ballot(riseb != 0u && room) != 0) {            // wave-uniform: some group has a rising entry
+      if (wballot(riseb != 0u && room) != 0) {            // wave-uniform: some group has a rising entry
         const int c3 = dpp_i<DPP_BCAST0 + 12>(cact);
         const int nbr = __builtin_ctz(riseb | 0x10000u) >> 2;
         const int cr = nbr == 0 ? c0 : (nbr == 1 ? c1 : (nbr == 2 ? c2 : c3));
         const int pr = cr >> 1, gr = cr >> 2;
         const bool okr = rise && !(gp >= 1 && trav < gk) && (!HYB || c < CAP);
         const bool clash = owner && act && !rise && (c == pr || c == gr || pc == cr || pc == pr);
-        const unsigned okb = (unsigned)(__ballot(okr) >> gbase) & 0xffffu;
-        const unsigned clb = (unsigned)(__ballot(clash) >> gbase) & 0xffffu;
+        const unsigned okb = (unsigned)(wballot(okr) >> gbase) & 0xffffu;
+        const unsigned clb = (unsigned)(wballot(clash) >> gbase) & 0xffffu;
         f2 = room && riseb != 0u && (riseb & (riseb - 1u)) == 0u && okb == riseb && clb == 0u;
         if (f2) n0 = 4;
       }
       fast = n0 == 4;
-      if (__ballot(f2 && rise) != 0) {                     // the risers: entry to the parent's slot, parent down to the entry's
+      if (wballot(f2 && rise) != 0) {                     // the risers: entry to the parent's slot, parent down to the entry's
         if (f2 && rise) {
           H.keys[pc] = trav;
           H.nodes[pc] = (NT)uself;
@@ -934,7 +894,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
         if (wr) recw[uself] = w_band(c);
-        if (HYB && __ballot(whi) != 0) {
+        if (HYB && wballot(whi) != 0) {
           if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
         H.ntr += __popc(newb & ((1u << (4 * n0)) - 1u));
@@ -942,29 +902,29 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     }
 #ifdef DZ_FMM_PROF
     PROF(5);
-    if (__ballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
+    if (wballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
     pa_[7] += 1000000;                        // iterations (x1e6) on top of the loop-top ticks
 #endif
 #ifdef DZ_FMM_PROF2   // experiment: how many slow-path pops consist of single one-level rises with untouched siblings?
-    if (!SPILL && __ballot(!fast)) {
+    if (!SPILL && wballot(!fast)) {
       const bool owner = q == 0;
       const bool act = stfix != 0, isnew = stfix < 0;
-      const unsigned newb = (unsigned)(__ballot(owner && isnew) >> gbase) & 0x1111u;
+      const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & 0x1111u;
       const int ntr0 = H.ntr - __popc(newb & ((1u << (4 * n0)) - 1u));            // (H.ntr was advanced for the neighbours < n0)
       const int c = isnew ? ntr0 + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
       const int pc = c >> 1, gp = pc >> 1;
       const float pk = H.keys[act ? pc : 0], gk = H.keys[(act && gp >= 1) ? gp : 0];
       const bool rise = owner && act && c > 1 && trav < pk;
-      const unsigned rb = (unsigned)(__ballot(rise) >> gbase) & 0xffffu;
+      const unsigned rb = (unsigned)(wballot(rise) >> gbase) & 0xffffu;
       const int rl = rb ? __builtin_ctz(rb) : 0;
       const int cr = __shfl(c, gbase + rl), pr = __shfl(pc, gbase + rl);
       const bool one = __popc(rb) == 1;
       const bool stops = !(gp >= 1 && trav < gk);                         // the riser stops after one level
       const bool clash = owner && act && gl != rl && (c == pr || pc == cr || pc == pr);
-      const unsigned cl = (unsigned)(__ballot(clash) >> gbase) & 0xffffu;
+      const unsigned cl = (unsigned)(wballot(clash) >> gbase) & 0xffffu;
       const bool stopr = __shfl((int)stops, gbase + rl) != 0;
       const bool ok = rb == 0 || (one && stopr && cl == 0 && !fast);
-      if (__ballot(!ok) == 0) pa_[0] += 1000000;   // covered slow pops (x1e6 on the "setup+loads" slot)
+      if (wballot(!ok) == 0) pa_[0] += 1000000;   // covered slow pops (x1e6 on the "setup+loads" slot)
     }
 #endif
     if (!fast) {
@@ -1001,7 +961,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
 #pragma unroll
         for (int n = 0; n < 4; n++) {
           bool live = nbs[n] != 0 && n >= n0 && !overflow;
-          if (__ballot(live) == 0) continue;
+          if (wballot(live) == 0) continue;
           int c = nbs[n];
           if (live && c < 0) {   // far -> close: appended at the bottom (addtree), else its key dropped in place (updtree)
             if (H.full()) {
@@ -1069,6 +1029,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   // task's predecessor (same batch, previous stage) was handed out a whole generation earlier and a workgroup only ever
   // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
   // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
+  const bool fastm = A.fastm != 0 && __builtin_amdgcn_readfirstlane(*A.vflag) == 0;
   const int nstage = SPILL ? 1 : A.ts_nstage;
   const bool ts = nstage > 1;
   unsigned &s_stage = *reinterpret_cast<unsigned *>(&s_keys[1][0]);   // (the dummy slot of the second field, like s_base)
@@ -1136,7 +1097,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         H.rec = rec_c;
         H.tsh = tsh_c;
         cbar();
-        const bool ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane,
+        const bool ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
                                                             stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
         cbar();
         if (ovf) {
@@ -1267,7 +1228,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, HYB, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane);
+        bool ovf = march<CAP, SPILL, NT, HYB, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -1341,7 +1302,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
             node = tile_x(cx - 1, tsh_c) + tile_z(cz - 1);
             w = rec_c[node];
           }
-          unsigned m = (unsigned)((__ballot(w_is_pending(w)) >> (grp * GP)) & 0xffffull);
+          unsigned m = (unsigned)((wballot(w_is_pending(w)) >> (grp * GP)) & 0xffffull);
           while (m) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
@@ -1358,7 +1319,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
           }
           if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
-        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane);
+        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -1616,10 +1577,29 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
   }
   if ((rc = dz_scratch(ctx, "fmm.slown", (size_t)tile_records(g.nnx, g.nnz) * kmax * 4, &p))) return rc;
   float *d_slown = (float *)p;
+  if ((rc = dz_scratch(ctx, "fmm.vflag", 64, &p))) return rc;
+  int *d_vflag = (int *)p;
+  // the short exact division / square root of the quadrant solve (div_exact): node spacings of 2 .. 4096 km on the coarse grid
+  // (0.25 km on the refined one) and, checked by gridder_kernel, velocities of 0.125 .. 16 km/s.  Option fmm.ieee = 1: never.
+  bool fastm = !(ctx->opts.count("fmm.ieee") && ctx->opts["fmm.ieee"]);
+  {
+    const float u1 = fabsf(EARTH * g.dnx);
+    if (!(u1 >= FAST_STEP_MIN && u1 <= FAST_STEP_MAX)) fastm = false;
+    for (float r : rc_tab) {
+      const float v1 = fabsf(r * g.dnz);
+      if (!(v1 >= FAST_STEP_MIN && v1 <= FAST_STEP_MAX)) fastm = false;
+    }
+    for (float r : rr_tab) {   // (the refined lattice: its steps are an eighth of these)
+      const float v1 = fabsf(r * g.dnz);
+      if (!(v1 >= FAST_STEP_MIN && v1 <= FAST_STEP_MAX)) fastm = false;
+    }
+  }
+  ctx->ksec["fmm.fast_math"] = fastm ? 1.0 : 0.0;
   {
     DzTimer t(ctx, "gridder");
     const int total = (int)(nn * kmax);
-    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln, d_slown);
+    DZ_HIP(hipMemsetAsync(d_vflag, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln, d_slown, d_vflag);
     DZ_HIP(hipGetLastError());
     t.stop();
   }
@@ -1636,6 +1616,8 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     A0.period = period.dev;
     A0.risti_c = d_rc;
     A0.risti_r = d_rr;
+    A0.fastm = fastm ? 1 : 0;
+    A0.vflag = d_vflag;
     A0.ttn = ttn.dev;
     A0.ttnr = ttnr.dev;
     A0.nstsr = nstsr.dev;

@@ -73,7 +73,11 @@ def run_program(exe, inputs, workdir, para="para.in"):
     for name, text in inputs.items():
         open(os.path.join(workdir, name), "w").write(text)
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run([exe, para], cwd=workdir, capture_output=True, text=True, env=env, timeout=3600)
+
+    def unlimited_stack():   # the programs keep their work arrays on the stack (test4_Yunnan: segfault under the default 8 MB)
+        import resource
+        resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))
+    r = subprocess.run([exe, para], cwd=workdir, capture_output=True, text=True, env=env, timeout=7200, preexec_fn=unlimited_stack)
     if r.returncode:
         raise RuntimeError(r.stdout[-2000:] + r.stderr[-2000:])
     out = {"__stdout__": r.stdout}
