@@ -17,6 +17,10 @@ RMAX = 129
 PI_F32 = np.float32(3.1415926535898)  # inv/CalSurfG.f90:166
 
 
+# status codes of include/dazim.h
+DAZIM_OK, DAZIM_E_SOURCE_OUTSIDE, DAZIM_E_RECEIVER_OUTSIDE, DAZIM_E_NNZ_OVERFLOW, DAZIM_E_BAD_ARG, DAZIM_E_ROOT_NOT_FOUND = 0, 1, 2, 4, 5, 6
+
+
 class DazimError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"dazim error {code}: {msg}")
@@ -265,7 +269,7 @@ class Context:
         nrp = np.zeros(max(nray.value, 1), np.int32)
         self._check(self.lib.dazim_ray_paths_copy(self._h, _ptr(xz), _ptr(nrp)))
         if (nrp[:nray.value] < 0).any():
-            raise DazimError(DAZIM_E_BAD_ARG if "DAZIM_E_BAD_ARG" in globals() else -1, "a ray path outgrew the point buffer")
+            raise DazimError(DAZIM_E_BAD_ARG, "a ray path outgrew the point buffer")
         return [xz[i, :nrp[i]].copy() for i in range(nray.value)]
 
     # ---- K6/K7 -----------------------------------------------------------------------------

@@ -1,4 +1,6 @@
 // ctx.hip -- context, memory helpers and host-side geometry of libdazim_hip.so.
+#include <cstring>
+
 #include "dazim_internal.h"
 
 int dz_fail(dazim_ctx *c, int code, const char *fmt, ...) {
@@ -262,12 +264,18 @@ int dazim_free(dazim_ctx *ctx, void *dptr) {
   DZ_HIP(hipFree(dptr));
   return 0;
 }
+// (both copies come after whatever the auxiliary stream still has to do -- the depth kernels of a disp.async call: a caller that
+// reads sen_* straight after dazim_dispersion_kernels gets the complete arrays, one that overwrites vel does not race the copies)
 int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  int rcj = dz_join_aux(ctx);
+  if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  int rcj = dz_join_aux(ctx);
+  if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -279,6 +287,32 @@ int dazim_sync(dazim_ctx *ctx) {
   return 0;
 }
 void *dazim_stream(dazim_ctx *ctx) { return (void *)ctx->stream; }
+
+// 64-bit hash of a host array (every byte; four independent multiply-xorshift lanes so that one core streams it at memory
+// speed).  The Fortran aprod drop-in keys its cached device matrix on it: the reference's aprod uses iw / rw as they are at call
+// time, so an in-place edit anywhere in them must be seen.
+unsigned long long dazim_hash64(const void *data, size_t bytes) {
+  const unsigned char *p = (const unsigned char *)data;
+  const unsigned long long K = 0x9E3779B97F4A7C15ull;
+  unsigned long long h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    unsigned long long w[4];
+    memcpy(w, p + i, 32);
+    for (int l = 0; l < 4; l++) {
+      h[l] = (h[l] ^ w[l]) * K;
+      h[l] ^= h[l] >> 29;
+    }
+  }
+  unsigned long long t = bytes;
+  for (; i < bytes; i++) t = (t ^ p[i]) * K;
+  unsigned long long r = t;
+  for (int l = 0; l < 4; l++) {
+    r = (r ^ h[l]) * K;
+    r ^= r >> 32;
+  }
+  return r;
+}
 
 int dazim_set_option(dazim_ctx *ctx, const char *name, int value) {
   if (!ctx || !name) return DAZIM_E_BAD_ARG;

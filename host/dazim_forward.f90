@@ -182,41 +182,12 @@ program SurfAAForward_amd
   end do
   close (12); close (13)
 
-  ! ---- FwdObsTraveltimeCPS (fwd/FwdTraveltimeCPS.f90:208) on the device ----
+  ! ---- FwdObsTraveltimeCPS (fwd/FwdTraveltimeCPS.f90:208) on the device: the drop-in of host/dazim_fwd_seam.f90, called as
+  ! fwd/MainForward.f90:372 calls the reference's ----
   write (*, *) ' Construct True Traveltime using Ture Sensitivity  Begin!'
-  call dazim_init(0)
-  call dazim_check(dazim_set_option(dazim_handle, 'rays.keep_small'//c_null_char, 1), 'set_option')
-  write (6, *) ' DepthkernelTI begin!'                         ! fwd/FwdTraveltimeCPS.f90:450-455, fwd/depthkernelTI.f90:42
-  write (6, *) ' depth kernel parallel:'
-  call system_clock(c1)
-  call dazim_lsen_gsc(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
-  call system_clock(c2)
-  write (6, *) ' DepthkernelTI successfully!'
-  write (*, '(a,f13.1,a)') "  DepthkernelTI time cost= ", real(c2 - c1)/real(crate), " s"
-  if (writepath) call dazim_check(dazim_set_option(dazim_handle, 'rays.keep_paths'//c_null_char, 1), 'set_option')
-  call dazim_assemble_G(.true., nx, ny, nz, vsf, obsTvs, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
-                        minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv)
-  if (writepath) call write_ray_paths()
-  xcol = 0                                                    ! (0 | GcCol | GsCol), :746-752
-  do k = 1, nz - 1
-    do jj = 1, ny - 2
-      do ii = 1, nx - 2
-        xcol(maxvp + (k - 1)*(nx - 2)*(ny - 2) + (jj - 1)*(nx - 2) + ii) = gcf(ii, jj, k)
-        xcol(2*maxvp + (k - 1)*(nx - 2)*(ny - 2) + (jj - 1)*(nx - 2) + ii) = gsf(ii, jj, k)
-      end do
-    end do
-  end do
-  yrow = 0
-  call dazim_check(dazim_aprod(dazim_handle, 1, G, xcol, yrow), 'aprod')
-  obsTaa(1:dall) = yrow(1:dall)
-  call dazim_check(dazim_csr_free(dazim_handle, G), 'free G')
-  do tt = 1, kmaxRc                                           ! tRcV, :764-771
-    do jj = 1, ny - 2
-      do ii = 1, nx - 2
-        tRcV((jj - 1)*(nx - 2) + ii, tt) = pv(jj*nx + ii + 1, tt)
-      end do
-    end do
-  end do
+  call FwdObsTraveltimeCPS(nx, ny, nz, maxvp, vsf, gcf, gsf, obsTvs, obsTaa, dall, 0, tRcV, Lsen_Gsc, &
+                           goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, minthk, &
+                           scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, writepath)
   write (*, *) ' Construct True Traveltime using True Sensitivity over!'
   open (42, file='period_Azm_tomo.real', status='replace', action='write')
   call write_period_azimuthal(42)
@@ -285,52 +256,6 @@ program SurfAAForward_amd
   call dazim_finalize()
 
 contains
-
-  ! raypath_refmdl_<T>s.dat: one file per period, per ray a '>' line with the period and the points of the ray as longitude,
-  ! latitude in degrees, receiver first (fwd/FwdTraveltimeCPS.f90:673-691, fwd/rpathsAzim.f90:617-625)
-  subroutine write_ray_paths()
-    integer(c_int64_t) :: nr8
-    integer(c_int) :: cap
-    real, allocatable :: xz(:, :, :)
-    integer(c_int), allocatable :: nrp(:)
-    integer :: k1, s1, r1, ray, q, nper
-    real*8 :: Tp1, Tp2
-    real :: rayx, rayz
-    character(len=30) :: rayfile
-    character(len=30) :: Tchar
-    logical :: isopen
-    call dazim_check(dazim_ray_paths_dims(dazim_handle, nr8, cap), 'ray paths')
-    if (nr8 < 1) return
-    allocate (xz(2, cap, nr8), nrp(nr8))
-    call dazim_check(dazim_ray_paths_copy(dazim_handle, xz, nrp), 'ray paths')
-    call dazim_check(dazim_set_option(dazim_handle, 'rays.keep_paths'//c_null_char, 0), 'set_option')
-    Tp1 = 0; ray = 0; isopen = .false.
-    do k1 = 1, kmax
-      do s1 = 1, nsrc1(k1)
-        do r1 = 1, nrc1(s1, k1)
-          ray = ray + 1
-          nper = periods(s1, k1)
-          Tp2 = tRc(nper)
-          if (abs(Tp1 - Tp2) > 1e-4) then
-            if (isopen) close (40)
-            write (Tchar, '(f5.1)') Tp2
-            rayfile = 'raypath_refmdl_'//trim(adjustl(Tchar))//'s.dat'
-            open (40, file=rayfile, action='write')
-            isopen = .true.
-            Tp1 = Tp2
-          end if
-          if (nrp(ray) < 0) stop 'a ray path outgrew the point buffer'
-          write (40, '(a,f4.1)') '>', Tp2
-          do q = 1, nrp(ray)
-            rayx = (pi/2 - xz(1, q, ray))*180.0/pi
-            rayz = xz(2, q, ray)*180.0/pi
-            write (40, *) rayz, rayx
-          end do
-        end do
-      end do
-    end do
-    if (isopen) close (40)
-  end subroutine
 
   subroutine summary(unit)
     integer, intent(in) :: unit

@@ -21,7 +21,7 @@ module dazim_mod
   use iso_c_binding
   implicit none
   private
-  public :: dazim_init, dazim_finalize, depthkernel, surfdisp96, dazim_surfdisp96, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense, dazim_aprod_forget
+  public :: dazim_init, dazim_finalize, depthkernel, surfdisp96, dazim_surfdisp96, CalSurfG, dazim_calsurfg_joint, aprod, LSMR, dazim_handle, dazim_fill_dense, dazim_aprod_forget, dazim_hash64
   ! device-resident variants used by host/dazim_main.f90 (G never leaves HBM between assembly and LSMR)
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
@@ -32,7 +32,10 @@ module dazim_mod
   type(c_ptr), save :: aprod_A = c_null_ptr
   integer(c_intptr_t), save :: aprod_iw = 0, aprod_rw = 0
   integer, save :: aprod_kk = -1, aprod_m = -1, aprod_n = -1
-  real(8), save :: aprod_fp = 0
+  integer(c_int64_t), save :: aprod_fp = 0
+  ! .true.: the caller promises not to edit iw / rw in place between aprod calls -- the cached matrix is then keyed on addresses
+  ! and sizes only (no pass over the arrays per call); dazim_aprod_forget() ends the promise for the matrix at hand
+  logical, save, public :: dazim_aprod_trust = .false.
   integer, save, public :: aprod_builds = 0
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
   logical, save :: dazim_fill_dense = .true.
@@ -52,6 +55,9 @@ module dazim_mod
   interface
     integer(c_int) function dazim_create(ctx, device) bind(C, name="dazim_create")
       import; type(c_ptr) :: ctx; integer(c_int), value :: device
+    end function
+    integer(c_int64_t) function dazim_hash64(data, bytes) bind(C, name="dazim_hash64")
+      import; type(c_ptr), value :: data; integer(c_size_t), value :: bytes
     end function
     subroutine dazim_destroy(ctx) bind(C, name="dazim_destroy")
       import; type(c_ptr), value :: ctx
@@ -326,11 +332,12 @@ contains
   end subroutine
 
   ! ---- inv/depthkernelTI.f90:2 (Lsen_Gsc only; the phase velocities are recomputed like the reference does) -------
-  subroutine dazim_lsen_gsc(nx, ny, nz, vel, kmaxRc, tRc, depz, minthk, Lsen_Gsc)
+  subroutine dazim_lsen_gsc(nx, ny, nz, vel, kmaxRc, tRc, depz, minthk, Lsen_Gsc, pvRc)
     integer :: nx, ny, nz, kmaxRc
     real :: vel(nx, ny, nz), depz(nz), minthk
     real*4 :: Lsen_Gsc(nx*ny, kmaxRc, nz - 1)
     real*8 :: tRc(kmaxRc)
+    real*8, optional :: pvRc(nx*ny, kmaxRc)      ! the column dispersion curves (depthkernelTI's second output)
     real*8, allocatable :: pv(:, :)
     integer(c_int) :: nfail
     call dazim_init(0)
@@ -338,6 +345,7 @@ contains
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
                                         c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
     call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, Lsen_Gsc), 'depthkernelTI/tregn96')
+    if (present(pvRc)) pvRc = pv
   end subroutine
 
   ! ---- inv/CalSurfG.f90:909 ----------------------------------------------------------------------
@@ -491,6 +499,7 @@ contains
     call check(dazim_set_option(dazim_handle, 'disp.async'//c_null_char, 1_c_int), 'option')
     call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, dvel, depz, minthk, kmaxRc, tRc, pv, p_svs, p_svp, &
                                         p_srho, nfail), 'CalSurfG/depthkernel')
+    call check(dazim_set_option(dazim_handle, 'disp.async'//c_null_char, 0_c_int), 'option')   ! (the handle is shared: only this call)
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
     if (joint .and. present(ti_here)) then
       if (ti_here) call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
@@ -552,9 +561,10 @@ contains
 
   ! ---- inv/aprod.f90:7 -----------------------------------------------------------------------------
   ! A caller that keeps the reference's own LSMR and swaps only aprod calls this twice per iteration with the same iw / rw: the
-  ! device CSR is built once and kept, keyed on the arrays' addresses, sizes and a fingerprint of their contents (the count
-  ! iw(1), 1024 evenly spaced samples of rw, of the row ids and of the column ids -- a caller that rewrites the arrays in place
-  ! between two solves changes it; dazim_aprod_forget() drops the cached matrix explicitly).
+  ! device CSR is built once and kept, keyed on the arrays' addresses, sizes and a 64-bit hash of EVERY element of iw and rw
+  ! (dazim_hash64, one pass at memory speed per call: the reference's aprod reads the arrays afresh on every call, so an in-place
+  ! edit anywhere -- a few rescaled rows, a handful of new weights -- must rebuild the matrix).  dazim_aprod_trust = .true. skips
+  ! the pass for callers that promise not to edit in place; dazim_aprod_forget() drops the cached matrix explicitly.
   subroutine aprod(mode, m, n, x, y, leniw, lenrw, iw, rw)
     integer :: mode, m, n, leniw, lenrw
     integer, target :: iw(leniw)
@@ -562,11 +572,13 @@ contains
     real :: x(n), y(m)
     integer :: kk
     integer(c_intptr_t) :: a_iw, a_rw
-    real(8) :: fp
+    integer(c_int64_t) :: fp
     call dazim_init(0)
     kk = iw(1)
     a_iw = transfer(c_loc(iw), a_iw); a_rw = transfer(c_loc(rw), a_rw)
-    fp = fingerprint(kk, iw, rw)
+    fp = 0
+    if (.not. dazim_aprod_trust .and. kk >= 1) &
+      fp = ieor(dazim_hash64(c_loc(iw), int(2*kk + 1, c_size_t)*4), 3*dazim_hash64(c_loc(rw), int(kk, c_size_t)*4))
     if (.not. (c_associated(aprod_A) .and. a_iw == aprod_iw .and. a_rw == aprod_rw .and. kk == aprod_kk .and. m == aprod_m &
                .and. n == aprod_n .and. fp == aprod_fp)) then
       call dazim_aprod_forget()
@@ -576,19 +588,6 @@ contains
       aprod_builds = aprod_builds + 1
     end if
     call check(dazim_aprod(dazim_handle, mode, aprod_A, x, y), 'aprod')
-  contains
-    real(8) function fingerprint(kk, iw, rw)
-      integer, intent(in) :: kk, iw(*)
-      real, intent(in) :: rw(*)
-      integer :: q, step
-      fingerprint = kk
-      if (kk < 1) return
-      step = max(1, kk/1024)
-      do q = 1, kk, step
-        fingerprint = fingerprint*1.0000001d0 + real(rw(q), 8) + 3.0d0*iw(1 + q) + 7.0d0*iw(1 + kk + q)
-      end do
-      fingerprint = fingerprint + real(rw(kk), 8) + iw(1 + kk) + iw(1 + 2*kk)
-    end function
   end subroutine
 
   ! drop the matrix the aprod drop-in keeps on the device (also done by dazim_finalize)

@@ -104,6 +104,13 @@ program host_example
     call aprod(1, m, n, x, yy, 2*nar + 1, nar, iw, rw)
     write (11, *) aprod_builds
     write (11, '(5es16.8)') yy
+    ! ... and after ONE value was changed in place (the reference's aprod reads the arrays afresh on every call): a third build
+    rw(nar/2 + 1) = rw(nar/2 + 1) + 1.0
+    yy = 0
+    call aprod(1, m, n, x, yy, 2*nar + 1, nar, iw, rw)
+    rw(nar/2 + 1) = rw(nar/2 + 1) - 1.0
+    write (11, *) aprod_builds, iw(1 + nar/2 + 1), col(nar/2 + 1)
+    write (11, '(5es16.8)') yy
   end block
   ! surfdisp96 with the subroutine's own arguments: Love-wave group velocities of the first higher mode, Rayleigh phase
   ! velocities of the fundamental mode, for a four-layer crust on a flat and on a spherical earth

@@ -13,7 +13,7 @@ subroutine ti_depth_kernels(nx, ny, nz, vsf, kmaxRc, tRc, depz, minthk, Lsen_Gsc
 end subroutine
 
 ! .true.: dazim_assemble_G may compute Lsen_Gsc itself from the dispersion curves it already has (one surfdisp96 pass per outer
-! iteration instead of two); host/ti_ref.f90 answers .false. and keeps the separate call
+! iteration instead of two); a provider that answers .false. keeps the separate call
 logical function ti_kernels_on_device()
   ti_kernels_on_device = .true.
 end function

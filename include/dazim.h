@@ -64,6 +64,9 @@ int dazim_free(dazim_ctx *ctx, void *dptr);
 int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dazim_sync(dazim_ctx *ctx);
+/* 64-bit hash of every byte of a host array (host/dazim_mod.f90's aprod keys its cached device matrix on iw and rw with it,
+ * replaces nothing in the reference: inv/aprod.f90:7 reads the arrays afresh on every call, which this makes observable) */
+unsigned long long dazim_hash64(const void *data, size_t bytes);
 void *dazim_stream(dazim_ctx *ctx); /* the hipStream_t every kernel of this ctx is launched on */
 /* seconds spent in the last call's kernels, measured with HIP events on the ctx stream; name
  * selects the kernel ("fmm", "gridder", "disp", "ti", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
@@ -87,15 +90,18 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
  * "fmm.ts": 1 / 2 = march every batch in stages that any workgroup may continue (time slicing) / never
  * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
- * the 512-slot hybrid heap, 4 elsewhere).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
+ * the 512-slot hybrid heap with 16-bit node ids = S-256, 8 on the 512-slot heap with two HBM levels = S-512, 4 elsewhere).
+ * "fmm.ieee": 1 = the compiler's IEEE division / square root in the quadrant solve on every grid (default: the short exact forms
+ * where node spacings are 2 .. 4096 km and velocities 0.125 .. 16 km/s; same bits either way).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
  * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  "fmm.hyb2": 1 / 2 =
  * on grids above 256 nodes a side the heaps with few levels in LDS and two in HBM (512 slots up to 682 nodes, 1024 above) always /
  * never (default 0: for batches of more than 2.5 workgroups per CU, and above 768 nodes).  Speed only, all four.
  * "disp.async": 1 (where it pays: at most two rounds of workgroups) or 2 (always) = dazim_dispersion_kernels (device-resident
  * arrays, depth kernels wanted) returns when pvRc is complete and
  * leaves the 6*nz perturbed copies of every column -- which only sen_* need -- running on the context's auxiliary stream, beside
- * whatever is called next (the eikonal fields); dazim_rays_build_G*, the next dazim_dispersion_kernels, dazim_free and
- * dazim_sync join that stream.  Until one of them has been called sen_* are incomplete and vel must not be overwritten.
+ * whatever is called next (the eikonal fields); dazim_rays_build_G*, the next dazim_dispersion_kernels, dazim_memcpy_h2d /
+ * _d2h, dazim_free and dazim_sync join that stream.  Until one of them has been called sen_* are incomplete and vel must not be
+ * overwritten (by anything but dazim_memcpy_h2d).
  * dazim_last_kernel_seconds("disp") is then the main stream's part, ("disp.copies") the auxiliary stream's (waits for it).
  * "disp.team": 1 / 2 = the column curves of such a call are / are not searched by 16 lanes per column, 16 grid points of the
  * bracket search at a time (default 0: when curves and copies together leave the chip under-filled; identical results).

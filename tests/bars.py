@@ -1,7 +1,7 @@
 """Parity bars with their measurements on record.
 
 `within(name, measured, bar)` asserts measured <= bar and prints both, so that a `pytest -m gpu -s` log lists every measured
-maximum next to the bar it is held to (tools/collect_measured.py turns such a log into the table of DESIGN.md section 5).
+maximum next to the bar it is held to (the table of DESIGN.md section 5 is made from such a log).
 VERDICT r2 #5: bars are twice the measured maximum (never below the quantum the quantity is printed / rounded with), and a
 failure names the measured value."""
 

@@ -59,7 +59,10 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     za = np.array(toks[p:p + n], np.float32); p += n
     builds2 = int(toks[p]); p += 1
     ya2 = np.array(toks[p:p + dall], np.float32); p += dall
-    assert builds1 == 1 and builds2 == 2
+    # one value changed in place, anywhere in rw: the matrix is rebuilt (every element is hashed) and the product moves
+    builds3, e_row, e_col = int(toks[p]), int(toks[p + 1]), int(toks[p + 2]); p += 3
+    ya3 = np.array(toks[p:p + dall], np.float32); p += dall
+    assert builds1 == 1 and builds2 == 2 and builds3 == 3
     # surfdisp96 through the Fortran mirror of the reference's argument list (Love group velocity, mode 2, flat; Rayleigh phase)
     cgl = np.array(toks[p:p + 6], np.float64); p += 6
     cgr = np.array(toks[p:p + 6], np.float64); p += 6
@@ -90,6 +93,8 @@ def test_fortran_host_calsurfg_lsmr(orc, tmp_path):
     orc.aprod(2, dall, n, zo, bvec.copy(), irow, icol, rw)
     assert np.linalg.norm(ya - yo) <= 3e-6 * np.linalg.norm(yo) and np.linalg.norm(za - zo) <= 3e-6 * np.linalg.norm(zo)
     assert np.linalg.norm(ya2 - 2 * yo) <= 3e-6 * np.linalg.norm(2 * yo)
+    want3 = 2 * yo.astype(np.float64); want3[e_row - 1] += x[e_col - 1]
+    assert np.linalg.norm(ya3 - want3) <= 3e-6 * np.linalg.norm(want3)
     # ---- the dense copy GVs the drop-in fills like the reference (inv/CalSurfG.f90:1369-1378): the caller's matmul(GVs, x)
     # (inv/CalSigamNorm.f90:73) must be the product with the library's dense twin (every entry of the |fdm| >= ftol cells, dVs
     # with the Brocher derivatives of the ray's last such cell; tests/test_rays_gpu.py checks the twin against the oracle)
