@@ -93,6 +93,30 @@ def profiled_traffic(workload, nfield, nnz):
     return out, os.path.relpath(PMC_FILE, ROOT) + " (" + prof.get("tag", "?") + ")"
 
 
+SQ_FILE = os.path.join(ROOT, "profiles", "sq_counters.json")
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G instructions/s
+# fp32 operations of the reference's own arithmetic per accepted node: four fouds2 calls (inv/CalSurfG.f90:557-729: one
+# quadrant = ~21 multiplies / adds + 1 sqrt + 1 division, of which the 16 lanes of a field evaluate all sixteen in one
+# instruction each), i.e. ~85 instruction slots per wave-pop of four fields if nothing but that arithmetic were issued
+USEFUL_VALU_PER_WAVE_POP = 85
+
+
+def profiled_sq(workload, nfield):
+    """the eikonal kernel's counters per launch from profiles/sq_counters.json (tools/profile_sq.sh), or None with the reason"""
+    try:
+        prof = json.load(open(SQ_FILE))
+    except Exception as e:
+        return None, f"no usable {os.path.relpath(SQ_FILE, ROOT)} ({type(e).__name__})"
+    if prof.get("source_sha") != kernel_source_hash():
+        return None, f"{os.path.relpath(SQ_FILE, ROOT)} was measured on other kernel sources ({prof.get('source_sha')}): stale, not quoted"
+    if prof.get("workload") != workload or prof.get("fields") != nfield:
+        return None, f"{os.path.relpath(SQ_FILE, ROOT)} was measured on workload {prof.get('workload')} / {prof.get('fields')} fields"
+    for name, v in prof["kernels"].items():
+        if "fmm_kernel" in name:
+            return v, os.path.relpath(SQ_FILE, ROOT) + " (" + prof.get("tag", "?") + ")"
+    return None, "no fmm_kernel in " + os.path.relpath(SQ_FILE, ROOT)
+
+
 WORKLOADS = {   # SURVEY.md 8d: name -> (nx = ny, periods); the metric is quoted on S-256, the others are the parity-test sizes
     "s128": (28, np.arange(5, 41, 5, dtype=np.float64)),      # 126 x 126 nodes, 8 periods
     "s256": (54, np.arange(5, 37, 2, dtype=np.float64)),      # 256 x 256 nodes, 16 periods
@@ -285,7 +309,7 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
             ref_extra["port_depthkernel_columns_per_s_same_sample"] = nrc / (time.perf_counter() - t0)
             t0 = time.perf_counter()
             nrf = 0
-            for f in range(0, nfield_total, max(1, nfield_total // 12)):
+            for f in range(0, nfield_total, max(1, nfield_total // 120)):    # >= 100 fields, ~1 s
                 ref.fmm_field(NX, NY, GOXD, GOZD, DV, DV, pv_maps[per[f] - 1], scx[f], scz[f])
                 nrf += 1
             ref_extra["reference_fmm_fields_per_s"] = nrf / (time.perf_counter() - t0)
@@ -329,6 +353,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="s256")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --sources per GPU; strong: --sources in total, one field list sharded over the ranks")
+    ap.add_argument("--sweep", default=None, help="comma-separated GPU counts, e.g. 1,2,4,8: one run and one JSON line per count "
+                                                  "(each launched as `bench.py --gpus N` with the other flags unchanged)")
     ap.add_argument("--dry-launch", action="store_true", help="spawn the ranks and shard the work, no GPU (CPU test of the launch path)")
     a = ap.parse_args()
     if a.sources is None:
@@ -336,6 +362,25 @@ def main():
     if a.receivers is None:
         a.receivers = 16 if a.workload == "s128" else 32
     nnodes = set_workload(a.workload)
+
+    if a.sweep and "WORLD_SIZE" not in os.environ:
+        # the scaling curve in one command: N = 1, 2, 4, 8 back to back, rank 0 of each run prints its JSON line
+        import subprocess
+        rest, skip = [], False
+        for t in sys.argv[1:]:
+            if skip:
+                skip = False
+            elif t in ("--sweep", "--gpus"):
+                skip = True
+            elif not t.startswith(("--sweep=", "--gpus=")):
+                rest.append(t)
+        rc = 0
+        for n in [int(t) for t in a.sweep.split(",") if t.strip()]:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", str(n)] + rest, stdout=subprocess.PIPE, text=True)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            print(lines[-1] if lines else json.dumps({"n_gpus": n, "error": f"no JSON line (exit code {r.returncode})"}), flush=True)
+            rc = rc or r.returncode
+        sys.exit(rc)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N`: become N ranks, one per GPU (the driver's other form starts torch.distributed.run itself)
@@ -554,6 +599,33 @@ def main():
         ib_aty = int(stats.get("aty_idx_bytes", 4) or 4)
         s_ax = b_ax - nnz * (4 - ib_ax)
         s_aty = b_aty - nnz * (4 - ib_aty)
+        # The dominant kernel is bound by VALU instruction issue (a serial chain of heap pops per field, all parallelism across
+        # fields), not by HBM: `achieved` = VALU instructions per launch (SQ_INSTS_VALU of the committed, hash-locked counter
+        # pass) / this run's launch duration, `peak` = what 1024 SIMDs issue at 2.4 GHz; `useful_frac` = the share of those
+        # instructions that is the reference's fp32 arithmetic.  The HBM view of the same launch stays under `hbm`.
+        sq, sq_src = profiled_sq(a.workload, nfield)
+        wave_pops = pops / 4.0
+        hbm = {"bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fmm_gbs / HBM_PEAK_GBS,
+               "traffic": traffic["fmm"], "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
+               "traffic_source": traffic_src,
+               "note": f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = FETCH_SIZE + WRITE_SIZE per "
+                       "launch (4-byte accesses: raw counter values, the gfx950 x2 read correction is only calibrated for 16-byte streams)"}
+        if sq:
+            ginst = sq["SQ_INSTS_VALU"] / stats["fmm_s"] / 1e9
+            roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
+                        "frac": ginst / VALU_PEAK_GINST, "traffic": traffic["fmm"],
+                        "valu_inst_per_launch": sq["SQ_INSTS_VALU"], "valu_inst_per_wave_pop": sq["SQ_INSTS_VALU"] / wave_pops,
+                        "useful_frac": USEFUL_VALU_PER_WAVE_POP * wave_pops / sq["SQ_INSTS_VALU"],
+                        "simd_valu_busy_in_profile": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+                        "counters_source": sq_src}
+        else:   # no counter pass of these sources: the HBM figures the metric asks for, and the reason
+            roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
+                        "frac": None, "traffic": traffic["fmm"], "counters_source": sq_src}
+        roofline.update({"node_acceptances_per_s": pops / stats["fmm_s"], "hbm": hbm,
+                         "note": "VALU-issue bound: three wavefronts per SIMD, a serial chain of heap pops per field, all parallelism across "
+                                 "fields; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (under this load the chip "
+                                 "clocks ~2.06 GHz, DESIGN.md 4); useful_frac = the reference's fp32 arithmetic (85 instruction slots per "
+                                 "pop of four fields) / all VALU instructions"})
         out = {
             "metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s",
             "value": total_fields / (dt / a.steps), "unit": "fields/s",
@@ -567,18 +639,7 @@ def main():
             # the dominant kernel.  It is bound by the serial heap order of fast marching (VALU instruction issue), not by HBM
             # bandwidth; the HBM fraction of its algorithmic bytes is still reported
             # (achieved / peak / frac) because the metric asks for it, next to what the kernel is really limited by (pops/s).
-            "roofline": {"kernel": "fmm_kernel", "bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fmm_gbs / HBM_PEAK_GBS, "traffic": traffic["fmm"],
-                         "node_acceptances_per_s": pops / stats["fmm_s"],
-                         "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
-                         "traffic_source": traffic_src,
-                         "note": "VALU-issue bound since the time-sliced marches keep three wavefronts per SIMD busy to the end of the "
-                                 "batch (SQ_ACTIVE_INST_VALU ~ every SIMD cycle, profiles/r3_sq_counters.md): a serial chain of heap "
-                                 "pops per field, ~410 VALU instructions per pop of four fields, all parallelism across fields; "
-                                 "`traffic` is what really moves (DESIGN.md 4); "
-                                 f"algorithmic bytes = {BYTES_PER_FIELD} B/field x {nfield} fields per launch; traffic = "
-                                 "FETCH_SIZE + WRITE_SIZE per launch (8-byte accesses: raw counter values, the gfx950 x2 read "
-                                 "correction is only calibrated for 16-byte streams)"},
+            "roofline": roofline,
             "spmv": {"kernels": {"Ax": kind_ax.get(int(stats.get("spmv_kind", -1)), "?"),
                                  "ATy": kind_aty.get(int(stats.get("spmvt_kind", -1)), "?")}, "bound": "hbm",
                      "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -609,7 +670,10 @@ def main():
         }
         if not a.no_cpu and world == 1:      # the CPU baseline is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
-            out["speedup_vs_cpu_1core_forward"] = (nfield / (stats["disp_s"] + stats["fmm_s"] + stats["rays_s"])) / out["cpu_baseline"]["value"]
+            # forward wall time of a step = the step minus its LSMR part (dispersion copies on the auxiliary stream included)
+            fwd_s = dt / a.steps - stats["lsmr_s"]
+            out["forward_wall_s_per_step"] = fwd_s
+            out["speedup_vs_cpu_1core_forward"] = (nfield / fwd_s) / out["cpu_baseline"]["value"]
         # the JSON line must be the last thing on stdout: flush whatever native libraries (RCCL's version
         # banner) still hold in C stdio first, and tear the process group down before printing
         result_line = json.dumps(out)

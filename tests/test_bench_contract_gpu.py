@@ -21,8 +21,13 @@ def check(stdout, steps=1):
     assert d["unit"] == "fields/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["scaling"] == "weak"
     assert d["steps"] == steps and d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and r["bound"] in ("hbm", "mfma", "latency")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the eikonal kernel is bound by VALU issue: `achieved` comes from the committed counter pass (None when that pass is of other
+    # sources or another workload, as on this reduced batch); the HBM view of the same launch sits under roofline.hbm
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm"} <= set(r) and r["bound"] == "valu"
+    if r["achieved"] is not None:
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["useful_frac"] < 1
+    h = r["hbm"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
     assert 0 < d["spmv"]["Ax"]["frac"] < 1 and 0 < d["spmv"]["ATy"]["frac"] < 1
     return d
 
@@ -49,3 +54,12 @@ def test_bench_forced_row_sharded_solve():
     assert out.returncode == 0, out.stderr[-2000:]
     d = check(out.stdout)
     assert d["lsmr_iterations"] == 20
+
+
+def test_bench_sweep_prints_one_line_per_count():
+    """--sweep: the scaling curve in one command (here: the single count a 1-GPU box has)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sweep", "1"] + ARGS, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    check(lines[0])

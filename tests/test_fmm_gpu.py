@@ -317,3 +317,95 @@ def test_fmm_time_sliced_many_hand_overs(ctx):
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
         ctx.set_option("fmm.hyb512", 0)
+
+
+def _bench_batch(nx, kmax, nsrc, seed):
+    import torch
+    dev = torch.device("cuda:0")
+    pv = synth.phase_velocity_maps(nx, nx, kmax)
+    lat, lon = synth.stations(nx, nx, 30.0, 100.0, 0.25, 0.25, nsrc, seed=seed, shrink=0.3)
+    sx, sz = synth.radians(lat, lon)
+    scx, scz = np.tile(sx, kmax), np.tile(sz, kmax)
+    per = np.repeat(np.arange(1, kmax + 1, dtype=np.int32), nsrc)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return pv, scx, scz, per, (t(pv), t(scx), t(scz), t(per))
+
+
+def _check_sampled_fields(orc, nx, pv, scx, scz, per, ttn, fields):
+    g = orc.geometry(nx, nx, 30.0, 100.0, 0.25, 0.25)
+    for f in fields:
+        k = int(per[f]) - 1
+        veln = orc.gridder(g, pv[k])
+        rc, want, *_ = orc.fmm_field(g, pv[k], veln, scx[f], scz[f])
+        got = ttn[f].cpu().numpy()
+        assert rc == 0 and np.array_equal(got, want), f"field {f}: max diff {np.abs(got - want).max()}"
+
+
+def test_fmm_s512_bench_batch_takes_the_automatic_path_at_full_size(ctx, orc):
+    """config 5 at the size bench.py runs it per GPU: 32 periods x 1000 sources = 32 000 fields on 511 x 511 nodes with NO option
+    set.  The dispatch must pick the 512-slot heap with two HBM levels (ten workgroups per CU) and eight time-sliced coarse
+    stages by itself; every traveltime of the batch equals the unsliced round-2 form (1024 LDS slots + one HBM level, fmm.ts = 2,
+    fmm.hyb2 = 2) on the device, and twelve sampled fields -- first, last, and the most central sources, whose bands are the widest
+    -- equal the oracle's bit for bit.  (33.4 GB of traveltimes per run.)"""
+    import torch
+    nx, kmax, nsrc = 105, 32, 1000
+    pv, scx, scz, per, (d_pv, d_scx, d_scz, d_per) = _bench_batch(nx, kmax, nsrc, seed=1)
+    nf = kmax * nsrc
+    dev = torch.device("cuda:0")
+
+    def run():
+        ttn = torch.empty((nf, 511, 511), dtype=torch.float32, device=dev)
+        st = torch.empty((nf,), dtype=torch.int32, device=dev)
+        ctx.fmm_batch(nx, nx, 30.0, 100.0, 0.25, 0.25, d_pv, d_scx, d_scz, d_per, ttn=ttn, status=st)
+        assert int(st.abs().sum()) == 0
+        return ttn
+    out = run()
+    assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10 and ctx.kernel_seconds("fmm.ts_stages") == 8
+    auto_s = ctx.kernel_seconds("fmm")
+    # the sources nearest the middle of the grid have the widest bands (the HBM levels of the heap are theirs)
+    cx, cz = np.median(scx[:nsrc]), np.median(scz[:nsrc])
+    central = np.argsort(np.maximum(np.abs(scx[:nsrc] - cx), np.abs(scz[:nsrc] - cz)))[:4]
+    fields = [0, nf - 1, 15 * nsrc + 500] + [int(c) for c in central] + [int(c) + 31 * nsrc for c in central] + [7 * nsrc + int(central[0])]
+    _check_sampled_fields(orc, nx, pv, scx, scz, per, out, fields)
+    try:
+        ctx.set_option("fmm.ts", 2)
+        ctx.set_option("fmm.hyb2", 2)
+        ref = run()
+        assert ctx.kernel_seconds("fmm.ts_stages") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") <= 5
+    finally:
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.hyb2", 0)
+    print(f"\n[measured] S-512 batch of {nf} fields: automatic path {auto_s:.3f} s, unsliced 1024-slot form {ctx.kernel_seconds('fmm'):.3f} s")
+    if not torch.equal(out, ref):
+        bad = torch.nonzero((out != ref).reshape(nf, -1).any(dim=1)).flatten()[:10].tolist()
+        raise AssertionError(f"fields {bad} differ between the automatic path and the unsliced form")
+
+
+def test_fmm_s128_bench_batch_at_full_size(ctx, orc):
+    """config 2 at its full size: 8 periods x 200 sources = 1 600 fields on 126 x 126 nodes down the default path (a batch that
+    leaves the chip partly empty: 512-slot all-LDS heaps, one task per field), against the time-sliced form of the same kernel on
+    the device and ten sampled fields against the oracle"""
+    import torch
+    nx, kmax, nsrc = 28, 8, 200
+    pv, scx, scz, per, (d_pv, d_scx, d_scz, d_per) = _bench_batch(nx, kmax, nsrc, seed=1)
+    nf = kmax * nsrc
+    dev = torch.device("cuda:0")
+
+    def run():
+        ttn = torch.empty((nf, 126, 126), dtype=torch.float32, device=dev)
+        st = torch.empty((nf,), dtype=torch.int32, device=dev)
+        ctx.fmm_batch(nx, nx, 30.0, 100.0, 0.25, 0.25, d_pv, d_scx, d_scz, d_per, ttn=ttn, status=st)
+        assert int(st.abs().sum()) == 0
+        return ttn
+    out = run()
+    assert ctx.kernel_seconds("fmm.ts_stages") == 0 and ctx.kernel_seconds("fmm.spilled_fields") == 0
+    _check_sampled_fields(orc, nx, pv, scx, scz, per, out, [0, 1, 199, 200, 777, 800, 1234, 1399, 1598, 1599])
+    try:
+        ctx.set_option("fmm.ts", 1)
+        ctx.set_option("fmm.ts_stages", 3)
+        ref = run()
+        assert ctx.kernel_seconds("fmm.ts_stages") == 3
+    finally:
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.ts_stages", 0)
+    assert torch.equal(out, ref)
