@@ -56,12 +56,25 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
     }
     s.first = nullptr;
     s.second = 0;
-    size_t want = bytes + bytes / 8;  // a little slack so slowly growing batches do not thrash
+    // a little slack so slowly growing batches do not thrash; none on the multi-GB blocks (the per-field state of time-sliced
+    // eikonal marches: an eighth of 34 GB would be 4 GB that nothing ever touches)
+    size_t want = bytes >= ((size_t)1 << 30) ? bytes : bytes + bytes / 8;
     DZ_HIP(dz_malloc_retry(ctx, &s.first, want));
     s.second = want;
   }
   *out = s.first;
   return 0;
+}
+
+// give a named scratch block back to the device (the caller knows nothing is using it any more)
+void dz_scratch_release(dazim_ctx *ctx, const char *name) {
+  auto it = ctx->scratch.find(name);
+  if (it == ctx->scratch.end()) return;
+  if (it->second.first) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(it->second.first);
+  }
+  ctx->scratch.erase(it);
 }
 
 // Staging cache: best fit among the free blocks, else a new allocation; at most 64 blocks / 2 GiB are kept, larger or surplus

@@ -54,6 +54,7 @@ int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what 
 
 // named scratch buffer of at least `bytes` bytes
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
+void dz_scratch_release(dazim_ctx *ctx, const char *name);   // free it now (scratch is otherwise kept for the life of the context)
 
 size_t dz_trim_caches(dazim_ctx *ctx);                                // free all idle cached blocks; bytes released
 hipError_t dz_malloc_retry(dazim_ctx *ctx, void **p, size_t bytes);   // hipMalloc; on out-of-memory trim the caches and retry once

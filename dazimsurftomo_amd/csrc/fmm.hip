@@ -1491,6 +1491,11 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
+  // The per-field state of a time-sliced batch is only needed while the batch runs.  Small (S-256: 4.2 GB) it is kept for the next
+  // call like every scratch block; above 8 GB (S-512: 34 GB for 32 000 fields) it goes back to the device at once, so that the G
+  // assembly and the solve that follow on the same context find the memory free.
+  if (ts && nown * (rec_field_bytes + (size_t)A.ovfcap * sizeof(HEnt)) + (size_t)nfield * CAP * 8 > ((size_t)8 << 30))
+    for (const char *nm : {"fmm.rec_c", "fmm.ts_keys", "fmm.ts_nodes", "fmm.ovf"}) dz_scratch_release(ctx, nm);
 #ifdef DZ_TS_WAITSTAT
   {
     unsigned long long h[2];
