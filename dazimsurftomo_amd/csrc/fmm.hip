@@ -180,6 +180,18 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __i
 constexpr int DPP_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
 constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
+// value held by the OWNER lane of neighbour N (the first lane of its quad / pair) in every lane of the field's group.  16 lanes per
+// field: one row_newbcast.  8 lanes per field: a row holds two fields -- lanes 0-7 take lane 2N, lanes 8-15 lane 8 + 2N (two DPP
+// moves with complementary bank masks; a bank = four lanes of the row)
+template <int GPL, int N> __device__ __forceinline__ int own_i(int v) {
+  if constexpr (GPL == 16) {
+    return dpp_i<DPP_BCAST0 + 4 * N>(v);
+  } else {
+    const int a = __builtin_amdgcn_mov_dpp(v, DPP_BCAST0 + 2 * N, 0xf, 0x3, false);
+    return __builtin_amdgcn_update_dpp(a, v, DPP_BCAST0 + 8 + 2 * N, 0xf, 0xc, false);
+  }
+}
+template <int GPL, int N> __device__ __forceinline__ float own_f(float v) { return __int_as_float(own_i<GPL, N>(__float_as_int(v))); }
 
 // LDS layout is structure-of-arrays: fp32 keys + node ids (the node's record index, see tile_x above): NT = unsigned short when
 // both grids of a field have at most 65 536 record slots (sides <= 256, the S-256 case: 6 bytes per entry, a third more fields
@@ -192,11 +204,14 @@ constexpr int DPP_BCAST0 = 0x150;  // row_newbcast:0 (+L for lane L of the row)
 // per SIMD), 512 slots + TWO HBM levels with 32-bit ids on 257..682-node grids (S-512: ten workgroups per CU; these grids wait
 // on latencies, and twice the wavefronts are worth one or two more dependent memory accesses per pop), 1024 slots + one level
 // (the round-2 form of S-512, option fmm.hyb2 = 2).
-template <int CAP, bool SPILL, class NT, bool HYB = false>
+template <int CAP, bool SPILL, class NT, bool HYB = false, int GPL = 16>
 struct Heap {
+  static constexpr int GP = GPL;                          // lanes per field: 16 (four fields per wavefront) or 8 (eight)
+  static constexpr int LV = GPL == 16 ? 4 : 3;            // levels per parallel sift-down step: GPL - 1 parent positions
+  static constexpr unsigned GMASK = (1u << GPL) - 1u;
   // HBM levels of the hybrid heap: one with 16-bit node ids, two with 32-bit ids (grids of 257..682 nodes a side: levels 1-9 in
   // LDS, levels 10 and 11 in HBM; above that levels 1-10 in LDS, 11 and 12 in HBM -- see run_fmm's dispatch)
-  static constexpr int NH = (HYB && sizeof(NT) == 4) ? 2 : 1;
+  static constexpr int NH = (HYB && (sizeof(NT) == 4 || CAP <= 256)) ? 2 : 1;
   static constexpr int TOT = HYB ? (CAP << NH) : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
@@ -285,8 +300,8 @@ struct Heap {
         an = (NT)e.node;
       }
     }
-    const unsigned mb = (unsigned)(wballot(valid && key < ak) >> gbase) & 0xffffu;
-    const int L = __builtin_ctz(~mb);                      // (bit 16 of ~mb is set: L <= 16, and <= 11 by the heap depth)
+    const unsigned mb = (unsigned)(wballot(valid && key < ak) >> gbase) & GMASK;
+    const int L = __builtin_ctz(~mb);                      // (bit GPL of ~mb is set: L <= GPL; <= 11 by the heap depth)
     const bool mover = live && gl < L;
     const int dst = mover ? (c >> gl) : 0;
     // (HYB: slot c itself -- lane 0's destination, or the entry's own if it does not rise -- and, with two HBM levels, its parent)
@@ -306,6 +321,18 @@ struct Heap {
     if (HYB && wballot(dhi || fhi) != 0) {
       if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
+    }
+    if constexpr (GPL < 16) {   // eight lanes see eight ancestors: an entry that passed all of them goes on from slot c >> GPL
+      if (live && L == GPL && (c >> GPL) == 1) {     // ... which is the root: nobody had gl == L to place it
+        keys[1] = key;
+        nodes[1] = (NT)node;
+        if (g0) set_slot((unsigned)node, 1);
+      }
+      const bool more = live && L == GPL && (c >> GPL) > 1;
+      if (wballot(more) != 0) {
+        cbar();
+        return L + rise_par(more, gl, gbase, more ? (c >> GPL) : 0, key, node);   // (a group that is done reads and writes slot 0)
+      }
     }
     return L;
   }
@@ -394,9 +421,10 @@ struct Heap {
   // tail.  Two steps empty a heap below 512 slots (every refined grid, grids up to ~170 nodes a side), three one below 8192.
   // The words of the entries that move up are left alone (lazy back-pointers, see march()); the caller stores the slot of the
   // dropped entry (fin_node at fin_slot).
-  static constexpr int NSTEP = CAP <= 32 ? 1 : (CAP <= 512 ? 2 : 3);
+  static constexpr int clog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+  static constexpr int NSTEP = (clog2(CAP) - 1 + LV - 1) / LV;   // the hole goes from level 0 to at most level clog2(CAP) - 1, LV levels per step
   __device__ __forceinline__ void pop_root_par(int lane, int &fin_node, int &fin_slot) {
-    static_assert(CAP <= 8192, "pop_root_par covers 13 levels");
+    static_assert(CAP <= 8192 && NSTEP <= 4, "pop_root_par covers 13 levels");
     static_assert((CAP & 1) == 0, "pairs of children are read together");
     static_assert(!HYB || (CAP & (CAP - 1)) == 0, "HYB: the LDS part of the heap is whole levels");
     const int gl = lane & (GP - 1), gsh = lane & ~(GP - 1);
@@ -431,7 +459,7 @@ struct Heap {
     if (dq >= 2) { G |= 1u << ((q >> 2) - 1); E |= (unsigned)((q >> 1) & 1) << ((q >> 2) - 1); }
     if (dq >= 3) { G |= 1u; E |= (unsigned)((q >> 2) & 1); }
     unsigned A = G | (1u << (q - 1));
-    if (gl == 15) A = 0x10000u;                            // the idle lane never matches (lt is cut to 16 bits)
+    if (gl == GP - 1) A = 1u << GP;                        // the idle lane never matches (lt is cut to GP bits)
     int p = 1;
     bool active = true, deep = false;
 #pragma unroll
@@ -461,18 +489,18 @@ struct Heap {
       const int cn = right ? n1 : n0;
       const unsigned long long gtm = wballot(right);
       const unsigned long long ltm = wballot(ck < mvk);
-      const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & 0xffffu;
+      const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & GMASK;
       const bool mine = (gt & G) == E && (lt & A) == A;    // (an inactive group has ck = +inf everywhere: nobody moves)
       const int dst = mine ? s : 0;
       keys[dst] = ck;
       nodes[dst] = (NT)cn;
-      const unsigned mb = (unsigned)(wballot(mine) >> gsh) & 0xffffu;   // <= one lane per level, levels 1..nm
+      const unsigned mb = (unsigned)(wballot(mine) >> gsh) & GMASK;   // <= one lane per level, levels 1..nm
       if (mb != 0) {
         const int qs = 32 - __clz(mb);                    // deepest parent whose child moved up: the hole is at that child now
         const int rt = 2 * qs + (int)((gt >> (qs - 1)) & 1u);
         const int dt = 31 - __clz(rt);
         p = (p << dt) + rt - (1 << dt);
-        active = dt == 4 && 2 * p <= ntr;
+        active = dt == LV && 2 * p <= ntr;
         if (HYB) deep = p >= CAP / 2 && 2 * p <= ntr;     // on the last LDS level, with children: they are in HBM
       } else {
         active = false;
@@ -647,15 +675,21 @@ __device__ unsigned long long g_fmm_prof[8];
 // ---- one marching run (travel, inv/CalSurfG.f90:356-456), executed by a 16-lane group --------
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
-template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float *__restrict__ slow,
+template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED, int GPL>
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane, bool fastm, int maxpop = 0x7fffffff) {
+  // Lanes of a field's group: 16 = 4 neighbours x 4 quadrants (jd, kd); 8 = 4 neighbours x 2 (jd), each lane solving the
+  // quadrants kd = -1 and kd = +1 one after the other (eight fields per wavefront: the per-pop bookkeeping is shared by twice the
+  // fields)
+  static_assert(GPL == 16 || (GPL == 8 && !SPILL), "lanes per field");
+  constexpr int GP = GPL, NBL = GPL / 4;                   // lanes per neighbour
+  constexpr unsigned GMASK = (1u << GPL) - 1u, OWNERS = GPL == 16 ? 0x1111u : 0x55u;
   const int gl = lane & (GP - 1), gbase = lane & ~(GP - 1);
-  const int nb = gl >> 2, q = gl & 3;
+  const int nb = gl / NBL, q = gl & (NBL - 1);
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
-  const int jd = (q & 2) ? 1 : -1, kd = (q & 1) ? 1 : -1;
+  const int jd = GPL == 16 ? ((q & 2) ? 1 : -1) : (q ? 1 : -1), kd = GPL == 16 ? ((q & 1) ? 1 : -1) : -1;
   unsigned *recw = H.rec;
   const int tsh = H.tsh;
   bool overflow = false;
@@ -709,6 +743,16 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     unsigned wj2 = recw[vj2 ? (unsigned)(xj2 + zn) : uroot];
     unsigned wk = recw[vk ? (unsigned)(xn + zk) : uroot];
     unsigned wk2 = recw[vk2 ? (unsigned)(xn + zk2) : uroot];
+    // (8 lanes per field: the lane's second quadrant, kd = +1)
+    bool vkp = false, vk2p = false;
+    unsigned wkp = 0, wk2p = 0;
+    if constexpr (GPL == 8) {
+      const int kp0 = nz0 + 1, kp20 = nz0 + 2;
+      vkp = nvalid && (unsigned)kp0 < unz;
+      vk2p = vkp && (unsigned)kp20 < unz;
+      wkp = recw[vkp ? (unsigned)(xn + tile_z(kp0)) : uroot];
+      wk2p = recw[vk2p ? (unsigned)(xn + tile_z(kp20)) : uroot];
+    }
     const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
     const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
     int nbn[4], nbs[4], nbm[4];
@@ -717,15 +761,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     // by the spill kernel's sequential sift-down (which entry moved where); the parallel kernel fetches them in its slow path.
     const int nrid = nvalid ? (int)uself : -1;
     if (SPILL) {
-      nbn[0] = dpp_i<DPP_BCAST0 + 0>(nrid); nbn[1] = dpp_i<DPP_BCAST0 + 4>(nrid);
-      nbn[2] = dpp_i<DPP_BCAST0 + 8>(nrid); nbn[3] = dpp_i<DPP_BCAST0 + 12>(nrid);
+      nbn[0] = own_i<GPL, 0>(nrid); nbn[1] = own_i<GPL, 1>(nrid);
+      nbn[2] = own_i<GPL, 2>(nrid); nbn[3] = own_i<GPL, 3>(nrid);
     } else {
       nbn[0] = nbn[1] = nbn[2] = nbn[3] = 0;
     }
 #pragma unroll
     for (int n = 0; n < 4; n++) nbm[n] = 0;
     int mynode = 0, myslot = 0, nmoves = 0;
-    constexpr int TOT = Heap<CAP, SPILL, NT, HYB>::TOT;
+    constexpr int TOT = Heap<CAP, SPILL, NT, HYB, GPL>::TOT;
     int fin_node = 0, fin_slot = 0;
     PROF(0);
     if (SPILL) {
@@ -739,7 +783,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     PROF(2);
     // keep the compiler from sinking the loads behind a test of the first one and from hoisting
     // the deferred stores above this point: all results are "used" here, together
-    asm volatile("" : "+v"(wself), "+v"(wj), "+v"(wj2), "+v"(wk), "+v"(wk2) : "v"(vel), "v"(risti) : "memory");
+    if constexpr (GPL == 8)
+      asm volatile("" : "+v"(wself), "+v"(wj), "+v"(wj2), "+v"(wk), "+v"(wk2), "+v"(wkp), "+v"(wk2p) : "v"(vel), "v"(risti) : "memory");
+    else
+      asm volatile("" : "+v"(wself), "+v"(wj), "+v"(wj2), "+v"(wk), "+v"(wk2) : "v"(vel), "v"(risti) : "memory");
     if (SPILL) {
       if (gl < nmoves) H.set_slot((unsigned)mynode, myslot);   // deferred back-pointers of the sift-down
     } else {
@@ -765,28 +812,42 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     const bool band = srec > 0;
     constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
     constexpr int LT = LEV / 4 + 1;
-    int lz_id0 = 0;
+    int lz_id0 = 0, lz_id1 = 0;
+    // (only slots 1 .. ntr are entries: a recorded slot may lie beyond the heap's present end, and what sits there is stale --
+    // after a time-sliced hand-over even another field's entries, whose ids can coincide with this neighbour's)
+    auto lz_ok = [&](int a) { return (unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP); };
     if (LAZY) {   // k = q first: an entry rarely moves up more than three levels between two stores of its slot
-      const int a = band ? (srec >> q) : 0;
-      // (only slots 1 .. ntr are entries: a recorded slot may lie beyond the heap's present end, and what sits there is stale --
-      // after a time-sliced hand-over even another field's entries, whose ids can coincide with this neighbour's)
-      lz_id0 = (int)H.nodes[((unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP)) ? a : 0];
+      // (8 lanes per field: the two lanes of the neighbour read two ancestors each, k = 2q and 2q + 1)
+      const int a = band ? (srec >> (GPL == 16 ? q : 2 * q)) : 0;
+      lz_id0 = (int)H.nodes[lz_ok(a) ? a : 0];
+      if constexpr (GPL == 8) lz_id1 = (int)H.nodes[lz_ok(a >> 1) ? (a >> 1) : 0];
     }
     float trav = INFINITY;
     PROF(3);
     if (vj && vk && nopen)
       trav = quadrant_time(vel, risti, dnx, dnz, __int_as_float((int)wj), __int_as_float((int)wj2), __int_as_float((int)wk),
                            __int_as_float((int)wk2), aj, aj2, ak, ak2, fastm);
+    if constexpr (GPL == 8) {
+      const bool akp = vkp && w_is_alive(wkp), ak2p = vk2p && w_is_alive(wk2p);
+      float travp = INFINITY;
+      if (vj && vkp && nopen)
+        travp = quadrant_time(vel, risti, dnx, dnz, __int_as_float((int)wj), __int_as_float((int)wj2), __int_as_float((int)wkp),
+                              __int_as_float((int)wk2p), aj, aj2, akp, ak2p, fastm);
+      trav = fminf(trav, travp);
+    }
     trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
-    trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
+    if constexpr (GPL == 16) trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
     if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
       int found = 64;
       {
-        const int a = band ? (srec >> q) : 0;
-        if ((unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP) && lz_id0 == (int)uself) found = q;
+        const int k0 = GPL == 16 ? q : 2 * q;
+        const int a = band ? (srec >> k0) : 0;
+        if constexpr (GPL == 8)
+          if (lz_ok(a >> 1) && lz_id1 == (int)uself) found = k0 + 1;
+        if (lz_ok(a) && lz_id0 == (int)uself) found = k0;
       }
       { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
-      { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+      if constexpr (GPL == 16) { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
       const bool isdrop = (int)uself == fin_node && fin_slot > 0;
 #ifdef DZ_FMM_LAZYSTAT   // experiment build: how often the first four ancestors do not hold the entry (lanes), and pops
       if (q == 0 && band) atomicAdd(&g_lazy_stat[found == 64 && !isdrop ? 1 : 0], 1ull);
@@ -795,20 +856,23 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       if (wballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
 #pragma unroll
         for (int t = 1; t < LT; t++) {
-          const int k = q + 4 * t;
-          const int a = band ? (srec >> k) : 0;
-          const bool ok = (unsigned)(a - 1) < (unsigned)H.ntr && (!HYB || a < CAP);
-          const int id = (int)H.nodes[ok ? a : 0];
-          if (ok && id == (int)uself) found = found < k ? found : k;
+#pragma unroll
+          for (int u = 0; u < 4 / NBL; u++) {                // (8 lanes per field: two ancestors per lane and round)
+            const int k = (4 / NBL) * q + u + 4 * t;
+            const int a = band ? (srec >> k) : 0;
+            const bool ok = lz_ok(a);
+            const int id = (int)H.nodes[ok ? a : 0];
+            if (ok && id == (int)uself) found = found < k ? found : k;
+          }
         }
         { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
-        { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+        if constexpr (GPL == 16) { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
       }
       if (band) {
         if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
         else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
         // (... unless THIS pop's sift-down took it from the lower HBM level up to the upper one: the word was loaded before)
-        else if (HYB && Heap<CAP, SPILL, NT, HYB>::NH > 1 && srec >= 2 * CAP && srec == fin_slot) stfix = srec >> 1;
+        else if (HYB && Heap<CAP, SPILL, NT, HYB, GPL>::NH > 1 && srec >= 2 * CAP && srec == fin_slot) stfix = srec >> 1;
       }
     }
     PROF(4);
@@ -823,12 +887,12 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
       const bool owner = q == 0;
       const bool act = stfix != 0, isnew = stfix < 0;          // (stfix: the neighbour's true slot, resolved above)
-      const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & 0x1111u;
+      const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & OWNERS;
       const int cnt = __popc(newb);
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
       const bool room = H.ntr + cnt < TOT;
       const int pc = c >> 1;
-      constexpr int NH = Heap<CAP, SPILL, NT, HYB>::NH;
+      constexpr int NH = Heap<CAP, SPILL, NT, HYB, GPL>::NH;
       const bool pchi = HYB && NH > 1 && act && room && pc >= CAP;   // (two HBM levels: the parent of a slot of the lower one)
       float pk = H.keys[(act && room && !pchi) ? pc : 0];
       // (for the one-level rise below: the grandparent's key and the parent's node, requested with the parent's key so that
@@ -844,15 +908,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         }
       }
       const int cact = act ? c : 0;
-      const int c0 = dpp_i<DPP_BCAST0 + 0>(cact), c1 = dpp_i<DPP_BCAST0 + 4>(cact), c2 = dpp_i<DPP_BCAST0 + 8>(cact);
-      const float t0 = dpp_f<DPP_BCAST0 + 0>(trav), t1 = dpp_f<DPP_BCAST0 + 4>(trav), t2 = dpp_f<DPP_BCAST0 + 8>(trav);
+      const int c0 = own_i<GPL, 0>(cact), c1 = own_i<GPL, 1>(cact), c2 = own_i<GPL, 2>(cact);
+      const float t0 = own_f<GPL, 0>(trav), t1 = own_f<GPL, 1>(trav), t2 = own_f<GPL, 2>(trav);
       if (nb > 0 && pc == c0) pk = t0;
       if (nb > 1 && pc == c1) pk = t1;
       if (nb > 2 && pc == c2) pk = t2;
       const bool rise = owner && act && c > 1 && trav < pk;
-      const unsigned riseb = (unsigned)(wballot(rise) >> gbase) & 0xffffu;
+      const unsigned riseb = (unsigned)(wballot(rise) >> gbase) & GMASK;
       // neighbours before the first rising one (n < n0) are written directly; from n0 on, sequentially
-      n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) >> 2) : 4);
+      n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) / NBL) : 4);
       // One-level rise in place (round 3).  41 % of the wave-pops have a rising entry in some group, and in 92 % of those every
       // such group has exactly ONE riser that stops after one level and whose move touches no slot another neighbour of the pop
       // reads or writes (measured, DZ_FMM_PROF2): then the sequential addtree/updtree calls still reduce to independent
@@ -865,14 +929,14 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
       //   * (hybrid heap) the riser's slot lies in the LDS part.
       bool f2 = false;
       if (wballot(riseb != 0u && room) != 0) {            // wave-uniform: some group has a rising entry
-        const int c3 = dpp_i<DPP_BCAST0 + 12>(cact);
-        const int nbr = __builtin_ctz(riseb | 0x10000u) >> 2;
+        const int c3 = own_i<GPL, 3>(cact);
+        const int nbr = __builtin_ctz(riseb | (1u << GPL)) / NBL;
         const int cr = nbr == 0 ? c0 : (nbr == 1 ? c1 : (nbr == 2 ? c2 : c3));
         const int pr = cr >> 1, gr = cr >> 2;
         const bool okr = rise && !(gp >= 1 && trav < gk) && (!HYB || c < CAP);
         const bool clash = owner && act && !rise && (c == pr || c == gr || pc == cr || pc == pr);
-        const unsigned okb = (unsigned)(wballot(okr) >> gbase) & 0xffffu;
-        const unsigned clb = (unsigned)(wballot(clash) >> gbase) & 0xffffu;
+        const unsigned okb = (unsigned)(wballot(okr) >> gbase) & GMASK;
+        const unsigned clb = (unsigned)(wballot(clash) >> gbase) & GMASK;
         f2 = room && riseb != 0u && (riseb & (riseb - 1u)) == 0u && okb == riseb && clb == 0u;
         if (f2) n0 = 4;
       }
@@ -897,7 +961,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
         if (HYB && wballot(whi) != 0) {
           if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
-        H.ntr += __popc(newb & ((1u << (4 * n0)) - 1u));
+        H.ntr += __popc(newb & ((1u << (NBL * n0)) - 1u));
       }
     }
 #ifdef DZ_FMM_PROF
@@ -928,13 +992,13 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
     }
 #endif
     if (!fast) {
-      nbs[0] = dpp_i<DPP_BCAST0 + 0>(stfix); nbs[1] = dpp_i<DPP_BCAST0 + 4>(stfix);
-      nbs[2] = dpp_i<DPP_BCAST0 + 8>(stfix); nbs[3] = dpp_i<DPP_BCAST0 + 12>(stfix);
-      nbt[0] = dpp_f<DPP_BCAST0 + 0>(trav); nbt[1] = dpp_f<DPP_BCAST0 + 4>(trav);
-      nbt[2] = dpp_f<DPP_BCAST0 + 8>(trav); nbt[3] = dpp_f<DPP_BCAST0 + 12>(trav);
+      nbs[0] = own_i<GPL, 0>(stfix); nbs[1] = own_i<GPL, 1>(stfix);
+      nbs[2] = own_i<GPL, 2>(stfix); nbs[3] = own_i<GPL, 3>(stfix);
+      nbt[0] = own_f<GPL, 0>(trav); nbt[1] = own_f<GPL, 1>(trav);
+      nbt[2] = own_f<GPL, 2>(trav); nbt[3] = own_f<GPL, 3>(trav);
       if (!SPILL) {
-        nbn[0] = dpp_i<DPP_BCAST0 + 0>(nrid); nbn[1] = dpp_i<DPP_BCAST0 + 4>(nrid);
-        nbn[2] = dpp_i<DPP_BCAST0 + 8>(nrid); nbn[3] = dpp_i<DPP_BCAST0 + 12>(nrid);
+        nbn[0] = own_i<GPL, 0>(nrid); nbn[1] = own_i<GPL, 1>(nrid);
+        nbn[2] = own_i<GPL, 2>(nrid); nbn[3] = own_i<GPL, 3>(nrid);
       }
       if (SPILL) {
 #pragma unroll
@@ -999,8 +1063,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB> &H, const float 
 #ifdef DZ_TS_WAITSTAT   // experiment build: clocks the workgroups spend waiting for the previous stage of their task
 __device__ unsigned long long g_ts_wait[2];
 #endif
-template <int CAP, bool SPILL, class NT, bool HYB>
+template <int CAP, bool SPILL, class NT, bool HYB, int GPL = 16>
 __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
+  constexpr int GP = GPL, FPW = 64 / GPL;   // lanes per field, fields per wavefront (these shadow the 16-lane constants above)
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
   // (rows padded so that the four fields sit eight LDS banks apart -- they are walked in step, and CAP is a multiple of the 32
@@ -1016,7 +1081,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   unsigned *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
   float *slownr = A.slownr + slot * NREC_R;
-  Heap<CAP, SPILL, NT, HYB> H;
+  Heap<CAP, SPILL, NT, HYB, GPL> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
   H.g0 = gl == 0;
@@ -1097,7 +1162,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         H.rec = rec_c;
         H.tsh = tsh_c;
         cbar();
-        const bool ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
+        const bool ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
                                                             stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
         cbar();
         if (ovf) {
@@ -1228,7 +1293,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, HYB, true>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
+        bool ovf = march<CAP, SPILL, NT, HYB, true, GPL>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -1302,7 +1367,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
             node = tile_x(cx - 1, tsh_c) + tile_z(cz - 1);
             w = rec_c[node];
           }
-          unsigned m = (unsigned)((wballot(w_is_pending(w)) >> (grp * GP)) & 0xffffull);
+          unsigned m = (unsigned)((wballot(w_is_pending(w)) >> (grp * GP)) & ((1ull << GP) - 1ull));
           while (m) {
             const int b = __builtin_ctz(m);
             m &= m - 1;
@@ -1319,7 +1384,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
           }
           if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
-        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
+        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -1345,13 +1410,14 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
 }
 
 
-template <int CAP, class NT, bool HYB = false>
+template <int CAP, class NT, bool HYB = false, int GPL = 16>
 int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::vector<int> &hs) {
+  constexpr int FPW = 64 / GPL;   // fields per wavefront of the fast kernel (the spill rerun keeps 16 lanes per field)
   int rc;
   void *p;
   // workgroups (one wavefront, FPW fields each): as many as the LDS heaps allow per CU
   int per_cu = 0;
-  DZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmm_kernel<CAP, false, NT, HYB>, 64, 0));
+  DZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmm_kernel<CAP, false, NT, HYB, GPL>, 64, 0));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;
   ctx->ksec["fmm.wg_per_cu"] = (double)per_cu;
@@ -1360,12 +1426,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // Small batches: a launch lasts at least as long as ONE field takes alone, and with fewer wavefronts than SIMDs most of the
   // chip idles; fewer fields per wavefront then put every field on a SIMD of its own sooner.  Option fmm.fpw forces 1, 2 or 4.
   A.fpw = FPW;
-  if (ctx->opts.count("fmm.fpw") && (ctx->opts["fmm.fpw"] == 1 || ctx->opts["fmm.fpw"] == 2 || ctx->opts["fmm.fpw"] == 4)) A.fpw = ctx->opts["fmm.fpw"];
+  if (ctx->opts.count("fmm.fpw") && (ctx->opts["fmm.fpw"] == 1 || ctx->opts["fmm.fpw"] == 2 || ctx->opts["fmm.fpw"] == 4) && ctx->opts["fmm.fpw"] < FPW) A.fpw = ctx->opts["fmm.fpw"];
+  ctx->ksec["fmm.lanes_per_field"] = GPL;
   ctx->ksec["fmm.fpw"] = A.fpw;
   if (nwg > (nfield + A.fpw - 1) / A.fpw) nwg = (nfield + A.fpw - 1) / A.fpw;
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068
-  A.ovfcap = HYB ? Heap<CAP, false, NT, HYB>::TOT - CAP : 0;   // the fast kernel: only the HYB heap has HBM levels
+  A.ovfcap = HYB ? Heap<CAP, false, NT, HYB, GPL>::TOT - CAP : 0;   // the fast kernel: only the HYB heap has HBM levels
   // Time slicing (see fmm_kernel): on when the batch does not fit the resident slots (more than one round) and the per-field node
   // words fit comfortably; option fmm.ts = 1 / 2 forces it on / off (0: this rule), fmm.ts_stages sets the number of coarse stages.
   // Few stages are best (not because of the hand-over fences: tools/exp_ts_fences.sh; with many short stages handed out
@@ -1391,7 +1458,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // predecessor is still running waits; with equal stages that wait is 0.15 % of the workgroups' time at 2 stages, 2 % at 8:
   // tools/exp_ts_wait.sh)
   ctx->ksec["fmm.ts_stages"] = ts ? (double)nseg : 0.0;
-  const size_t nown = ts ? (size_t)nfield : (size_t)nslot;   // owners of node words / HBM heap levels: fields or resident slots
+  const size_t nown = (ts ? (size_t)nfield : (size_t)nslot) + 8;   // owners of node words / HBM heap levels: fields or resident slots
   if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
   A.rec_c = (unsigned *)p;
   A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr;
@@ -1461,7 +1528,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   std::vector<int> redo;
   if (!force_spill) {
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
-    hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB>), dim3(nwg), dim3(64), 0, ctx->stream, A);
+    hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB, GPL>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -1477,13 +1544,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     A.flist = (const int *)p;
     A.nfield = (int)redo.size();
     DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
-    A.fpw = FPW;
+    A.fpw = 4;                                        // (16 lanes per field: the spill kernel's sequential sift-down is written for them)
     A.ts_nstage = 1;
-    int nwg2 = ((int)redo.size() + FPW - 1) / FPW;
+    int nwg2 = ((int)redo.size() + 3) / 4;
     if (nwg2 > nwg) nwg2 = nwg;
     // the spill kernel keeps every slot >= CAP in HBM: maxbt entries per resident field, allocated only when a field needs it
     A.ovfcap = ovfcap;
-    if ((rc = dz_scratch(ctx, "fmm.ovf_spill", (size_t)nwg2 * FPW * ovfcap * sizeof(HEnt), &p))) return rc;
+    if ((rc = dz_scratch(ctx, "fmm.ovf_spill", (size_t)nwg2 * 4 * ovfcap * sizeof(HEnt), &p))) return rc;
     A.ovf = (HEnt *)p;
     hipLaunchKernelGGL((fmm_kernel<CAP, true, NT, false>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
@@ -1653,6 +1720,15 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if (ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 1) use_hyb2 = cap > 768;
     if (ctx->opts.count("fmm.hyb2") && ctx->opts["fmm.hyb2"] == 2) use_hyb2 = false;
     if ((ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"]) || (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0)) use_hyb2 = false;
+    // Eight fields per wavefront (8 lanes per field, two quadrants per lane; round 4, option fmm.gp8): 1 = on the heaps the batch
+    // would take anyway (512 LDS slots, all-LDS up to 170-node grids, + one HBM level up to 256), 2 = 255 LDS slots + two HBM
+    // levels (1.5 KB of LDS per field).  Grids with 16-bit node ids only.  Measurements: DESIGN.md section 4.
+    const int gp8 = ctx->opts.count("fmm.gp8") ? ctx->opts["fmm.gp8"] : 0;
+    if (gp8 && small && cap <= 768) {
+      if (gp8 == 2) rc = run_fmm<256, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
+      else if (cap <= 512) rc = run_fmm<512, unsigned short, false, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
+      else rc = run_fmm<512, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
+    } else
     if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
     // grids of 171 .. 256 nodes a side (S-256) with more fields than the 768-slot heaps hold at once (8 workgroups of 4 per CU):

@@ -409,3 +409,35 @@ def test_fmm_s128_bench_batch_at_full_size(ctx, orc):
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
     assert torch.equal(out, ref)
+
+
+def test_fmm_eight_fields_per_wavefront(ctx, orc):
+    """option fmm.gp8 (round 4): 8 lanes per field, each solving two quadrants -- eight fields per wavefront, three-level parallel
+    sift-down steps, two-lane slot look-ups -- on the 512-slot heaps (1) and on 255 LDS slots + two HBM levels (2): every grid
+    size class with 16-bit node ids, corner sources, central sources with the widest bands, rough maps, time slicing, and a heap
+    that overflows into the 16-lane spill kernel; all bit-identical to the oracle"""
+    try:
+        for mode in (1, 2):
+            ctx.set_option("fmm.gp8", mode)
+            _run_case(ctx, orc, 17, 17, 3, 12, seed=3, goxd=26.5, gozd=101.25, edge_sources=True)
+            assert ctx.kernel_seconds("fmm.lanes_per_field") == 8
+            _run_case(ctx, orc, 12, 23, 2, 9, seed=11, edge_sources=True)
+            _run_case(ctx, orc, 28, 28, 2, 9, seed=78, rough=True)
+            _run_case(ctx, orc, 54, 54, 2, 7, seed=5)
+            _run_case(ctx, orc, 54, 54, 1, 9, seed=6, shrink=5.0)          # central sources: bands beyond the LDS slots
+            _run_case(ctx, orc, 54, 54, 1, 5, seed=7, edge_sources=True, rough=True)
+            ctx.set_option("fmm.ts", 1)
+            for stages in (1, 3, 7):
+                ctx.set_option("fmm.ts_stages", stages)
+                _run_case(ctx, orc, 54, 54, 2, 9, seed=15 + stages)
+                assert ctx.kernel_seconds("fmm.ts_stages") == stages
+            ctx.set_option("fmm.ts", 0)
+            ctx.set_option("fmm.ts_stages", 0)
+        ctx.set_option("fmm.gp8", 1)
+        ctx.set_option("fmm.cap", 64)                                       # (an explicit cap turns gp8 off: the 16-lane kernels)
+        _run_case(ctx, orc, 17, 17, 2, 6, seed=8, goxd=26.5, gozd=101.25)
+    finally:
+        ctx.set_option("fmm.gp8", 0)
+        ctx.set_option("fmm.cap", 0)
+        ctx.set_option("fmm.ts", 0)
+        ctx.set_option("fmm.ts_stages", 0)

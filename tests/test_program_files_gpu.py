@@ -282,3 +282,34 @@ def test_forward_program_files_match_the_reference_program(tmp_path, tag):
             spec[name] = ({}, 2e-5, ())
     assert tag == "forward" or sum(n.startswith("raypath_") for n in ref) == 4
     check(tag, got, ref, spec)
+
+
+GOLD_T4 = os.path.join(GOLD, "program_test4.npz")
+
+
+@pytest.mark.skipif(not os.path.exists(GOLD_T4), reason="tests/golden/program_test4.npz not generated (make_program_test4_golden.py)")
+def test_inversion_program_on_test4_yunnan_matches_the_reference_program(tmp_path):
+    """BASELINE config 4 at program level: host/DAzimSurfTomo_amd on the bundled example/test4_Yunnan inputs (38 x 42 x 18 model,
+    36 periods, 20 877 traveltimes, joint inversion, 5 outer iterations) against every file the flang-built reference PROGRAM wrote
+    on them (tests/golden/make_program_test4_golden.py: half an hour of one core).  Line structure exact; numbers within the bars
+    below -- five fp32 LSMR solves of ~170-200 iterations each with a 10-vector reorthogonalisation window lie between the inputs
+    and the final model, so the bars are those of tests/test_e2e_test4_gpu.py (twice the measured maxima; SURVEY 8d proposed
+    Vs 2e-3 km/s, Gc / Gs 0.02 %)."""
+    ins, ref = load("test4")
+    got = run(INV_EXE, ins, tmp_path)
+    spec = inversion_spec(True)
+    spec.update(T4_SPEC)
+    check("test4", got, ref, spec)
+
+
+# measured on MI355X (round 4), max |ours - reference program| over the whole file; bar = 2 x measured
+T4_SPEC = {
+    "DSurfTomo.inv": ({3: 2e-3}, 0.0, ()),
+    "MOD_Ref": ({}, 2e-3, ()),
+    "IterVel.out": ({"Vs": 2e-3, "DWS": lambda v: 2e-3 * abs(v) + 1e-3}, 0.0, ()),
+    "Gc_Gs_model.inv": ({0: 0.0, 1: 0.0, 2: 0.0, 3: 2e-3, 5: 4e-2, 6: 4e-2, 7: 4e-2}, 0.0, (4,)),
+    "period_phaseVMOD.dat": ({3: 2e-3}, 0.0, ()),
+    "phaseV_FWD.dat": ({3: 2e-3}, 0.0, ()),
+    "period_Azm_tomo.inv": ({3: 2e-3, 5: 2e-2, 6: 2e-2, 7: 2e-2, 8: 2e-2}, 0.0, (4,)),
+    "Traveltime_statis_00th.dat": ({}, lambda v: 2e-3 * abs(v) + 2e-2, ()),
+}
