@@ -59,6 +59,9 @@ struct DispArgs {
   int *ff_m;           // [ncol]  0: no information
   double *ff_c;        // [ncol]
   int *ff_v;           // [ncol]  steps the perturbed copies may jump at most (see disp_bracket_kernel: a dip of |del| before the bracket)
+  // central differences formed by the launch itself (the copies' launch of disp.async: var0 = 1, an even number of variants per
+  // column, so the -/+ pair of a perturbation sits in neighbouring lanes of one wavefront); null: disp_finalize forms them
+  double *svs, *svp, *srho;   // [nz][kmax][ncol]
 };
 
 __device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
@@ -858,6 +861,20 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
       if (lane == 0) { atomicAdd(&g_disp_stat[1], st_iter * 64ull); atomicAdd(&g_disp_stat[2], st_iter * 64ull); }
     }
 #endif
+    // ---- the central differences of depthkernel (inv/CalSurfG.f90:90-133) as this launch's epilogue: lanes 2j / 2j + 1 of the
+    // wavefront hold the - / + copy of one perturbation (knot K.pi, quantity K.pq) with all their periods finished -- this task's
+    // by this wavefront, earlier chunks' visible since the acquire at the top of the task.  Same arithmetic as disp_finalize:
+    // ((double)cg2 - (double)cg1) / (double)(0.01f * base), cg the fp32-rounded phase velocities.
+    if (A.svs && kend == kmax && team == 1) {
+      double *const out = K.pq == 0 ? A.svs : (K.pq == 1 ? A.svp : A.srho);
+      const float base = active && var > 0 ? (K.pq == 0 ? K.vs : (K.pq == 1 ? K.vp : K.rho))[K.pi - 1] : 1.0f;
+      const double den = (double)(0.01f * base);
+      for (int kk = 0; kk < kmax; kk++) {
+        const float mine = active ? cg[kk] : 0.0f;
+        const float other = __shfl_xor(mine, 1);
+        if (active && !(lane & 1)) out[((size_t)(K.pi - 1) * kmax + kk) * A.ncol + col] = ((double)other - (double)mine) / den;
+      }
+    }
     if (active && kend < kmax && !(chunk > 0 && A.st_f[wi])) {   // hand the chain to the next chunk
       A.st_c[wi] = cprev;
       A.st_d[wi] = del1st;
@@ -977,6 +994,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   }
   void *p;
   DispArgs A;
+  A.svs = A.svp = A.srho = nullptr;
   A.ncol = ncol;
   A.nz = nz;
   A.kmax = kmax;
@@ -1138,10 +1156,12 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       DZ_HIP(hipGetLastError());
       DZ_HIP(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
       DZ_HIP(hipEventRecord(ctx->ev_a0, ctx->stream2));
+      // (the copies' launch forms the central differences itself -- DispArgs::svs: a separate kernel behind it would wait for a free
+      // SIMD until the eikonal kernel's persistent workgroups leave, 190 ms at S-256, profiles/r3_bench_kernel_stats.md)
+      C.svs = svs.dev;
+      C.svp = svp.dev;
+      C.srho = srho.dev;
       launch(C, nwgC, dyn_lds, ctx->stream2);
-      DZ_HIP(hipGetLastError());
-      hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream2, ncol, nz, kmax, nvar,
-                         vel.dev, A.cg, (double *)nullptr, svs.dev, svp.dev, srho.dev, d_nfail);
       DZ_HIP(hipGetLastError());
       DZ_HIP(hipEventRecord(ctx->ev_a1, ctx->stream2));
       ctx->aux_pending = true;
