@@ -62,6 +62,9 @@ struct DispArgs {
   // central differences formed by the launch itself (the copies' launch of disp.async: var0 = 1, an even number of variants per
   // column, so the -/+ pair of a perturbation sits in neighbouring lanes of one wavefront); null: disp_finalize forms them
   double *svs, *svp, *srho;   // [nz][kmax][ncol]
+  // ... and pvRc by the launch of the columns' own curves (var0 = 0, one variant per column); null: disp_finalize
+  double *pv;                 // [kmax][ncol]
+  int *nfail;                 // periods without a root (counted where pv is written)
 };
 
 __device__ __forceinline__ double sgn(double x) { return copysign(1.0, x); }
@@ -865,6 +868,15 @@ __global__ __launch_bounds__(DT, 3) void disp_kernel(DispArgs A) {
     // wavefront hold the - / + copy of one perturbation (knot K.pi, quantity K.pq) with all their periods finished -- this task's
     // by this wavefront, earlier chunks' visible since the acquire at the top of the task.  Same arithmetic as disp_finalize:
     // ((double)cg2 - (double)cg1) / (double)(0.01f * base), cg the fp32-rounded phase velocities.
+    if (A.pv && kend == kmax && active && var == 0 && tl == 0) {   // pvRc = the column's own curve (inv/CalSurfG.f90:60)
+      int nzero = 0;
+      for (int kk = 0; kk < kmax; kk++) {
+        const float c0 = cg[kk];
+        A.pv[(size_t)kk * A.ncol + col] = (double)c0;
+        nzero += c0 == 0.0f ? 1 : 0;
+      }
+      if (nzero) atomicAdd(A.nfail, nzero);
+    }
     if (A.svs && kend == kmax && team == 1) {
       double *const out = K.pq == 0 ? A.svs : (K.pq == 1 ? A.svp : A.srho);
       const float base = active && var > 0 ? (K.pq == 0 ? K.vs : (K.pq == 1 ? K.vp : K.rho))[K.pi - 1] : 1.0f;
@@ -994,7 +1006,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   }
   void *p;
   DispArgs A;
-  A.svs = A.svp = A.srho = nullptr;
+  A.svs = A.svp = A.srho = A.pv = nullptr;
+  A.nfail = nullptr;
   A.ncol = ncol;
   A.nz = nz;
   A.kmax = kmax;
@@ -1144,6 +1157,8 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       B.var0 = 0;
       B.nvarp = 1;
       B.team = teams ? TEAM : 1;
+      B.pv = pv.dev;              // (written by the launch itself: no kernel behind it that waits for a free SIMD beside the copies)
+      B.nfail = d_nfail;
       B.ngroup = (ncol + TW / B.team - 1) / (TW / B.team);
       ctx->ksec["disp.team"] = B.team;
       if ((rc = dz_scratch(ctx, "disp.ready_b", (size_t)B.ngroup * 4 + 64, &p))) return rc;
@@ -1166,9 +1181,6 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       DZ_HIP(hipEventRecord(ctx->ev_a1, ctx->stream2));
       ctx->aux_pending = true;
       ctx->aux_timed = true;
-      hipLaunchKernelGGL(disp_finalize, dim3((unsigned)((nf + 255) / 256)), dim3(256), 0, ctx->stream, ncol, nz, kmax, nvar,
-                         vel.dev, A.cg, pv.dev, (double *)nullptr, (double *)nullptr, (double *)nullptr, d_nfail);
-      DZ_HIP(hipGetLastError());
     }
     t.stop();
   }

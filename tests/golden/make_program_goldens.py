@@ -72,7 +72,7 @@ def run_program(exe, inputs, workdir, para="para.in"):
     os.makedirs(workdir)
     for name, text in inputs.items():
         open(os.path.join(workdir, name), "w").write(text)
-    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("DAZIM_GOLDEN_THREADS", "1"))
 
     def unlimited_stack():   # the programs keep their work arrays on the stack (test4_Yunnan: segfault under the default 8 MB)
         import resource

@@ -35,7 +35,7 @@ def main():
         t0 = time.time()
         out = run_program(exe, inputs, os.path.join(tmp, "run_test4"))
         print("reference program: %.0f s" % (time.time() - t0))
-        np.savez_compressed(os.path.join(HERE, "program_test4.npz"), **{"in:" + k: v for k, v in inputs.items()},
+        np.savez_compressed(os.environ.get("DAZIM_GOLDEN_OUT", os.path.join(HERE, "program_test4.npz")), **{"in:" + k: v for k, v in inputs.items()},
                             **{"out:" + k: v for k, v in out.items()}, seconds=np.float64(time.time() - t0))
         print("test4", {k: len(v.splitlines()) for k, v in out.items()})
     finally:
