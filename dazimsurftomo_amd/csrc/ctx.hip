@@ -33,6 +33,17 @@ size_t dz_trim_caches(dazim_ctx *ctx) {
     if (!ctx->stage[i].busy) { freed += ctx->stage[i].bytes; (void)hipFree(ctx->stage[i].p); ctx->stage.erase(ctx->stage.begin() + i); }
   for (size_t i = ctx->big.size(); i-- > 0;)
     if (!ctx->big[i].busy) { freed += ctx->big[i].bytes; (void)hipFree(ctx->big[i].p); ctx->big.erase(ctx->big.begin() + i); }
+  // ... and the multi-GB per-field state of a time-sliced eikonal batch (S-512: 34 GB), which is kept between calls because
+  // giving it back and asking for it again costs 0.7 s per step -- unless an eikonal call is the one that ran out of memory
+  if (!ctx->fmm_busy)
+    for (const char *nm : {"fmm.rec_c", "fmm.ts_keys", "fmm.ts_nodes", "fmm.ovf"}) {
+      auto it = ctx->scratch.find(nm);
+      if (it != ctx->scratch.end() && it->second.first && it->second.second >= ((size_t)1 << 30)) {
+        freed += it->second.second;
+        (void)hipFree(it->second.first);
+        ctx->scratch.erase(it);
+      }
+    }
   return freed;
 }
 
@@ -64,17 +75,6 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
   }
   *out = s.first;
   return 0;
-}
-
-// give a named scratch block back to the device (the caller knows nothing is using it any more)
-void dz_scratch_release(dazim_ctx *ctx, const char *name) {
-  auto it = ctx->scratch.find(name);
-  if (it == ctx->scratch.end()) return;
-  if (it->second.first) {
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(it->second.first);
-  }
-  ctx->scratch.erase(it);
 }
 
 // Staging cache: best fit among the free blocks, else a new allocation; at most 64 blocks / 2 GiB are kept, larger or surplus
@@ -235,6 +235,20 @@ int dazim_create(dazim_ctx **out, int device) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+  // DAZIM_OPTS=name=value,name=value: tuning options (include/dazim.h, dazim_set_option) for callers that do not set them
+  // themselves -- the Fortran programs under tools/run_test4_program.sh; speed only, like the options
+  if (const char *ev = getenv("DAZIM_OPTS")) {
+    std::string str(ev);
+    size_t pos = 0;
+    while (pos < str.size()) {
+      size_t end = str.find(',', pos);
+      if (end == std::string::npos) end = str.size();
+      const std::string kv = str.substr(pos, end - pos);
+      const size_t eq = kv.find('=');
+      if (eq != std::string::npos && eq > 0) ctx->opts[kv.substr(0, eq)] = atoi(kv.c_str() + eq + 1);
+      pos = end + 1;
+    }
+  }
   *out = ctx;
   return 0;
 }

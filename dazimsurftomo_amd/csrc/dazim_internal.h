@@ -21,6 +21,7 @@ struct dazim_ctx {
   std::map<std::string, int> opts;     // dazim_set_option
   // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
   std::map<std::string, std::pair<void *, size_t>> scratch;
+  bool fmm_busy = false;   // an eikonal call is using its scratch blocks (dz_trim_caches must not free them)
   // RCCL communicator of a row-sharded solve (dazim_comm_init); nullptr = single GPU, RCCL never touched
   // staging blocks for host-pointer arguments (DzBuf): released blocks are kept and handed out again, because a
   // hipMalloc + hipFree pair per staged array costs milliseconds in a program that calls the library once per outer iteration
@@ -54,7 +55,6 @@ int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what 
 
 // named scratch buffer of at least `bytes` bytes
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
-void dz_scratch_release(dazim_ctx *ctx, const char *name);   // free it now (scratch is otherwise kept for the life of the context)
 
 size_t dz_trim_caches(dazim_ctx *ctx);                                // free all idle cached blocks; bytes released
 hipError_t dz_malloc_retry(dazim_ctx *ctx, void **p, size_t bytes);   // hipMalloc; on out-of-memory trim the caches and retry once

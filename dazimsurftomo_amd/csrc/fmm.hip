@@ -1558,11 +1558,6 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
-  // The per-field state of a time-sliced batch is only needed while the batch runs.  Small (S-256: 4.2 GB) it is kept for the next
-  // call like every scratch block; above 8 GB (S-512: 34 GB for 32 000 fields) it goes back to the device at once, so that the G
-  // assembly and the solve that follow on the same context find the memory free.
-  if (ts && nown * (rec_field_bytes + (size_t)A.ovfcap * sizeof(HEnt)) + (size_t)nfield * CAP * 8 > ((size_t)8 << 30))
-    for (const char *nm : {"fmm.rec_c", "fmm.ts_keys", "fmm.ts_nodes", "fmm.ovf"}) dz_scratch_release(ctx, nm);
 #ifdef DZ_TS_WAITSTAT
   {
     unsigned long long h[2];
@@ -1607,6 +1602,11 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
   if (kmax < 1 || nfield < 0 || !pv_u || !ttn_u || (nfield > 0 && (!scx_u || !scz_u || !period_u)) || g.nnx > 32767 || g.nnz > 32767)
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_fmm_batch");
   DZ_HIP(hipSetDevice(ctx->device));
+  struct Busy {   // (the multi-GB scratch of a time-sliced batch may be freed by dz_trim_caches when another call runs out of memory)
+    dazim_ctx *c;
+    explicit Busy(dazim_ctx *c_) : c(c_) { c->fmm_busy = true; }
+    ~Busy() { c->fmm_busy = false; }
+  } busy(ctx);
   const size_t nn = (size_t)g.nnx * g.nnz, npv = (size_t)(g.nvz + 2) * (g.nvx + 2), nr = (size_t)RM * RM;
   DzBuf<double> pv;
   DzBuf<float> scx, scz, veln, ttn, ttnr;
