@@ -1041,8 +1041,13 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   bool async = kernels && ctx->opts.count("disp.async") && ctx->opts["disp.async"] && !vel.staged && !svs.staged &&
                !svp.staged && !srho.staged && !(ctx->opts.count("disp.pchunk") && ctx->opts["disp.pchunk"] > 0 && ctx->opts["disp.pchunk"] < kmax);
   // the column curves of an asynchronous call in teams (disp_kernel: TEAM grid points of the bracket search at a time) when the
-  // copies leave room for the extra wavefronts -- less than a round of workgroups; option disp.team = 1 / 2 forces them on / off
-  bool teams = (double)(((long)ncol * (nvar - 1) + DT - 1) / DT) + (double)((ncol * TEAM + DT - 1) / DT) <= 0.98 * (double)((long)ctx->num_cu * 3);   // (test4_Yunnan, 1.01 of a round with teams: 62 -> 25 ms of column curves, but the copies beside them 139 -> 163 ms: no gain)
+  // extra wavefronts do not add a round of workgroups to the copies beside them: everything fits one round (S-128), or the copies
+  // need a second, partly filled round anyway (S-256: 832 + 183 workgroups on 768 slots; the curves are what the eikonal kernel
+  // waits for, 23.5 -> 12 ms, step 370 -> 366 ms).  test4_Yunnan (0.89 of a round, 1.01 with teams: 62 -> 25 ms of column curves,
+  // but the copies beside them 139 -> 163 ms) stays without.  Option disp.team = 1 / 2 forces them on / off.
+  const double wg_copies = (double)(((long)ncol * (nvar - 1) + DT - 1) / DT), wg_teams = (double)((ncol * TEAM + DT - 1) / DT);
+  const double wg_round = (double)((long)ctx->num_cu * 3);
+  bool teams = wg_copies + wg_teams <= 0.98 * wg_round || (wg_copies > 1.02 * wg_round && wg_copies + wg_teams <= 1.9 * wg_round);
   if (ctx->opts.count("disp.team") && ctx->opts["disp.team"] == 1) teams = true;
   if (ctx->opts.count("disp.team") && ctx->opts["disp.team"] == 2) teams = false;
   const size_t dyn_lds = knot_lds(nvar), dyn_lds_base = teams ? knot_lds(1, TW / TEAM) : knot_lds(1);
