@@ -441,3 +441,32 @@ def test_fmm_eight_fields_per_wavefront(ctx, orc):
         ctx.set_option("fmm.cap", 0)
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
+
+
+def test_fmm_short_exact_division_and_its_guard(ctx, orc):
+    """the quadrant solve's short exact division / square root (round 4) runs only inside a checked range of node spacings and
+    velocities; option fmm.ieee = 1, a grid with 0.22 km node spacing and a map with a velocity above 16 km/s take the compiler's
+    IEEE sequences instead -- same bits in every case"""
+    _run_case(ctx, orc, 17, 17, 2, 6, seed=31, goxd=26.5, gozd=101.25)
+    assert ctx.kernel_seconds("fmm.fast_math") == 1
+    try:
+        ctx.set_option("fmm.ieee", 1)
+        _run_case(ctx, orc, 17, 17, 2, 6, seed=31, goxd=26.5, gozd=101.25)
+        assert ctx.kernel_seconds("fmm.fast_math") == 0
+    finally:
+        ctx.set_option("fmm.ieee", 0)
+    _run_case(ctx, orc, 17, 17, 2, 6, seed=32, goxd=26.5, gozd=101.25, dv=0.01, shrink=0.012)       # 1.1 km cells -> 0.22 km nodes
+    assert ctx.kernel_seconds("fmm.fast_math") == 0
+    # a velocity outside 0.125 .. 16 km/s is seen by gridder_kernel (the host only knows the geometry): fields still identical
+    nx = ny = 17
+    pv = synth.phase_velocity_maps(nx, ny, 1, 5)
+    pv[0, 40] = 17.5
+    lat, lon = synth.stations(nx, ny, 26.5, 101.25, 0.25, 0.25, 5, 6)
+    sx, sz = synth.radians(lat, lon)
+    per = np.ones(5, np.int32)
+    out = ctx.fmm_batch(nx, ny, 26.5, 101.25, 0.25, 0.25, pv, sx, sz, per)
+    g = orc.geometry(nx, ny, 26.5, 101.25, 0.25, 0.25)
+    veln = orc.gridder(g, pv[0])
+    for f in range(5):
+        rc, ttn, *_ = orc.fmm_field(g, pv[0], veln, sx[f], sz[f])
+        assert rc == 0 and np.array_equal(out["ttn"][f], ttn)
