@@ -63,6 +63,8 @@ def compare_text(name, ref, got, bars, default_bar, structure_only_cols=(), line
             if label in a:
                 line_bar = lb
         for c, ((sa, _), (sb, _)) in enumerate(zip(ta, tb)):
+            if sa.endswith("s") and sb.endswith("s") and NUM.match(sa[:-1]) and NUM.match(sb[:-1]):   # "0.3214s": a number with its unit
+                sa, sb = sa[:-1], sb[:-1]
             na, nb = NUM.match(sa), NUM.match(sb)
             if na and nb:
                 if timing or c in structure_only_cols:
@@ -291,10 +293,9 @@ GOLD_T4 = os.path.join(GOLD, "program_test4.npz")
 def test_inversion_program_on_test4_yunnan_matches_the_reference_program(tmp_path):
     """BASELINE config 4 at program level: host/DAzimSurfTomo_amd on the bundled example/test4_Yunnan inputs (38 x 42 x 18 model,
     36 periods, 20 877 traveltimes, joint inversion, 5 outer iterations) against every file the flang-built reference PROGRAM wrote
-    on them (tests/golden/make_program_test4_golden.py: half an hour of one core).  Line structure exact; numbers within the bars
-    below -- five fp32 LSMR solves of ~170-200 iterations each with a 10-vector reorthogonalisation window lie between the inputs
-    and the final model, so the bars are those of tests/test_e2e_test4_gpu.py (twice the measured maxima; SURVEY 8d proposed
-    Vs 2e-3 km/s, Gc / Gs 0.02 %)."""
+    on them (tests/golden/make_program_test4_golden.py).  Line structure exact; numbers within twice the measured maxima (T4_SPEC
+    below) -- five fp32 LSMR solves of ~150-170 iterations each lie between the inputs and the final model, and the final Vs
+    still agrees to the last printed digit (SURVEY 8d proposed Vs 2e-3 km/s, Gc / Gs 0.02 %: met with a factor of ten to spare)."""
     ins, ref = load("test4")
     got = run(INV_EXE, ins, tmp_path)
     spec = inversion_spec(True)
@@ -302,14 +303,17 @@ def test_inversion_program_on_test4_yunnan_matches_the_reference_program(tmp_pat
     check("test4", got, ref, spec)
 
 
-# measured on MI355X (round 4), max |ours - reference program| over the whole file; bar = 2 x measured
+# measured on MI355X (round 4), max |ours - reference program| over the whole file (the golden's DAzimSurfTomo ran with 6 OpenMP
+# threads in depthkernel, 1 098 s): Vs 1e-4 km/s = one unit of the last printed digit in DSurfTomo.inv, MOD_Ref and Gc_Gs_model.inv,
+# Gc/L 1.1e-3 %, Gs/L 7e-4 %, period maps <= 2e-5, period_phaseVMOD.dat identical, lsmr.txt 4.3e-4 relative on the first ten
+# iterations of each of the five solves.  Bars = 2 x measured (compare_text adds one unit of the last printed digit).
 T4_SPEC = {
-    "DSurfTomo.inv": ({3: 2e-3}, 0.0, ()),
-    "MOD_Ref": ({}, 2e-3, ()),
-    "IterVel.out": ({"Vs": 2e-3, "DWS": lambda v: 2e-3 * abs(v) + 1e-3}, 0.0, ()),
-    "Gc_Gs_model.inv": ({0: 0.0, 1: 0.0, 2: 0.0, 3: 2e-3, 5: 4e-2, 6: 4e-2, 7: 4e-2}, 0.0, (4,)),
-    "period_phaseVMOD.dat": ({3: 2e-3}, 0.0, ()),
-    "phaseV_FWD.dat": ({3: 2e-3}, 0.0, ()),
-    "period_Azm_tomo.inv": ({3: 2e-3, 5: 2e-2, 6: 2e-2, 7: 2e-2, 8: 2e-2}, 0.0, (4,)),
+    "DSurfTomo.inv": ({2: 2e-4, 3: 2e-4}, 0.0, ()),
+    "MOD_Ref": ({}, 2e-4, ()),
+    "IterVel.out": ({"Vs": 2e-4, "DWS": lambda v: 2e-3 * abs(v) + 1e-3}, 0.0, ()),
+    "Gc_Gs_model.inv": ({0: 0.0, 1: 0.0, 2: 0.0, 3: 2e-4, 5: 2e-4, 6: 2.2e-3, 7: 1.4e-3}, 0.0, (4,)),
+    "period_phaseVMOD.dat": ({3: 2e-4}, 0.0, ()),
+    "phaseV_FWD.dat": ({3: 2e-4}, 0.0, ()),
+    "period_Azm_tomo.inv": ({3: 4e-5, 5: 2e-5, 6: 2e-5, 7: 4e-5, 8: 2e-5}, 0.0, (4,)),
     "Traveltime_statis_00th.dat": ({}, lambda v: 2e-3 * abs(v) + 2e-2, ()),
 }
