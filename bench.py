@@ -616,7 +616,9 @@ def main():
                         "frac": ginst / VALU_PEAK_GINST, "traffic": traffic["fmm"],
                         "valu_inst_per_launch": sq["SQ_INSTS_VALU"], "valu_inst_per_wave_pop": sq["SQ_INSTS_VALU"] / wave_pops,
                         "useful_frac": USEFUL_VALU_PER_WAVE_POP * wave_pops / sq["SQ_INSTS_VALU"],
-                        "simd_valu_busy_in_profile": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+                        # share of a resident wavefront's cycles in which it has a VALU instruction active; three wavefronts share a
+                        # SIMD, so x 3 ~ the SIMD's VALU pipe busy
+                        "valu_active_share_of_wave_cycles": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
                         "counters_source": sq_src}
         else:   # no counter pass of these sources: the HBM figures the metric asks for, and the reason
             roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
