@@ -92,7 +92,12 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
  * the 512-slot hybrid heap with 16-bit node ids = S-256, 8 on the 512-slot heap with two HBM levels = S-512, 4 elsewhere).
  * "fmm.ieee": 1 = the compiler's IEEE division / square root in the quadrant solve on every grid (default: the short exact forms
- * where node spacings are 2 .. 4096 km and velocities 0.125 .. 16 km/s; same bits either way).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
+ * where node spacings are 2 .. 4096 km and velocities 0.125 .. 16 km/s; same bits either way).
+ * "fmm.gp8": 1 / 2 = eight fields per wavefront on grids up to 256 nodes a side (8 lanes per field, two quadrants per lane) with
+ * the heap the batch would take anyway / with 255 LDS slots + two HBM levels.  Bit-identical; measured slower than the default
+ * four fields per wavefront, kept for experiments.
+ * The environment variable DAZIM_OPTS=name=value,name=value sets options when a context is created (for callers that do not
+ * call dazim_set_option themselves, e.g. the Fortran programs).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
  * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  "fmm.hyb2": 1 / 2 =
  * on grids above 256 nodes a side the heaps with few levels in LDS and two in HBM (512 slots up to 682 nodes, 1024 above) always /
  * never (default 0: for batches of more than 2.5 workgroups per CU, and above 768 nodes).  Speed only, all four.
