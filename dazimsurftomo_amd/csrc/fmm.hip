@@ -73,6 +73,7 @@ struct FmmArgs {
   int ovfcap;
   unsigned *counter;
   const int *flist;  // nullable: indirection used by the spill rerun
+  int prio;          // 1: the wavefronts raise their issue priority (small batches beside the dispersion copies, see run_fmm)
   int fastm;         // grid steps within the range in which the short exact division / square root may run (see div_exact)
   const int *vflag;  // [1] set by gridder_kernel when a phase velocity lies outside that range
   int fpw;           // fields a wavefront takes per batch (1, 2 or FPW = 4 of its 16-lane groups are active): see run_fmm
@@ -1095,6 +1096,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
   // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
   const bool fastm = A.fastm != 0 && __builtin_amdgcn_readfirstlane(*A.vflag) == 0;
+  if (A.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over another kernel's wavefronts on the same SIMD (see run_fmm)
   const int nstage = SPILL ? 1 : A.ts_nstage;
   const bool ts = nstage > 1;
   unsigned &s_stage = *reinterpret_cast<unsigned *>(&s_keys[1][0]);   // (the dummy slot of the second field, like s_base)
@@ -1429,6 +1431,16 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   if (ctx->opts.count("fmm.fpw") && (ctx->opts["fmm.fpw"] == 1 || ctx->opts["fmm.fpw"] == 2 || ctx->opts["fmm.fpw"] == 4) && ctx->opts["fmm.fpw"] < FPW) A.fpw = ctx->opts["fmm.fpw"];
   ctx->ksec["fmm.lanes_per_field"] = GPL;
   ctx->ksec["fmm.fpw"] = A.fpw;
+  // Issue priority (round 4).  A batch that leaves most of the chip empty lasts as long as one field's serial chain, and every cycle
+  // one of its wavefronts waits for an issue slot behind another kernel's wavefronts -- the dispersion kernel's perturbed copies on
+  // the auxiliary stream (disp.async) -- lengthens that chain: s_setprio 3 gives them the slot first.  S-128: eikonal launch 52.0 ->
+  // 45.0 ms (= alone on the chip), step 64.0 -> 56.9 ms; test4_Yunnan program: assembly 1.015 -> 0.875 s.  A batch that fills the chip
+  // gains nothing among its own wavefronts and only starves the copies the ray kernel then waits for (S-256: step 368 -> 380 ms), so
+  // the rule is: at most half of the resident workgroups.  Option fmm.prio = 1 / 2 forces it on / off.
+  A.prio = (nfield + A.fpw - 1) / A.fpw <= nwg / 2 ? 1 : 0;
+  if (ctx->opts.count("fmm.prio") && ctx->opts["fmm.prio"] == 1) A.prio = 1;
+  if (ctx->opts.count("fmm.prio") && ctx->opts["fmm.prio"] == 2) A.prio = 0;
+  ctx->ksec["fmm.prio"] = A.prio;
   if (nwg > (nfield + A.fpw - 1) / A.fpw) nwg = (nfield + A.fpw - 1) / A.fpw;
   const int nslot = nwg * FPW;
   const int ovfcap = (int)((nn > nr ? nn : nr) / 2 + 64);  // maxbt = nint(snb*nnx*nnz), inv/CalSurfG.f90:1068

@@ -93,6 +93,8 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
  * the 512-slot hybrid heap with 16-bit node ids = S-256, 8 on the 512-slot heap with two HBM levels = S-512, 4 elsewhere).
  * "fmm.ieee": 1 = the compiler's IEEE division / square root in the quadrant solve on every grid (default: the short exact forms
  * where node spacings are 2 .. 4096 km and velocities 0.125 .. 16 km/s; same bits either way).
+ * "fmm.prio": 1 / 2 = the eikonal kernel's wavefronts raise their issue priority always / never (default 0: when the batch
+ * occupies at most half of the resident workgroups, i.e. runs at one field's latency beside the dispersion copies).  Speed only.
  * "fmm.gp8": 1 / 2 = eight fields per wavefront on grids up to 256 nodes a side (8 lanes per field, two quadrants per lane) with
  * the heap the batch would take anyway / with 255 LDS slots + two HBM levels.  Bit-identical; measured slower than the default
  * four fields per wavefront, kept for experiments.
