@@ -271,6 +271,9 @@ __global__ void ti_model_kernel(TiArgs A) {
 }
 
 __global__ __launch_bounds__(TT) void ti_kernel(TiArgs A) {
+  // a small launch the eikonal solve waits for, usually beside the dispersion kernel's perturbed copies (auxiliary stream): issue
+  // priority over their wavefronts (test4_Yunnan: 13.5 ms per call beside the copies, 1.6 ms alone)
+  __builtin_amdgcn_s_setprio(3);
   const long lane = (long)blockIdx.x * TT + threadIdx.x;
   const long nlane = (long)A.ncol * A.kmax;
   if (lane >= nlane) return;
