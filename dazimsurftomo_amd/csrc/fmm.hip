@@ -663,6 +663,11 @@ __device__ unsigned long long g_fmm_prof[8];
 #define PROF(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pa_[i] += n_ - pt_; pt_ = n_; } while (0)
 #define PROF_WAIT asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PROF_FLUSH do { if (lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&g_fmm_prof[i_], pa_[i_]); } while (0)
+#elif defined(DZ_FMM_MARK)   // experiment-only build: phase markers in the assembly (tools/fmm_phase_count.py counts the instructions between them)
+#define PROF_DECL
+#define PROF(i) asm volatile("; MARK " #i ::: "memory")
+#define PROF_WAIT
+#define PROF_FLUSH
 #else
 #define PROF_DECL
 #define PROF(i)
@@ -965,8 +970,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
         H.ntr += __popc(newb & ((1u << (NBL * n0)) - 1u));
       }
     }
-#ifdef DZ_FMM_PROF
     PROF(5);
+#ifdef DZ_FMM_PROF
     if (wballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
     pa_[7] += 1000000;                        // iterations (x1e6) on top of the loop-top ticks
 #endif
@@ -1064,8 +1069,33 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
 #ifdef DZ_TS_WAITSTAT   // experiment build: clocks the workgroups spend waiting for the previous stage of their task
 __device__ unsigned long long g_ts_wait[2];
 #endif
+// The kernel reads its arguments through a pointer to the kernarg segment that the compiler cannot see through (round 5).  Taken
+// as a by-value struct, the compiler loads all of FmmArgs into ~60 scalar registers at entry and keeps them alive across the
+// marching loop; with the loop's own lane masks that is more than the 102 a wavefront has, and the spill code reloaded a whole
+// 16-register tuple of arguments from VGPR lanes in EVERY pop (23 v_readlane_b32 of 380 VALU instructions per pop, each a
+// four-cycle issue slot: profiles/r5_fmm_phase_split.md).  Behind the laundered pointer an argument is one s_load_dword where it is
+// used (scalar memory, no VALU slot), and nothing but the pointer is alive across a march.
+using FmmArgP = const __attribute__((address_space(4))) FmmArgs *;
+__device__ __forceinline__ FmmArgP arg_launder(FmmArgP p) {
+  int z;   // a zero the compiler cannot fold, made wavefront-uniform again (the result of an asm counts as divergent)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return (FmmArgP)((const __attribute__((address_space(4))) char *)p + __builtin_amdgcn_readfirstlane(z));
+}
+#ifdef DZ_FMM_ARGS_BYVALUE   // experiment: the round-4 form
+#define FMM_ARGS_DECL(A_)
+#define FMM_ARGS_FRESH
+#else
+#define FMM_ARGS_DECL(A_) FmmArgP Ap = arg_launder((FmmArgP)__builtin_amdgcn_kernarg_segment_ptr())
+#define FMM_ARGS_FRESH Ap = arg_launder(Ap)
+#endif
 template <int CAP, bool SPILL, class NT, bool HYB, int GPL = 16>
-__global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
+__global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
+#ifdef DZ_FMM_ARGS_BYVALUE
+  const FmmArgs &A = A_;
+#else
+  FMM_ARGS_DECL(A_);
+#define A (*Ap)
+#endif
   constexpr int GP = GPL, FPW = 64 / GPL;   // lanes per field, fields per wavefront (these shadow the 16-lane constants above)
   __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
   __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
@@ -1075,7 +1105,9 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   // loop, idle between fields): the kernel's LDS is exactly the heaps, so five 32 KB workgroups of the hybrid heap fill 160 KB
   unsigned &s_base = *reinterpret_cast<unsigned *>(&s_keys[0][0]);
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
-  const dazim_geom g = A.g;
+  dazim_geom g;   // (member by member: the arguments live in the constant address space)
+  g.nvx = A.g.nvx; g.nvz = A.g.nvz; g.nnx = A.g.nnx; g.nnz = A.g.nnz;
+  g.gox = A.g.gox; g.goz = A.g.goz; g.dnx = A.g.dnx; g.dnz = A.g.dnz; g.dvx = A.g.dvx; g.dvz = A.g.dvz;
   const int nnx = g.nnx, nnz = g.nnz, nn = nnx * nnz;
   const int tsh_c = tile_shift(nnz), nrec_c = tile_records(nnx, nnz);
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
@@ -1108,6 +1140,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
   const unsigned nquad = ((unsigned)A.nfield + fpw - 1) / fpw;
   int chunk = (int)(blockIdx.x & 7);
   for (;;) {
+    FMM_ARGS_FRESH;
     __syncthreads();
     if (lane == 0) {
       unsigned found = 0xffffffffu;
@@ -1166,6 +1199,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         cbar();
         const bool ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
                                                             stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
+        FMM_ARGS_FRESH;
         cbar();
         if (ovf) {
           if (gl == 0) { A.status[f] = -2; A.ts_nodes[(size_t)q * CAP] = -1; }
@@ -1296,6 +1330,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
         bool ovf = march<CAP, SPILL, NT, HYB, true, GPL>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
+        FMM_ARGS_FRESH;
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
         {
@@ -1387,6 +1422,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
           if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
         if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
+        FMM_ARGS_FRESH;
         cbar();
         if (ovf) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
@@ -1409,6 +1445,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A) {
       if (lane == 0) __hip_atomic_store(A.ts_flag + fbase / fpw, (unsigned)stage + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#undef A
 }
 
 
