@@ -168,6 +168,21 @@ constexpr int FPW = 4;   // fields per wavefront
 // whenever the predicate is a combination of lane masks); the builtin takes the lane mask as it stands.
 __device__ __forceinline__ unsigned long long wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// Lane masks (round 5).  A ballot of anything but a plain comparison -- a && b, a loop-carried flag, a flag set under a branch -- is
+// compiled as v_cndmask 0/1 + v_cmp_ne (two four-cycle VALU slots), 17 times per pop in the round-4 loop.  The marching loop
+// therefore forms such masks from the ballots of the plain comparisons with scalar and / or / andn2 (free: the scalar unit), and
+// turns a mask back into a per-lane predicate with the inverse ballot (no instruction at all).  ~m may set bits of inactive
+// lanes; every mask that is tested or shifted has at least one un-negated ballot factor, which is zero there.
+using lmask = unsigned long long;
+__device__ __forceinline__ bool lanes(lmask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+// min with the lane's xor-1 / xor-2 partner in ONE instruction (v_min_*_dpp; fminf() through a v_mov_dpp costs the move, two
+// canonicalising v_max and the v_min).  IEEE mode: a quiet NaN operand gives the other operand, like fminf; arithmetic cannot
+// produce a signalling one.  s_nop 1 = the two wait states a DPP read needs after the VALU write of its source.
+__device__ __forceinline__ float fmin_xor1(float v) { float r; asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ float fmin_xor2(float v) { float r; asm("s_nop 1\n\tv_min_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ int imin_xor1(int v) { int r; asm("s_nop 1\n\tv_min_i32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v)); return r; }
+__device__ __forceinline__ int imin_xor2(int v) { int r; asm("s_nop 1\n\tv_min_i32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(r) : "v"(v)); return r; }
+
 __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // compiler-only barrier:
 // same-wave LDS/VMEM operations execute in program order, so no s_waitcnt is needed for lane 0's
 // stores to be seen by the group's later loads.
@@ -462,10 +477,11 @@ struct Heap {
     unsigned A = G | (1u << (q - 1));
     if (gl == GP - 1) A = 1u << GP;                        // the idle lane never matches (lt is cut to GP bits)
     int p = 1;
-    bool active = true, deep = false;
+    lmask actm = ~0ull, deepm = 0;                        // lanes of the groups that go on sifting / whose hole has children in HBM
 #pragma unroll
     for (int b = 0; b < NSTEP; b++) {
-      if (b > 0 && wballot(active) == 0) break;          // wave-uniform: no group of this wavefront goes deeper
+      if (b > 0 && actm == 0) break;                      // wave-uniform: no group of this wavefront goes deeper
+      const bool active = b == 0 || lanes(actm);
       // straight-line code: lanes with nothing to read use the pair at slot 0 (slot 0 is never a heap entry, slot 1 is only
       // read), lanes with nothing to move write their entry to slot 0
       const int s = (p << dq) + oq;                        // this lane's parent slot
@@ -491,21 +507,25 @@ struct Heap {
       const unsigned long long gtm = wballot(right);
       const unsigned long long ltm = wballot(ck < mvk);
       const unsigned gt = (unsigned)(gtm >> gsh), lt = (unsigned)(ltm >> gsh) & GMASK;
-      const bool mine = (gt & G) == E && (lt & A) == A;    // (an inactive group has ck = +inf everywhere: nobody moves)
+      const lmask minem = wballot((gt & G) == E) & wballot((lt & A) == A);   // (an inactive group has ck = +inf everywhere: nobody moves)
+      const bool mine = lanes(minem);
       const int dst = mine ? s : 0;
       keys[dst] = ck;
       nodes[dst] = (NT)cn;
-      const unsigned mb = (unsigned)(wballot(mine) >> gsh) & GMASK;   // <= one lane per level, levels 1..nm
+      const unsigned mb = (unsigned)(minem >> gsh) & GMASK;   // <= one lane per level, levels 1..nm
+      // (the flags of the next step as ballots of comparisons made in THIS block: a flag set under the branch below would come back
+      // as a 0 / 1 integer.)  The hole went down all LV levels <=> a parent of the subtree's last level moved its child up
+      constexpr unsigned LASTLV = ((1u << (GP - 1)) - 1u) & ~((1u << (GP / 2 - 1)) - 1u);
+      const lmask mvd = wballot(mb != 0), full = wballot((mb & LASTLV) != 0);
       if (mb != 0) {
         const int qs = 32 - __clz(mb);                    // deepest parent whose child moved up: the hole is at that child now
         const int rt = 2 * qs + (int)((gt >> (qs - 1)) & 1u);
         const int dt = 31 - __clz(rt);
         p = (p << dt) + rt - (1 << dt);
-        active = dt == LV && 2 * p <= ntr;
-        if (HYB) deep = p >= CAP / 2 && 2 * p <= ntr;     // on the last LDS level, with children: they are in HBM
-      } else {
-        active = false;
       }
+      const lmask kids = wballot(2 * p <= ntr);
+      actm = full & kids;
+      if (HYB) deepm = (deepm & ~mvd) | (mvd & kids & wballot(p >= CAP / 2));   // on the last LDS level, with children: they are in HBM
     }
     if (HYB) {
       // the hole reached the last level of the LDS part and has children: they live in HBM.  One sequential step of downtree
@@ -515,8 +535,9 @@ struct Heap {
       // entries in the HBM levels are exact -- march() cannot search there.
 #pragma unroll
       for (int h = 0; h < NH; h++) {
-        if (wballot(deep) == 0) break;
-        if (deep) {
+        if (deepm == 0) break;
+        int again = 0;
+        if (lanes(deepm)) {
           const HEnt *ch = ovf + (2 * p - CAP);
           const HEnt c0 = ch[0];
           HEnt c1 = HEnt{INFINITY, 0};
@@ -524,7 +545,6 @@ struct Heap {
           const bool right = c0.key > c1.key;
           const float ck = right ? c1.key : c0.key;
           const int cn = right ? c1.node : c0.node;
-          deep = false;
           if (ck < mvk) {
             if (h == 0) {
               keys[p] = ck;
@@ -534,9 +554,10 @@ struct Heap {
               set_slot((unsigned)cn, p);
             }
             p = 2 * p + (right ? 1 : 0);
-            deep = NH > h + 1 && 2 * p <= ntr;
+            again = (NH > h + 1 && 2 * p <= ntr) ? 1 : 0;
           }
         }
+        deepm = NH > h + 1 ? wballot(again != 0) : 0;
       }
     }
     const bool phi = HYB && p >= CAP;
@@ -584,7 +605,7 @@ struct Heap {
 // (`fast` false: the compiler's sequences).  Division by three: q = RN(x / 3), then one residual step -- equal to x / 3.0f for every
 // finite float (2^32 cases, tools/check_div3.c).  Square root: v_sqrt_f32 is within one ulp; the two residual tests pick the
 // correctly rounded neighbour (the compiler's own sequence minus its rescaling of arguments below 2^-96 and its class test).
-__device__ __forceinline__ float div_exact(float x, float y, bool fast) {
+__device__ __forceinline__ float div_exact(float x, float y, int fast) {
   if (!fast) return x / y;
   float r = __builtin_amdgcn_rcpf(y);
   const float e = __builtin_fmaf(-y, r, 1.0f);
@@ -600,7 +621,7 @@ __device__ __forceinline__ float div3_exact(float x) {
   const float q = x * third;
   return __builtin_fmaf(__builtin_fmaf(-3.0f, q, x), third, q);
 }
-__device__ __forceinline__ float sqrt_exact(float x, bool fast) {
+__device__ __forceinline__ float sqrt_exact(float x, int fast) {
   if (!fast) return sqrtf(x);
   const float s = __builtin_amdgcn_sqrtf(x);
   const float sm = __int_as_float(__float_as_int(s) - 1), sp = __int_as_float(__float_as_int(s) + 1);
@@ -612,7 +633,7 @@ __device__ __forceinline__ float sqrt_exact(float x, bool fast) {
 
 // tj, tj2, tk, tk2: the words of the four nodes read as floats (the time, when the node is alive); aj .. ak2: alive and inside the grid
 __device__ __forceinline__ float quadrant_time(float slown, float risti, float dnx, float dnz, float tj, float tj2, float tk,
-                                               float tk2, bool aj, bool aj2, bool ak, bool ak2, bool fast) {
+                                               float tk2, bool aj, bool aj2, bool ak, bool ak2, int fast) {
   const float ri = EARTH;
   const bool so2j = aj2 && aj && tj > tj2;
   const bool so2k = ak2 && ak && tk > tk2;
@@ -634,7 +655,9 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   const float c2 = uu * (em * em - ss * vv);
   const float tref2 = both2 ? X2 : (so2j ? tk : tj);
   // ---- one-sided ----
-  const bool so1 = onlyj ? so2j : so2k;
+  // so1 = onlyj ? so2j : so2k.  Only used when exactly one direction is alive, and then the other direction's flag is false anyway
+  // (so2j needs aj, so2k needs ak): an OR, where a select between two predicates would go through 0 / 1 integers
+  const bool so1 = so2j || so2k;
   const float u1 = onlyj ? U2 : V2;
   const float c1s = -(u1 * u1) * ss;
   const float c1f = (-ss * (onlyj ? ri * ri : risti * risti)) * (onlyj ? dnx * dnx : dnz * dnz);
@@ -643,7 +666,7 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   // ---- common tail ----
   const float a = two ? a2 : 1.0f, b = two ? b2 : 0.0f, c = two ? c2 : c1;
   const float tref = two ? tref2 : tref1;
-  const bool third = two ? both2 : so1;            // tdiv = 3 (else 1)
+  const bool third = both2 || (!two && so1);       // two ? both2 : so1 -- tdiv = 3 (else 1)
   float rd1 = b * b - 4.0f * a * c;
   if (rd1 < 0.0f) rd1 = 0.0f;
   const float tdsh = div_exact(-b + sqrt_exact(rd1, fast), 2.0f * a, fast);
@@ -684,7 +707,7 @@ __device__ unsigned long long g_fmm_prof[8];
 template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED, int GPL>
 __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const float *__restrict__ slow,
                                       const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
-                                      int ex, int lane, bool fastm, int maxpop = 0x7fffffff) {
+                                      int ex, int lane, int fastm, int maxpop = 0x7fffffff) {
   // Lanes of a field's group: 16 = 4 neighbours x 4 quadrants (jd, kd); 8 = 4 neighbours x 2 (jd), each lane solving the
   // quadrants kd = -1 and kd = +1 one after the other (eight fields per wavefront: the per-pop bookkeeping is shared by twice the
   // fields)
@@ -799,6 +822,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       // (the entries the sift-down moved UP get no store, see below; the dropped entry moved down and gets one)
       if (H.g0 && fin_slot > 0) H.set_slot((unsigned)fin_node, fin_slot);
     }
+    const lmask fslotm = wballot(fin_slot > 0);            // (ballots are taken in the block that makes the comparison, see lanes())
     // status of the neighbour: -1 far, 0 alive / outside, > 0 heap slot.  A word that is not alive has its sign bit set, and its low
     // 31 bits sign-extended are the status: 0xffffffff -> -1, 0x80000000 | slot -> slot
     const bool nopen = nvalid && !w_is_alive(wself);
@@ -816,6 +840,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
     // (the reads go out here and are looked at after the quadrant solve: their latency hides behind it)
     const int srec = stfix;
     const bool band = srec > 0;
+    const lmask bandm = wballot(srec > 0);
     constexpr int LEV = 31 - __builtin_clz((unsigned)(TOT - 1));   // deepest level of the heap (root = level 0)
     constexpr int LT = LEV / 4 + 1;
     int lz_id0 = 0, lz_id1 = 0;
@@ -841,8 +866,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
                               __int_as_float((int)wk2p), aj, aj2, akp, ak2p, fastm);
       trav = fminf(trav, travp);
     }
-    trav = fminf(trav, dpp_f<DPP_XOR1>(trav));
-    if constexpr (GPL == 16) trav = fminf(trav, dpp_f<DPP_XOR2>(trav));
+    trav = fmin_xor1(trav);
+    if constexpr (GPL == 16) trav = fmin_xor2(trav);
     if (LAZY) {   // the true slot of a band neighbour (lazy back-pointers, above)
       int found = 64;
       {
@@ -852,14 +877,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
           if (lz_ok(a >> 1) && lz_id1 == (int)uself) found = k0 + 1;
         if (lz_ok(a) && lz_id0 == (int)uself) found = k0;
       }
-      { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
-      if constexpr (GPL == 16) { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
-      const bool isdrop = (int)uself == fin_node && fin_slot > 0;
+      found = imin_xor1(found);
+      if constexpr (GPL == 16) found = imin_xor2(found);
+      const lmask dropm = wballot((int)uself == fin_node) & fslotm;
+      const bool isdrop = lanes(dropm);
 #ifdef DZ_FMM_LAZYSTAT   // experiment build: how often the first four ancestors do not hold the entry (lanes), and pops
       if (q == 0 && band) atomicAdd(&g_lazy_stat[found == 64 && !isdrop ? 1 : 0], 1ull);
       if (q == 0 && band && isdrop) atomicAdd(&g_lazy_stat[2], 1ull);
 #endif
-      if (wballot(band && found == 64 && !isdrop) != 0) {   // (wave-uniform, rare) the higher ancestors
+      if ((bandm & wballot(found == 64) & ~dropm) != 0) {   // (wave-uniform, rare) the higher ancestors
 #pragma unroll
         for (int t = 1; t < LT; t++) {
 #pragma unroll
@@ -871,11 +897,11 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
             if (ok && id == (int)uself) found = found < k ? found : k;
           }
         }
-        { const int o = dpp_i<DPP_XOR1>(found); found = found < o ? found : o; }
-        if constexpr (GPL == 16) { const int o = dpp_i<DPP_XOR2>(found); found = found < o ? found : o; }
+        found = imin_xor1(found);
+        if constexpr (GPL == 16) found = imin_xor2(found);
       }
       if (band) {
-        if ((int)uself == fin_node && fin_slot > 0) stfix = fin_slot;
+        if (isdrop) stfix = fin_slot;
         else if (found < 64) stfix = srec >> found;        // (else, hybrid heap: still at srec in the HBM level)
         // (... unless THIS pop's sift-down took it from the lower HBM level up to the upper one: the word was loaded before)
         else if (HYB && Heap<CAP, SPILL, NT, HYB, GPL>::NH > 1 && srec >= 2 * CAP && srec == fin_slot) stfix = srec >> 1;
@@ -891,12 +917,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       // lie at the far side of the band), so the four addtree/updtree calls reduce to independent writes,
       // done by the owner lanes.  A parent that is itself an earlier neighbour (m < nb) is compared with
       // its new key, as the sequential order would.  Any rise in the group -> the sequential code below.
+      constexpr lmask OWN64 = GPL == 16 ? 0x1111111111111111ull : 0x5555555555555555ull;   // the owner lanes (q == 0)
       const bool owner = q == 0;
       const bool act = stfix != 0, isnew = stfix < 0;          // (stfix: the neighbour's true slot, resolved above)
-      const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & OWNERS;
+      const lmask actm = wballot(stfix != 0), ownact = OWN64 & actm;
+      const unsigned newb = (unsigned)((wballot(stfix < 0) & OWN64) >> gbase) & GMASK;
       const int cnt = __popc(newb);
       const int c = isnew ? H.ntr + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
-      const bool room = H.ntr + cnt < TOT;
+      const lmask roomm = wballot(H.ntr + cnt < TOT);
+      const bool room = lanes(roomm);
       const int pc = c >> 1;
       constexpr int NH = Heap<CAP, SPILL, NT, HYB, GPL>::NH;
       const bool pchi = HYB && NH > 1 && act && room && pc >= CAP;   // (two HBM levels: the parent of a slot of the lower one)
@@ -919,8 +948,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       if (nb > 0 && pc == c0) pk = t0;
       if (nb > 1 && pc == c1) pk = t1;
       if (nb > 2 && pc == c2) pk = t2;
-      const bool rise = owner && act && c > 1 && trav < pk;
-      const unsigned riseb = (unsigned)(wballot(rise) >> gbase) & GMASK;
+      const lmask risem = ownact & wballot(c > 1) & wballot(trav < pk);
+      const bool rise = lanes(risem);
+      const unsigned riseb = (unsigned)(risem >> gbase) & GMASK;
       // neighbours before the first rising one (n < n0) are written directly; from n0 on, sequentially
       n0 = !room ? 0 : (riseb ? (__builtin_ctz(riseb) / NBL) : 4);
       // One-level rise in place (round 3).  41 % of the wave-pops have a rising entry in some group, and in 92 % of those every
@@ -933,22 +963,27 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       //     against the array as it was, are then the ones the sequential order makes (neighbours before r see r's old
       //     entry, neighbours after r see slots r did not touch), and r's own comparisons see no slot an earlier neighbour wrote;
       //   * (hybrid heap) the riser's slot lies in the LDS part.
-      bool f2 = false;
-      if (wballot(riseb != 0u && room) != 0) {            // wave-uniform: some group has a rising entry
+      lmask f2m = 0;
+      const lmask anyrise = wballot(riseb != 0u) & roomm;
+      if (anyrise != 0) {                                  // wave-uniform: some group has a rising entry
         const int c3 = own_i<GPL, 3>(cact);
         const int nbr = __builtin_ctz(riseb | (1u << GPL)) / NBL;
         const int cr = nbr == 0 ? c0 : (nbr == 1 ? c1 : (nbr == 2 ? c2 : c3));
         const int pr = cr >> 1, gr = cr >> 2;
-        const bool okr = rise && !(gp >= 1 && trav < gk) && (!HYB || c < CAP);
-        const bool clash = owner && act && !rise && (c == pr || c == gr || pc == cr || pc == pr);
-        const unsigned okb = (unsigned)(wballot(okr) >> gbase) & GMASK;
-        const unsigned clb = (unsigned)(wballot(clash) >> gbase) & GMASK;
-        f2 = room && riseb != 0u && (riseb & (riseb - 1u)) == 0u && okb == riseb && clb == 0u;
-        if (f2) n0 = 4;
+        // okr = rise && !(gp >= 1 && trav < gk) && (!HYB || c < CAP);  clash = owner && act && !rise && (c == pr || c == gr || pc == cr || pc == pr)
+        lmask okm = risem & ~(wballot(gp >= 1) & wballot(trav < gk));
+        if (HYB) okm &= wballot(c < CAP);
+        const lmask clm = ownact & ~risem & (wballot(c == pr) | wballot(c == gr) | wballot(pc == cr) | wballot(pc == pr));
+        const unsigned okb = (unsigned)(okm >> gbase) & GMASK;
+        const unsigned clb = (unsigned)(clm >> gbase) & GMASK;
+        // f2 = room && riseb != 0 && exactly one riser && okb == riseb && clb == 0
+        f2m = anyrise & wballot(((riseb & (riseb - 1u)) | (okb ^ riseb) | clb) == 0u);
+        if (lanes(f2m)) n0 = 4;
       }
       fast = n0 == 4;
-      if (wballot(f2 && rise) != 0) {                     // the risers: entry to the parent's slot, parent down to the entry's
-        if (f2 && rise) {
+      const lmask f2rise = f2m & risem;
+      if (f2rise != 0) {                                   // the risers: entry to the parent's slot, parent down to the entry's
+        if (lanes(f2rise)) {
           H.keys[pc] = trav;
           H.nodes[pc] = (NT)uself;
           recw[uself] = w_band(pc);
@@ -958,14 +993,15 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
         }
       }
       {
-        const bool wr = owner && act && nb < n0 && !(f2 && rise);
-        const bool whi = HYB && wr && c >= CAP;            // (HYB) the entry's slot lies in the HBM level
-        const int dst = (wr && !whi) ? c : 0;              // slot 0 is never a heap entry
+        const lmask wrm = ownact & wballot(nb < n0) & ~f2rise;   // wr = owner && act && nb < n0 && !(f2 && rise)
+        const lmask whim = HYB ? (wrm & wballot(c >= CAP)) : 0;   // (HYB) the entry's slot lies in the HBM level
+        const bool wr = lanes(wrm);
+        const int dst = lanes(wrm & ~whim) ? c : 0;        // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
         if (wr) recw[uself] = w_band(c);
-        if (HYB && wballot(whi) != 0) {
-          if (whi) H.ovf[c - CAP] = HEnt{trav, (int)uself};
+        if (HYB && whim != 0) {
+          if (lanes(whim)) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
         H.ntr += __popc(newb & ((1u << (NBL * n0)) - 1u));
       }
@@ -1127,7 +1163,8 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   // task's predecessor (same batch, previous stage) was handed out a whole generation earlier and a workgroup only ever
   // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
   // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
-  const bool fastm = A.fastm != 0 && __builtin_amdgcn_readfirstlane(*A.vflag) == 0;
+  // (an integer in a scalar register: a wavefront-uniform bool is still a lane mask to the compiler, and a branch on it costs VALU work)
+  const int fastm = __builtin_amdgcn_readfirstlane(*A.vflag) == 0 ? A.fastm : 0;
   if (A.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over another kernel's wavefronts on the same SIMD (see run_fmm)
   const int nstage = SPILL ? 1 : A.ts_nstage;
   const bool ts = nstage > 1;

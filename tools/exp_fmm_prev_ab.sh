@@ -1,0 +1,8 @@
+#!/bin/bash
+# same-box A/B of the eikonal kernel against a previous fmm.hip kept as tools/experiments/fmm_prev.hip.txt (3 runs each, interleaved)
+cp tools/experiments/fmm_prev.hip.txt /tmp/fmm_prev.hip
+bash tools/build_alt.sh /tmp/fmm_prev.hip /tmp/libdazim_prev.so "-I$PWD/include" > /dev/null 2>&1 || echo "alt build failed"
+for rep in 1 2 3; do
+  echo -n "[prev] "; DAZIM_LIB=/tmp/libdazim_prev.so python tools/fmm_only.py ${SRC:-1000} 1 2>&1 | grep kernel | awk '{print $7, $8, $9}'
+  echo -n "[new]  "; python tools/fmm_only.py ${SRC:-1000} 1 2>&1 | grep kernel | awk '{print $7, $8, $9}'
+done
