@@ -55,8 +55,9 @@ struct FmmArgs {
   int nfield, kmax;
   const double *pv;
   const float *veln;  // [kmax][nnx][nnz]
-  const float *slown; // [kmax][tiled nnx x nnz]  1/veln (the slown = 1.0/vel of fouds2 :583, one IEEE division per node instead of
-                      // one per update), in the same 4 x 4 tiles as the node records: one index serves both
+  const float2 *slown; // [kmax][tiled nnx x nnz]  {1/veln, EARTH*sin(colatitude of the node's column)}: the slown = 1.0/vel of fouds2 :583
+                      // (one IEEE division per node instead of one per update) and its risti (:585), in the same 4 x 4 tiles as the
+                      // node records -- one index and one 8-byte load serve both (round 5; risti used to be a table look-up by column)
   const float *scx, *scz;
   const int *period;
   const float *risti_c;  // [nnx]       EARTH*sin(gox+(ix-1)*dnx)
@@ -68,7 +69,7 @@ struct FmmArgs {
   unsigned *rec_c;   // [nwg][tiled nnx x nnz] node words of the coarse grid (see w_alive ...)
   unsigned *rec_r;   // [nwg][tiled RM x RM] node words of the refined grid
   float *velnr;  // [nwg][RM*RM]
-  float *slownr; // [nwg][tiled RM x RM]  1/velnr
+  float2 *slownr; // [nwg][tiled RM x RM]  {1/velnr, risti} of the refined grid
   HEnt *ovf;     // [nwg][ovfcap]
   int ovfcap;
   unsigned *counter;
@@ -121,7 +122,8 @@ constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 33 792 re
 // convex combinations of the pv values (the cubic B-spline weights are non-negative and sum to one)
 constexpr float FAST_VMIN = 0.125f, FAST_VMAX = 16.0f, FAST_STEP_MIN = 2.0f, FAST_STEP_MAX = 4096.0f;
 __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict__ pv,
-                               float *__restrict__ veln, float *__restrict__ slown, int *__restrict__ vflag) {
+                               float *__restrict__ veln, float2 *__restrict__ slown, const float *__restrict__ risti_c,
+                               int *__restrict__ vflag) {
   const int nn = g.nnx * g.nnz;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= nn * kmax) return;
@@ -152,7 +154,7 @@ __global__ void gridder_kernel(dazim_geom g, int kmax, const double *__restrict_
   }
   if (bad) *vflag = 1;
   veln[tid] = sumi;
-  slown[(size_t)k * tile_records(g.nnx, g.nnz) + tile_x(stx - 1, tile_shift(g.nnz)) + tile_z(stz - 1)] = 1.0f / sumi;   // 4 x 4 tiles
+  slown[(size_t)k * tile_records(g.nnx, g.nnz) + tile_x(stx - 1, tile_shift(g.nnz)) + tile_z(stz - 1)] = make_float2(1.0f / sumi, risti_c[stx - 1]);   // 4 x 4 tiles
 }
 
 // ---- narrow-band heap (addtree/downtree/updtree, inv/CalSurfG.f90:738-891) -------------------
@@ -229,6 +231,15 @@ struct Heap {
   // LDS, levels 10 and 11 in HBM; above that levels 1-10 in LDS, 11 and 12 in HBM -- see run_fmm's dispatch)
   static constexpr int NH = (HYB && (sizeof(NT) == 4 || CAP <= 256)) ? 2 : 1;
   static constexpr int TOT = HYB ? (CAP << NH) : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
+  // interior-root table of march(): kernels whose LDS has 288 bytes to spare without losing a workgroup per CU (16-bit node ids,
+  // whose record-index differences fit 16 bits)
+#ifdef DZ_FMM_NOTAB   // experiment: the coordinate path for every root
+  static constexpr bool TAB = false;
+#else
+  static constexpr bool TAB = !SPILL && GPL == 16 && sizeof(NT) == 2;
+#endif
+  short *tab;   // [144] the wavefront's table (16-bit: the S-256 form must stay within 12 800 bytes of LDS -- allocation comes in
+                // 1 280-byte granules on this chip, and with 12 864 bytes a CU held eleven workgroups instead of twelve, -6 %)
   float *keys;  // this group's [CAP] keys (slot 0 unused)
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
@@ -705,8 +716,8 @@ __device__ unsigned long long g_fmm_prof[8];
 // REFINED: urg=1 early-exit rule on the edges flagged in `ex` (bit0 x=1, bit1 x=nnx, bit2 z=1,
 // bit3 z=nnz).
 template <int CAP, bool SPILL, class NT, bool HYB, bool REFINED, int GPL>
-__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const float *__restrict__ slow,
-                                      const float *__restrict__ risti_tab, int nnx, int nnz, float dnx, float dnz,
+__device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const float2 *__restrict__ slow,
+                                      int nnx, int nnz, float dnx, float dnz,
                                       int ex, int lane, int fastm, int maxpop = 0x7fffffff) {
   // Lanes of a field's group: 16 = 4 neighbours x 4 quadrants (jd, kd); 8 = 4 neighbours x 2 (jd), each lane solving the
   // quadrants kd = -1 and kd = +1 one after the other (eight fields per wavefront: the per-pop bookkeeping is shared by twice the
@@ -726,6 +737,35 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
   // the hybrid heap of the 342..682-node grids too (S-512: 6 790 -> 7 530 fields/s in a same-box A/B, bit-identical; an entry of
   // the HBM level that moves up into LDS is found one level above the slot its word holds, one that stays is not found and keeps it)
   constexpr bool LAZY = !SPILL;
+  // the interior-root table (see the loop): record-index differences by lane class and coordinate residue
+  constexpr bool TAB = Heap<CAP, SPILL, NT, HYB, GPL>::TAB;
+  const bool tab_ok = TAB && nnx >= 8 && nnz >= 8;
+  const unsigned XMASK = ~((1u << tsh) - 1u) | 0xCu, ZMASK = ((1u << tsh) - 1u) & ~0xCu;   // the x and z bits of a record index
+  // (both parts are monotone in their coordinate: one unsigned range test each; a grid too small to have an interior never passes)
+  const unsigned xlo = tab_ok ? (unsigned)tile_x(3, tsh) : 0xffffffffu, xspan = tab_ok ? (unsigned)tile_x(nnx - 4, tsh) - xlo : 0u;
+  const unsigned zlo = (unsigned)tile_z(3), zspan = tab_ok ? (unsigned)tile_z(nnz - 4) - zlo : 0u;
+  const short *xt = nullptr, *zt = nullptr;
+  if constexpr (TAB) {
+    short *tab = H.tab;
+    cbar();
+    for (int e = gl; e < 48; e += GP) {   // (every group writes the whole table: any of them may be the only one that marches)
+      const int l = e < 24 ? e : e - 24;
+      const int c = l >> 2, m = l & 3, d = (c >> 1) - 1, sg = (c & 1) ? 1 : -1;   // class = (dix or diz, jd or kd), residue
+      const int c0 = 4 + m, cn = c0 + d;
+      if (e < 24) {
+        tab[l] = (short)(tile_x(cn, tsh) - tile_x(c0, tsh));
+        tab[24 + l] = (short)(tile_x(cn + sg, tsh) - tile_x(cn, tsh));
+        tab[48 + l] = (short)(tile_x(cn + 2 * sg, tsh) - tile_x(cn, tsh));
+      } else {
+        tab[72 + l] = (short)(tile_z(cn) - tile_z(c0));
+        tab[96 + l] = (short)(tile_z(cn + sg) - tile_z(cn));
+        tab[120 + l] = (short)(tile_z(cn + 2 * sg) - tile_z(cn));
+      }
+    }
+    cbar();
+    xt = tab + ((dix + 1) * 2 + (jd > 0 ? 1 : 0)) * 4;
+    zt = tab + 72 + ((diz + 1) * 2 + (kd > 0 ? 1 : 0)) * 4;
+  }
   PROF_DECL;
   int npop = 0;
   while (H.ntr > 0 && !overflow && npop < maxpop) {
@@ -734,56 +774,97 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
     PROF(7);
     const HEnt root = H.get(1);
     const int iroot = root.node;                            // record index of the node being accepted
-    const int ix = rid_x0(iroot, tsh) + 1, iz = rid_z0(iroot, tsh) + 1;
-    if (REFINED) {
-      bool swrg = false;
-      if (ix == 1 && (ex & 1)) swrg = true;
-      if (ix == nnx && (ex & 2)) swrg = true;
-      if (iz == 1 && (ex & 4)) swrg = true;
-      if (iz == nnz && (ex & 8)) swrg = true;
-      if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-        if (H.g0) recw[iroot] = w_alive(root.key);            // (it stays at slot 1 of the heap; its time is its key)
-        if (LAZY)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
-          for (int i = 2 + gl; i <= H.ntr; i += GP) recw[(unsigned)H.get(i).node] = w_band(i);
-        break;
+    const unsigned uroot = (unsigned)iroot;
+    // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
+    // it.  All loads are issued unconditionally (invalid lanes read the root's own record) and
+    // stay in flight while the root is sifted down in LDS. ----
+    unsigned uself, aj_i, aj2_i, ak_i, ak2_i;               // record indices of the neighbour and of the nodes behind it along x and z
+    lmask nvalidm, vjm, vj2m, vkm, vk2m;                     // ... and whether they lie inside the grid
+    bool vkp = false, vk2p = false;
+    unsigned akp_i = uroot, ak2p_i = uroot;                  // (8 lanes per field: the lane's second quadrant, kd = +1)
+    // Interior roots (round 5): a root at least three nodes from every edge has its whole stencil inside the grid, and the record
+    // index of node (x + d) differs from that of node x by an amount that depends on x & 3 and d alone (4 x 4 tiles).  Those
+    // differences sit in a 288-byte LDS table per wavefront (built at the start of the march: 6 lane classes x 4 residues for
+    // each of the three x parts and the three z parts), so the usual pop forms its five indices with six LDS reads and six
+    // additions instead of decoding the root, offsetting, range-testing and re-tiling five coordinates (66 -> ~30 VALU
+    // instructions in this phase).  One edge root among the four fields (17 % of the pops of a 256 x 256 grid) sends the wavefront
+    // through the coordinate path.
+    bool interior = false;
+    if constexpr (TAB) {
+      const lmask inm = wballot(((uroot & XMASK) - xlo) <= xspan) & wballot(((uroot & ZMASK) - zlo) <= zspan);
+      interior = inm == wballot(true);
+    }
+    if (TAB && interior) {
+      const short *xa = xt + ((uroot >> 2) & 3u), *za = zt + (uroot & 3u);
+      const int dnx_ = xa[0], dj_ = xa[24], dj2_ = xa[48];
+      const int dnz_ = za[0], dk_ = za[24], dk2_ = za[48];
+      uself = uroot + (unsigned)dnx_ + (unsigned)dnz_;
+      aj_i = uself + (unsigned)dj_;
+      aj2_i = uself + (unsigned)dj2_;
+      ak_i = uself + (unsigned)dk_;
+      ak2_i = uself + (unsigned)dk2_;
+      nvalidm = vjm = vj2m = vkm = vk2m = ~0ull;
+    } else {
+      const int ix = rid_x0(iroot, tsh) + 1, iz = rid_z0(iroot, tsh) + 1;
+      if (REFINED) {
+        bool swrg = false;
+        if (ix == 1 && (ex & 1)) swrg = true;
+        if (ix == nnx && (ex & 2)) swrg = true;
+        if (iz == 1 && (ex & 4)) swrg = true;
+        if (iz == nnz && (ex & 8)) swrg = true;
+        if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
+          if (H.g0) recw[iroot] = w_alive(root.key);            // (it stays at slot 1 of the heap; its time is its key)
+          if (LAZY)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
+            for (int i = 2 + gl; i <= H.ntr; i += GP) recw[(unsigned)H.get(i).node] = w_band(i);
+          break;
+        }
+      }
+      const int nix = ix + dix, niz = iz + diz;
+      // 0-based coordinates and one unsigned comparison per range test ((unsigned)(x) < n  <=>  0 <= x < n)
+      const int nx0 = nix - 1, nz0 = niz - 1;
+      const unsigned unx = (unsigned)nnx, unz = (unsigned)nnz;
+      const bool nvalid = (unsigned)nx0 < unx && (unsigned)nz0 < unz;
+      const int j0 = nx0 + jd, j20 = nx0 + 2 * jd, k0 = nz0 + kd, k20 = nz0 + 2 * kd;
+      const bool vj = nvalid && (unsigned)j0 < unx, vj2 = vj && (unsigned)j20 < unx;
+      const bool vk = nvalid && (unsigned)k0 < unz, vk2 = vk && (unsigned)k20 < unz;
+      // tiled record indices: an X part per column (neighbour, +-1, +-2) and a Z part per row; out-of-grid coordinates give
+      // garbage that the validity flags replace by the root's own record.  Unsigned indices: no sign extension per address.
+      const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
+      const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
+      uself = nvalid ? (unsigned)(xn + zn) : uroot;
+      aj_i = vj ? (unsigned)(xj + zn) : uroot;
+      aj2_i = vj2 ? (unsigned)(xj2 + zn) : uroot;
+      ak_i = vk ? (unsigned)(xn + zk) : uroot;
+      ak2_i = vk2 ? (unsigned)(xn + zk2) : uroot;
+      nvalidm = wballot((unsigned)nx0 < unx) & wballot((unsigned)nz0 < unz);
+      vjm = nvalidm & wballot((unsigned)j0 < unx);
+      vj2m = vjm & wballot((unsigned)j20 < unx);
+      vkm = nvalidm & wballot((unsigned)k0 < unz);
+      vk2m = vkm & wballot((unsigned)k20 < unz);
+      if constexpr (GPL == 8) {
+        const int kp0 = nz0 + 1, kp20 = nz0 + 2;
+        vkp = nvalid && (unsigned)kp0 < unz;
+        vk2p = vkp && (unsigned)kp20 < unz;
+        akp_i = vkp ? (unsigned)(xn + tile_z(kp0)) : uroot;
+        ak2p_i = vk2p ? (unsigned)(xn + tile_z(kp20)) : uroot;
       }
     }
+    const bool nvalid = lanes(nvalidm), vj = lanes(vjm), vj2 = lanes(vj2m), vk = lanes(vkm), vk2 = lanes(vk2m);
     if (H.g0) recw[iroot] = w_alive(root.key);              // accepted: the word becomes the time (= the heap key, the trial time)
     cbar();
-    // ---- stencil loads first: lane (nb,q) of the group reads its neighbour and the 4 nodes behind
-    // it.  All seven loads are issued unconditionally (invalid lanes read the root's own record) and
-    // stay in flight while the root is sifted down in LDS. ----
-    const int nix = ix + dix, niz = iz + diz;
-    // 0-based coordinates and one unsigned comparison per range test ((unsigned)(x) < n  <=>  0 <= x < n)
-    const int nx0 = nix - 1, nz0 = niz - 1;
-    const unsigned unx = (unsigned)nnx, unz = (unsigned)nnz;
-    const bool nvalid = (unsigned)nx0 < unx && (unsigned)nz0 < unz;
-    const int j0 = nx0 + jd, j20 = nx0 + 2 * jd, k0 = nz0 + kd, k20 = nz0 + 2 * kd;
-    const bool vj = nvalid && (unsigned)j0 < unx, vj2 = vj && (unsigned)j20 < unx;
-    const bool vk = nvalid && (unsigned)k0 < unz, vk2 = vk && (unsigned)k20 < unz;
-    // tiled record indices: an X part per column (neighbour, +-1, +-2) and a Z part per row; out-of-grid coordinates give
-    // garbage that the validity flags replace by the root's own record.  Unsigned indices: no sign extension per address.
-    const int xn = tile_x(nx0, tsh), xj = tile_x(j0, tsh), xj2 = tile_x(j20, tsh);
-    const int zn = tile_z(nz0), zk = tile_z(k0), zk2 = tile_z(k20);
-    const unsigned uroot = (unsigned)iroot, uself = nvalid ? (unsigned)(xn + zn) : uroot;
     // (the node words as they are: an alive node's word is its time, sign bit clear; see w_alive)
     unsigned wself = recw[uself];
-    unsigned wj = recw[vj ? (unsigned)(xj + zn) : uroot];
-    unsigned wj2 = recw[vj2 ? (unsigned)(xj2 + zn) : uroot];
-    unsigned wk = recw[vk ? (unsigned)(xn + zk) : uroot];
-    unsigned wk2 = recw[vk2 ? (unsigned)(xn + zk2) : uroot];
-    // (8 lanes per field: the lane's second quadrant, kd = +1)
-    bool vkp = false, vk2p = false;
+    unsigned wj = recw[aj_i];
+    unsigned wj2 = recw[aj2_i];
+    unsigned wk = recw[ak_i];
+    unsigned wk2 = recw[ak2_i];
     unsigned wkp = 0, wk2p = 0;
     if constexpr (GPL == 8) {
-      const int kp0 = nz0 + 1, kp20 = nz0 + 2;
-      vkp = nvalid && (unsigned)kp0 < unz;
-      vk2p = vkp && (unsigned)kp20 < unz;
-      wkp = recw[vkp ? (unsigned)(xn + tile_z(kp0)) : uroot];
-      wk2p = recw[vk2p ? (unsigned)(xn + tile_z(kp20)) : uroot];
+      wkp = recw[akp_i];
+      wk2p = recw[ak2p_i];
     }
-    const float vel = slow[uself];                          // slowness of the neighbour (1/velocity, precomputed, same tiling)
-    const float risti = risti_tab[(unsigned)(nvalid ? nx0 : ix - 1)];
+    const float2 slri = slow[uself];                        // slowness of the neighbour (1/velocity, precomputed, same tiling) and its risti
+    const float vel = slri.x, risti = slri.y;
     int nbn[4], nbs[4], nbm[4];
     float nbt[4];
     // the four neighbours' record indices, from their owner lanes (nb, q = 0); -1 outside the grid.  Needed before the pop only
@@ -1097,10 +1178,19 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
   return overflow;
 }
 
+// Register budget: the wavefronts per SIMD that the kernel's LDS allows (one wavefront per workgroup, 160 KB per CU, four SIMDs) --
+// the S-256 form (12 864 bytes) fits twelve workgroups per CU only while it stays within 168 registers, and the compiler does not
+// know about that cliff unless it is told.
+template <int CAP, class NT, int GPL, bool TAB>
+constexpr int fmm_waves_per_simd() {
+  const int lds = (64 / GPL) * CAP * (4 + (int)sizeof(NT)) + (TAB ? 288 : 4);
+  const int w = (163840 / ((lds + 1279) / 1280 * 1280)) / 4;
+  return w < 1 ? 1 : (w > 3 ? 3 : w);   // (never fewer than 168 registers: the loop needs ~150-170)
+}
 #ifdef DZ_FMM_WPE   // experiment: register budget for DZ_FMM_WPE wavefronts per SIMD
 #define FMM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(DZ_FMM_WPE, DZ_FMM_WPE)))
 #else
-#define FMM_WPE_ATTR
+#define FMM_WPE_ATTR __attribute__((amdgpu_waves_per_eu(fmm_waves_per_simd<CAP, NT, GPL, Heap<CAP, SPILL, NT, HYB, GPL>::TAB>())))
 #endif
 #ifdef DZ_TS_WAITSTAT   // experiment build: clocks the workgroups spend waiting for the previous stage of their task
 __device__ unsigned long long g_ts_wait[2];
@@ -1139,6 +1229,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   // banks -- measured: no difference, 53.4 k fields/s either way)
   // the queue position is handed to the wavefront through slot 0 of the first field's keys (the dummy slot of the marching
   // loop, idle between fields): the kernel's LDS is exactly the heaps, so five 32 KB workgroups of the hybrid heap fill 160 KB
+  __shared__ short s_tab[Heap<CAP, SPILL, NT, HYB, GPL>::TAB ? 144 : 2];
   unsigned &s_base = *reinterpret_cast<unsigned *>(&s_keys[0][0]);
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   dazim_geom g;   // (member by member: the arguments live in the constant address space)
@@ -1149,11 +1240,12 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   const size_t slot = (size_t)blockIdx.x * FPW + grp;
   unsigned *rec_r = A.rec_r + slot * NREC_R;
   float *velnr = A.velnr + slot * RM * RM;
-  float *slownr = A.slownr + slot * NREC_R;
+  float2 *slownr = A.slownr + slot * NREC_R;
   Heap<CAP, SPILL, NT, HYB, GPL> H;
   H.keys = s_keys[grp];
   H.nodes = s_nodes[grp];
   H.g0 = gl == 0;
+  H.tab = s_tab;
   // Time slicing (round 3, late).  A field is one serial chain of pops and all fields are equally long, so a launch lasts a whole
   // number of rounds of one field's latency at the occupancy of that round: S-256's 16 000 fields on 13 312 resident slots would
   // run one full round and a second one with a fifth of the chip busy.  With ts_nstage > 1 a field is marched in stages that
@@ -1234,7 +1326,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         H.rec = rec_c;
         H.tsh = tsh_c;
         cbar();
-        const bool ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
+        const bool ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
                                                             stage == nstage - 1 ? 0x7fffffff : A.ts_pops);
         FMM_ARGS_FRESH;
         cbar();
@@ -1293,6 +1385,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
 
         // ---- bsplrefine (inv/CalSurfG.f90:1525-1591) + status reset ----
         {
+          const float *risti_rr = A.risti_r + (size_t)(bx.vnl - 1) * RM;   // EARTH*sin(colatitude) of the refined columns of this box
           const int nrxr = GDX * SGDL, nrzr = GDZ * SGDL;
           const int origx = (bx.vnl - 1) * SGDL + 1, origz = (bx.vnt - 1) * SGDL + 1;
           for (int idx = gl; idx < nnxr * RM; idx += GP) {
@@ -1319,7 +1412,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
             const float vr = sum[0] + sum[1] + sum[2] + sum[3];
             velnr[idx] = vr;
             const int ti = tile_x(idm2 - 1, TSH_R) + tile_z(idm1 - 1);
-            slownr[ti] = 1.0f / vr;
+            slownr[ti] = make_float2(1.0f / vr, risti_rr[idm2 - 1]);
             rec_r[ti] = W_FAR;
           }
         }
@@ -1366,7 +1459,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         // compared with the REFINED nnx/nnz, which is what the module variables hold at that point
         const int ex = (bx.vnl != 1 ? 1 : 0) | (bx.vnr != nnxr ? 2 : 0) | (bx.vnt != 1 ? 4 : 0) |
                        (bx.vnb != nnzr ? 8 : 0);
-        bool ovf = march<CAP, SPILL, NT, HYB, true, GPL>(H, slownr, A.risti_r + (size_t)(bx.vnl - 1) * RM, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
+        bool ovf = march<CAP, SPILL, NT, HYB, true, GPL>(H, slownr, nnxr, nnzr, bx.dnxr, bx.dnzr, ex, lane, fastm);
         FMM_ARGS_FRESH;
         cbar();
         // ---- refined outputs (ttnr=ttn, nstsr=nsts, :1246-1247) + reset of the coarse records ----
@@ -1458,7 +1551,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
           }
           if (gl == 0) A.ts_nodes[(size_t)q * CAP] = H.ntr;
         }
-        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, A.risti_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
+        if (!ts && !ovf) ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm);
         FMM_ARGS_FRESH;
         cbar();
         if (ovf) {
@@ -1561,8 +1654,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.rec_r = (unsigned *)p;
   if ((rc = dz_scratch(ctx, "fmm.velnr", (size_t)nslot * nr * 4, &p))) return rc;
   A.velnr = (float *)p;
-  if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * 4, &p))) return rc;
-  A.slownr = (float *)p;
+  if ((rc = dz_scratch(ctx, "fmm.slownr", (size_t)nslot * NREC_R * sizeof(float2), &p))) return rc;
+  A.slownr = (float2 *)p;
   if ((rc = dz_scratch(ctx, "fmm.ovf", nown * A.ovfcap * sizeof(HEnt) + 64, &p))) return rc;
   A.ovf = (HEnt *)p;
   if ((rc = dz_scratch(ctx, "fmm.counter", 256, &p))) return rc;
@@ -1733,8 +1826,8 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     if ((rc = dz_scratch(ctx, "fmm.veln", nn * kmax * 4, &p))) return rc;
     d_veln = (float *)p;
   }
-  if ((rc = dz_scratch(ctx, "fmm.slown", (size_t)tile_records(g.nnx, g.nnz) * kmax * 4, &p))) return rc;
-  float *d_slown = (float *)p;
+  if ((rc = dz_scratch(ctx, "fmm.slown", (size_t)tile_records(g.nnx, g.nnz) * kmax * sizeof(float2), &p))) return rc;
+  float2 *d_slown = (float2 *)p;
   if ((rc = dz_scratch(ctx, "fmm.vflag", 64, &p))) return rc;
   int *d_vflag = (int *)p;
   // the short exact division / square root of the quadrant solve (div_exact): node spacings of 2 .. 4096 km on the coarse grid
@@ -1757,7 +1850,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     DzTimer t(ctx, "gridder");
     const int total = (int)(nn * kmax);
     DZ_HIP(hipMemsetAsync(d_vflag, 0, 4, ctx->stream));
-    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln, d_slown, d_vflag);
+    hipLaunchKernelGGL(gridder_kernel, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, g, kmax, pv.dev, d_veln, d_slown, d_rc, d_vflag);
     DZ_HIP(hipGetLastError());
     t.stop();
   }

@@ -31,7 +31,7 @@ constexpr int ITERS = 4096;   // 16 * 8 * 4096 = 524 288 instructions of the opc
   asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7) OP(8) OP(9) OP(10) OP(11) OP(12) OP(13) OP(14) OP(15)     \
                : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),          \
                  "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])     \
-               : "v"(x), "v"(y) : "vcc", "s20", "s21", "memory")
+               : "v"(x), "v"(y) : "vcc", "scc", "s20", "s21", "s22", "s23", "memory")
 
 #define OP_ADD_F32(i) "v_add_f32 %" #i ", %" #i ", %16\n"
 #define OP_MUL_F32(i) "v_mul_f32 %" #i ", %" #i ", %16\n"
@@ -78,6 +78,14 @@ constexpr int ITERS = 4096;   // 16 * 8 * 4096 = 524 288 instructions of the opc
 #define OP_DS_READ(i) "ds_read_b32 %" #i ", %16\n"
 #define OP_DS_READ64(i) "ds_read_b64 %" #i ", %16\n"
 #define OP_DS_WRITE(i) "ds_write_b32 %16, %" #i "\n"
+#define OP_SAND64(i) "s_and_b64 s[20:21], s[22:23], exec\n"
+#define OP_SNOP(i) "s_nop 0\n"
+#define OP_SWAIT(i) "s_waitcnt lgkmcnt(0)\n"
+#define OP_V4_SALU(i) "v_min_f32 %" #i ", %" #i ", %16\ns_and_b64 s[20:21], s[22:23], exec\n"
+#define OP_V4_SALU2(i) "v_min_f32 %" #i ", %" #i ", %16\ns_and_b64 s[20:21], s[22:23], exec\ns_or_b64 s[22:23], s[20:21], exec\n"
+#define OP_CMP_SAND_CND(i) "v_cmp_lt_f32_e64 s[20:21], %" #i ", %16\ns_and_b64 s[22:23], s[20:21], exec\nv_cndmask_b32_e64 %" #i ", %" #i ", %17, s[22:23]\n"
+#define OP_DEP_ADD(i) "v_add_f32 %0, %0, %16\n"
+#define OP_DEP_MIN(i) "v_min_f32 %0, %0, %16\n"
 #define OP_ADD_MUL_PAIR(i) "v_add_f32 %" #i ", %" #i ", %16\nv_fma_f32 %" #i ", %" #i ", %16, %17\n"
 
 struct Out { unsigned long long ticks; unsigned long long clocks; };
@@ -143,6 +151,14 @@ __global__ __launch_bounds__(1024) void k_stream(Out *out, T seed, int iters) {
       if constexpr (KIND == 41) STREAM16(OP_DS_READ);
       if constexpr (KIND == 42) STREAM16(OP_DS_WRITE);
       if constexpr (KIND == 43) STREAM16(OP_ADD_MUL_PAIR);
+      if constexpr (KIND == 44) STREAM16(OP_SAND64);
+      if constexpr (KIND == 45) STREAM16(OP_SNOP);
+      if constexpr (KIND == 46) STREAM16(OP_SWAIT);
+      if constexpr (KIND == 47) STREAM16(OP_V4_SALU);
+      if constexpr (KIND == 48) STREAM16(OP_V4_SALU2);
+      if constexpr (KIND == 49) STREAM16(OP_CMP_SAND_CND);
+      if constexpr (KIND == 50) STREAM16(OP_DEP_ADD);
+      if constexpr (KIND == 51) STREAM16(OP_DEP_MIN);
     }
   }
   const unsigned long long c1 = __builtin_readcyclecounter();
@@ -197,6 +213,12 @@ int main(int argc, char **argv) {
       {"s_add_u32", 39, false, "SALU"}, {"v_readlane_b32", 40, false, ""},
       {"ds_read_b32", 41, false, "LDS, conflict-free"}, {"ds_write_b32", 42, false, "LDS, conflict-free"},
       {"v_add_f32 + v_fma_f32 (per pair)", 43, false, "2 instructions per count"},
+      {"s_and_b64", 44, false, "SALU"}, {"s_nop 0", 45, false, ""}, {"s_waitcnt lgkmcnt(0) (nothing pending)", 46, false, ""},
+      {"v_min_f32 + s_and_b64 (per pair)", 47, false, "4-cycle VALU + SALU of one wavefront"},
+      {"v_min_f32 + 2 SALU (per triple)", 48, false, ""},
+      {"v_cmp_e64 -> s_and_b64 -> v_cndmask_e64 (per triple, dependent through SGPRs)", 49, false, ""},
+      {"v_add_f32 dependent chain", 50, false, "every instruction needs the previous result"},
+      {"v_min_f32 dependent chain", 51, false, "every instruction needs the previous result"},
   };
   Out *d_out;
   const int maxw = ncu * 16 + 1;
@@ -220,6 +242,7 @@ int main(int argc, char **argv) {
           L32(0) L32(1) L32(2) LU32(3) LU32(4) LU32(5) L32(6) L32(7) L64(8) L64(9) L64(10) L64(11) L64(12) L64(13) L64(14)
           L32(15) L32(16) L32(17) L32(18) LU32(19) LU32(20) LU32(21) LU32(22) LU32(23) LU32(24) LU32(25) LU32(26) LU32(27) LU32(28) LU32(29) LU32(30)
           L32(31) L32(32) L32(33) L32(34) L32(35) L32(36) LU32(37) L32(38) LU32(39) LU32(40) LU32(41) LU32(42) L32(43)
+          LU32(44) LU32(45) LU32(46) L32(47) L32(48) L32(49) L32(50) L32(51)
         }
       };
       launch(64);   // warm-up (code object load, clocks)
