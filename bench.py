@@ -56,7 +56,6 @@ BYTES_PER_FIELD = 256 * 256 * 8 + 129 * 129 * 8   # read veln + write ttn, coars
 # same command by tools/profile_round.sh, which writes profiles/pmc_traffic.json: KiB per dispatch and kernel, the workload, and
 # the hash of the kernel sources it was measured on).  A profile of other sources, or of another workload, is NOT quoted:
 # `traffic` is null then.  FETCH_SIZE of the 16-byte streaming kernels is doubled as MI355X_MICROARCH.md prescribes for gfx950.
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def kernel_source_hash():
@@ -68,9 +67,15 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def counter_file(kind, workload):
+    """profiles/<kind>_<workload>.json: one hash-locked counter pass per workload (tools/profile_round.sh / profile_sq.sh <tag> <workload>)"""
+    return os.path.join(ROOT, "profiles", f"{kind}_{workload}.json")
+
+
 def profiled_traffic(workload, nfield, nnz):
-    """bytes per launch of the eikonal kernel and of the two products from profiles/pmc_traffic.json, or Nones with the reason"""
+    """bytes per launch of the eikonal kernel and of the two products from profiles/pmc_traffic_<workload>.json, or Nones with the reason"""
     none = {"fmm": None, "ax": None, "aty": None}
+    PMC_FILE = counter_file("pmc_traffic", workload)
     try:
         prof = json.load(open(PMC_FILE))
     except Exception as e:
@@ -93,8 +98,16 @@ def profiled_traffic(workload, nfield, nnz):
     return out, os.path.relpath(PMC_FILE, ROOT) + " (" + prof.get("tag", "?") + ")"
 
 
-SQ_FILE = os.path.join(ROOT, "profiles", "sq_counters.json")
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4     # 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction = 614.4 G instructions/s
+# VALU issue peak, MEASURED (round 5: tools/valu_issue_calib.hip -> profiles/r5_valu_issue.md).  A gfx950 SIMD issues a wave64
+# instruction of the "simple" class (v_add/sub/mul_f32, v_add/sub_u32, v_and/or/xor_b32, v_mov_b32, v_fma_f32 with an inline
+# constant) every 2.2-2.5 cycles when at least two wavefronts share it, and one of every other class -- compares, v_cndmask, DPP, shifts,
+# min/max, three-register VOP3, packed and 64-bit operations, v_readlane -- every 4.1-4.3 cycles (transcendentals 8.2); one
+# wavefront alone issues at most one instruction of ANY kind per 4.4-4.9 cycles.  /opt/skills/guides/MI355X_MICROARCH.md's "SIMD-32,
+# 2 cycles" (1 228.8 G inst/s) is the first class only; the eikonal kernel's marching loop is 27 % first class, 72 % second, 1 %
+# transcendental by static count (tools/fmm_phase_count.py, profiles/r5_fmm_phase_split.md) = 3.7 cycles per instruction.
+VALU_CYCLES = {"simple": 2.25, "other": 4.2, "transcendental": 8.2}
+FMM_VALU_MIX = {"simple": 0.27, "other": 0.72, "transcendental": 0.01}
+VALU_PEAK_GINST = 256 * 4 * 2.4 / sum(FMM_VALU_MIX[k] * VALU_CYCLES[k] for k in VALU_CYCLES)   # = 661 G instructions/s
 # fp32 operations of the reference's own arithmetic per accepted node: four fouds2 calls (inv/CalSurfG.f90:557-729: one
 # quadrant = ~21 multiplies / adds + 1 sqrt + 1 division, of which the 16 lanes of a field evaluate all sixteen in one
 # instruction each), i.e. ~85 instruction slots per wave-pop of four fields if nothing but that arithmetic were issued
@@ -102,7 +115,8 @@ USEFUL_VALU_PER_WAVE_POP = 85
 
 
 def profiled_sq(workload, nfield):
-    """the eikonal kernel's counters per launch from profiles/sq_counters.json (tools/profile_sq.sh), or None with the reason"""
+    """the eikonal kernel's counters per launch from profiles/sq_counters_<workload>.json (tools/profile_sq.sh), or None with the reason"""
+    SQ_FILE = counter_file("sq_counters", workload)
     try:
         prof = json.load(open(SQ_FILE))
     except Exception as e:
@@ -334,7 +348,9 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
         **ref_extra,
         "multicore": mc,
         "value": 1.0 / per_field, "unit": "fields/s", "cores": 1, "kind": "port",
-        "sample": f"{ncol_s} columns of depthkernel (73 curves x {kmax} periods each), {nf} eikonal fields {g.nnx}x{g.nnz}, "
+        "extrapolated": True,
+        "sample": f"EXTRAPOLATED from a bounded sample, not a timed forward pass: {ncol_s} columns of depthkernel (73 curves x {kmax} "
+                  f"periods each), {nf} eikonal fields {g.nnx}x{g.nnz} on synthetic phase-velocity maps of the same statistics, "
                   f"{nr} rays traced (row assembly excluded); forward time per field = fmm + {rays_per_field} rays + "
                   f"dispersion share of {ncolumns} columns / {nfield_total} fields",
         "fmm_fields_per_s": 1.0 / t_field, "rays_per_s": 1.0 / t_ray, "depthkernel_columns_per_s": 1.0 / t_disp_col,
@@ -526,6 +542,7 @@ def main():
         lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
         stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")
+        stats["fmm_field_pops"] = ctx.kernel_seconds("fmm.field_pops")
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, sen, tpred=d_tpred)
         stats["rays_s"] = ctx.kernel_seconds("rays")
@@ -599,12 +616,17 @@ def main():
         ib_aty = int(stats.get("aty_idx_bytes", 4) or 4)
         s_ax = b_ax - nnz * (4 - ib_ax)
         s_aty = b_aty - nnz * (4 - ib_aty)
-        # The dominant kernel is bound by VALU instruction issue (a serial chain of heap pops per field, all parallelism across
-        # fields), not by HBM: `achieved` = VALU instructions per launch (SQ_INSTS_VALU of the committed, hash-locked counter
-        # pass) / this run's launch duration, `peak` = what 1024 SIMDs issue at 2.4 GHz; `useful_frac` = the share of those
-        # instructions that is the reference's fp32 arithmetic.  The HBM view of the same launch stays under `hbm`.
+        # The dominant kernel is bound by instruction issue (a serial chain of heap pops per field, all parallelism across
+        # fields), not by HBM.  `roofline` prices it against the MEASURED VALU issue peak of its instruction mix (VALU_PEAK_GINST
+        # above): `achieved` / `frac` = the USEFUL instruction rate -- the reference's own fp32 arithmetic, 85 instruction slots per
+        # pop of four fields, x the pops the launch itself counted / its duration -- so that the number is defined for every
+        # workload and every build; `issue` = all VALU instructions (SQ_INSTS_VALU of the committed counter pass of this workload,
+        # hash-locked to csrc/) against the same peak, null with the reason when that pass is stale.  The HBM view stays under `hbm`.
         sq, sq_src = profiled_sq(a.workload, nfield)
+        if stats.get("fmm_field_pops", 0) > 0:
+            pops = float(stats["fmm_field_pops"])                # counted by the kernel (the refined march stops at its box's edge)
         wave_pops = pops / 4.0
+        useful_ginst = USEFUL_VALU_PER_WAVE_POP * wave_pops / stats["fmm_s"] / 1e9
         hbm = {"bound": "hbm", "achieved": fmm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fmm_gbs / HBM_PEAK_GBS,
                "traffic": traffic["fmm"], "traffic_bytes_per_acceptance": (traffic["fmm"] / pops) if traffic["fmm"] else None,
                "traffic_source": traffic_src,
@@ -612,22 +634,24 @@ def main():
                        "launch (4-byte accesses: raw counter values, the gfx950 x2 read correction is only calibrated for 16-byte streams)"}
         if sq:
             ginst = sq["SQ_INSTS_VALU"] / stats["fmm_s"] / 1e9
-            roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
-                        "frac": ginst / VALU_PEAK_GINST, "traffic": traffic["fmm"],
-                        "valu_inst_per_launch": sq["SQ_INSTS_VALU"], "valu_inst_per_wave_pop": sq["SQ_INSTS_VALU"] / wave_pops,
-                        "useful_frac": USEFUL_VALU_PER_WAVE_POP * wave_pops / sq["SQ_INSTS_VALU"],
-                        # share of a resident wavefront's cycles in which it has a VALU instruction active; three wavefronts share a
-                        # SIMD, so x 3 ~ the SIMD's VALU pipe busy
-                        "valu_active_share_of_wave_cycles": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
-                        "counters_source": sq_src}
-        else:   # no counter pass of these sources: the HBM figures the metric asks for, and the reason
-            roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": None, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
-                        "frac": None, "traffic": traffic["fmm"], "counters_source": sq_src}
-        roofline.update({"node_acceptances_per_s": pops / stats["fmm_s"], "hbm": hbm,
-                         "note": "VALU-issue bound: three wavefronts per SIMD, a serial chain of heap pops per field, all parallelism across "
-                                 "fields; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction (under this load the chip "
-                                 "clocks ~2.06 GHz, DESIGN.md 4); useful_frac = the reference's fp32 arithmetic (85 instruction slots per "
-                                 "pop of four fields) / all VALU instructions"})
+            issue = {"achieved": ginst, "frac": ginst / VALU_PEAK_GINST, "valu_inst_per_launch": sq["SQ_INSTS_VALU"],
+                     "valu_inst_per_wave_pop": sq["SQ_INSTS_VALU"] / wave_pops,
+                     # share of a resident wavefront's cycles in which it has a VALU instruction active (quad-cycles / quad-cycles)
+                     "valu_active_share_of_wave_cycles": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAVE_CYCLES") else None,
+                     "counters_source": sq_src}
+        else:
+            issue = {"achieved": None, "frac": None, "counters_source": sq_src}
+        roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": useful_ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
+                    "frac": useful_ginst / VALU_PEAK_GINST, "traffic": traffic["fmm"],
+                    "useful_valu_per_wave_pop": USEFUL_VALU_PER_WAVE_POP, "wave_pops_per_launch": wave_pops, "issue": issue,
+                    "useful_frac_of_issued": (USEFUL_VALU_PER_WAVE_POP * wave_pops / sq["SQ_INSTS_VALU"]) if sq else None,
+                    "node_acceptances_per_s": pops / stats["fmm_s"], "hbm": hbm,
+                    "peak_source": "profiles/r5_valu_issue.md (tools/valu_issue_calib.hip): 2.25 / 4.2 / 8.2 cycles per wave64 instruction "
+                                   "by class, weighted with the marching loop's mix 0.27 / 0.72 / 0.01 -> 3.7 cycles on 1024 SIMDs at 2.4 GHz",
+                    "note": "instruction-issue bound: three wavefronts per SIMD, a serial chain of heap pops per field, all parallelism "
+                            "across fields.  achieved / frac = USEFUL VALU instructions (the reference's fp32 arithmetic, 85 per pop of four "
+                            "fields, x pops counted by the launch) per second against the measured issue peak; issue = every VALU "
+                            "instruction (counter pass) against the same peak"}
         out = {
             "metric": "FMM traveltime fields/sec (256^2 grid, 16 periods) + LSQR SpMV HBM GB/s",
             "value": total_fields / (dt / a.steps), "unit": "fields/s",

@@ -72,7 +72,7 @@ struct FmmArgs {
   float2 *slownr; // [nwg][tiled RM x RM]  {1/velnr, risti} of the refined grid
   HEnt *ovf;     // [nwg][ovfcap]
   int ovfcap;
-  unsigned *counter;
+  unsigned *counter;     // [0..7] the XCD ranges' queue positions; [16..17] (as one 64-bit word) nodes accepted by the launch
   const int *flist;  // nullable: indirection used by the spill rerun
   int prio;          // 1: the wavefronts raise their issue priority (small batches beside the dispersion copies, see run_fmm)
   int fastm;         // grid steps within the range in which the short exact division / square root may run (see div_exact)
@@ -231,13 +231,14 @@ struct Heap {
   // LDS, levels 10 and 11 in HBM; above that levels 1-10 in LDS, 11 and 12 in HBM -- see run_fmm's dispatch)
   static constexpr int NH = (HYB && (sizeof(NT) == 4 || CAP <= 256)) ? 2 : 1;
   static constexpr int TOT = HYB ? (CAP << NH) : CAP;   // slots the fast kernel can hold before the field is handed to the spill kernel
-  // interior-root table of march(): kernels whose LDS has 288 bytes to spare without losing a workgroup per CU (16-bit node ids,
-  // whose record-index differences fit 16 bits)
+  // interior-root table of march(): 288 bytes of LDS, which cost no kernel form a workgroup per CU (LDS comes in 1 280-byte granules:
+  // 12 288 + 288 B still give twelve, 16 384 + 288 nine like 16 384 alone -- profiles/r5_lds_granule.md)
 #ifdef DZ_FMM_NOTAB   // experiment: the coordinate path for every root
   static constexpr bool TAB = false;
 #else
-  static constexpr bool TAB = !SPILL && GPL == 16 && sizeof(NT) == 2;
+  static constexpr bool TAB = !SPILL && GPL == 16;
 #endif
+  unsigned long long *popcnt;   // nodes accepted by the launch (nullable)
   short *tab;   // [144] the wavefront's table (16-bit: the S-256 form must stay within 12 800 bytes of LDS -- allocation comes in
                 // 1 280-byte granules on this chip, and with 12 864 bytes a CU held eleven workgroups instead of twelve, -6 %)
   float *keys;  // this group's [CAP] keys (slot 0 unused)
@@ -739,7 +740,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
   constexpr bool LAZY = !SPILL;
   // the interior-root table (see the loop): record-index differences by lane class and coordinate residue
   constexpr bool TAB = Heap<CAP, SPILL, NT, HYB, GPL>::TAB;
-  const bool tab_ok = TAB && nnx >= 8 && nnz >= 8;
+  const bool tab_ok = TAB && nnx >= 8 && nnz >= 8 && tsh <= 14;   // (16-bit table entries: tile strides up to 2^14 records)
   const unsigned XMASK = ~((1u << tsh) - 1u) | 0xCu, ZMASK = ((1u << tsh) - 1u) & ~0xCu;   // the x and z bits of a record index
   // (both parts are monotone in their coordinate: one unsigned range test each; a grid too small to have an interior never passes)
   const unsigned xlo = tab_ok ? (unsigned)tile_x(3, tsh) : 0xffffffffu, xspan = tab_ok ? (unsigned)tile_x(nnx - 4, tsh) - xlo : 0u;
@@ -1175,6 +1176,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
     PROF(6);
   }
   PROF_FLUSH;
+  if (H.g0 && H.popcnt) atomicAdd(H.popcnt, (unsigned long long)npop);   // (one per field and march: what bench.py prices the launch by)
   return overflow;
 }
 
@@ -1246,6 +1248,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   H.nodes = s_nodes[grp];
   H.g0 = gl == 0;
   H.tab = s_tab;
+  H.popcnt = reinterpret_cast<unsigned long long *>(A.counter + 16);
   // Time slicing (round 3, late).  A field is one serial chain of pops and all fields are equally long, so a launch lasts a whole
   // number of rounds of one field's latency at the occupancy of that round: S-256's 16 000 fields on 13 312 resident slots would
   // run one full round and a second one with a fifth of the chip busy.  With ts_nstage > 1 a field is marched in stages that
@@ -1587,6 +1590,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // workgroups (one wavefront, FPW fields each): as many as the LDS heaps allow per CU
   int per_cu = 0;
   DZ_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fmm_kernel<CAP, false, NT, HYB, GPL>, 64, 0));
+  {   // the API rounds LDS differently from the allocator, which hands out 1 280-byte granules of the CU's 160 KB: at 12 288, 16 384
+      // and 32 768 bytes it answers one workgroup too many (measured: tools/lds_granule_probe.hip, profiles/r5_lds_granule.md)
+    hipFuncAttributes fa;
+    DZ_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&fmm_kernel<CAP, false, NT, HYB, GPL>)));
+    const int by_lds = (int)(163840 / ((fa.sharedSizeBytes + 1279) / 1280 * 1280));
+    if (per_cu > by_lds) per_cu = by_lds;
+  }
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 16) per_cu = 16;
   ctx->ksec["fmm.wg_per_cu"] = (double)per_cu;
@@ -1705,8 +1715,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const bool force_spill = ctx->opts.count("fmm.force_spill") && ctx->opts["fmm.force_spill"];
   DzTimer t(ctx, "fmm");
   std::vector<int> redo;
+  DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
   if (!force_spill) {
-    DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
     hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB, GPL>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
     DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1722,7 +1732,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipMemcpyAsync(p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice, ctx->stream));
     A.flist = (const int *)p;
     A.nfield = (int)redo.size();
-    DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
+    DZ_HIP(hipMemsetAsync(A.counter, 0, 64, ctx->stream));   // (the queue positions; the count of accepted nodes goes on)
     A.fpw = 4;                                        // (16 lanes per field: the spill kernel's sequential sift-down is written for them)
     A.ts_nstage = 1;
     int nwg2 = ((int)redo.size() + 3) / 4;
@@ -1737,6 +1747,11 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipStreamSynchronize(ctx->stream));
   }
   t.stop();
+  {
+    unsigned long long hp = 0;
+    DZ_HIP(hipMemcpy(&hp, A.counter + 16, 8, hipMemcpyDeviceToHost));
+    ctx->ksec["fmm.field_pops"] = (double)hp;   // nodes accepted by this call (all fields, refined + coarse marches, incl. spill reruns)
+  }
 #ifdef DZ_TS_WAITSTAT
   {
     unsigned long long h[2];

@@ -21,11 +21,14 @@ def check(stdout, steps=1):
     assert d["unit"] == "fields/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["scaling"] == "weak"
     assert d["steps"] == steps and d["n_gpus"] == 1 and d["value"] > 0 and "workload" in d["config"]
     r = d["roofline"]
-    # the eikonal kernel is bound by VALU issue: `achieved` comes from the committed counter pass (None when that pass is of other
-    # sources or another workload, as on this reduced batch); the HBM view of the same launch sits under roofline.hbm
-    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm"} <= set(r) and r["bound"] == "valu"
-    if r["achieved"] is not None:
-        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["useful_frac"] < 1
+    # the eikonal kernel is bound by instruction issue: `achieved` / `frac` = the useful VALU instruction rate (the reference's
+    # arithmetic x the pops the launch counted) against the measured issue peak -- ALWAYS numeric; `issue` = all VALU instructions
+    # of the committed counter pass (null on this reduced batch, which has no pass); the HBM view sits under roofline.hbm
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "hbm", "issue"} <= set(r) and r["bound"] == "valu"
+    assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0 < r["frac"] < 1
+    assert r["wave_pops_per_launch"] > 0 and 600 < r["peak"] < 700
+    if r["issue"]["achieved"] is not None:
+        assert r["frac"] < r["issue"]["frac"] < 1.2 and 0 < r["useful_frac_of_issued"] < 1
     h = r["hbm"]
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
     assert 0 < d["spmv"]["Ax"]["frac"] < 1 and 0 < d["spmv"]["ATy"]["frac"] < 1

@@ -77,10 +77,10 @@ def test_fmm_511_central_sources_use_the_hbm_level(ctx, orc):
     try:
         ctx.set_option("fmm.hyb2", 1)                                    # 511 LDS slots + TWO HBM levels (large batches' default)
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
-        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 9
         ctx.set_option("fmm.hyb2", 2)                                    # 1023 LDS slots + one HBM level
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
-        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") == 5
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") == 4
         ctx.set_option("fmm.hyb2", 0)
         ctx.set_option("fmm.no_hybrid", 1)
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
@@ -100,7 +100,7 @@ def test_fmm_341_two_hbm_levels_below_a_small_lds_part(ctx, orc):
     try:
         ctx.set_option("fmm.hyb2", 1)
         _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
-        assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+        assert ctx.kernel_seconds("fmm.wg_per_cu") >= 9
         _run_case(ctx, orc, 71, 71, 1, 5, seed=32, edge_sources=True)
         _run_case(ctx, orc, 71, 71, 1, 3, seed=33, shrink=6.0, rough=True)
         ctx.set_option("fmm.ts", 1)
@@ -108,7 +108,7 @@ def test_fmm_341_two_hbm_levels_below_a_small_lds_part(ctx, orc):
         _run_case(ctx, orc, 71, 71, 1, 6, seed=31, shrink=6.0)
         ctx.set_option("fmm.ts", 0)
         _run_case(ctx, orc, 143, 143, 1, 3, seed=17, shrink=12.0)       # 701 x 701: levels 1-10 in LDS, 11 and 12 in HBM
-        assert ctx.kernel_seconds("fmm.wg_per_cu") == 5
+        assert ctx.kernel_seconds("fmm.wg_per_cu") == 4
     finally:
         ctx.set_option("fmm.ts", 0)
         ctx.set_option("fmm.ts_stages", 0)
@@ -230,7 +230,7 @@ def test_fmm_time_sliced_marches(ctx, orc):
         assert ctx.kernel_seconds("fmm.spilled_fields") == 0
         ctx.set_option("fmm.hyb2", 1)                                   # 511 LDS slots + two HBM levels (the large batches')
         _run_case(ctx, orc, 105, 105, 1, 6, seed=21, shrink=10.0)
-        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 10
+        assert ctx.kernel_seconds("fmm.spilled_fields") == 0 and ctx.kernel_seconds("fmm.wg_per_cu") >= 9
         ctx.set_option("fmm.hyb2", 0)
         ctx.set_option("fmm.cap", 64)                                   # overflowing fields are flagged in stage 0 or later and redone
         _run_case(ctx, orc, 17, 17, 2, 6, seed=8, goxd=26.5, gozd=101.25)
@@ -360,7 +360,7 @@ def test_fmm_s512_bench_batch_takes_the_automatic_path_at_full_size(ctx, orc):
         assert int(st.abs().sum()) == 0
         return ttn
     out = run()
-    assert ctx.kernel_seconds("fmm.wg_per_cu") >= 10 and ctx.kernel_seconds("fmm.ts_stages") == 8
+    assert ctx.kernel_seconds("fmm.wg_per_cu") >= 9 and ctx.kernel_seconds("fmm.ts_stages") == 8
     auto_s = ctx.kernel_seconds("fmm")
     # the sources nearest the middle of the grid have the widest bands (the HBM levels of the heap are theirs)
     cx, cz = np.median(scx[:nsrc]), np.median(scz[:nsrc])
