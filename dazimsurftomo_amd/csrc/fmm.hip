@@ -365,6 +365,11 @@ struct Heap {
     return L;
   }
   __device__ __forceinline__ bool full() const { return !SPILL && ntr + 1 >= TOT; }
+  // keys of the LDS slots from `from` on = +inf: the parallel sift-down reads children without asking whether they exist (slots
+  // beyond the heap's end must lose every comparison); pop_root_par keeps the invariant when the heap shrinks, growing overwrites
+  __device__ __forceinline__ void pad(int gl, int from) {
+    for (int i = from + gl; i < CAP; i += GPL) keys[i] = INFINITY;
+  }
   __device__ __forceinline__ void add(float key, int node) {
     const int nbn[4] = {0, 0, 0, 0};
     int nbs[4] = {0, 0, 0, 0};
@@ -466,6 +471,7 @@ struct Heap {
     const int mls = mhi ? 0 : ntr;
     float mvk = keys[mls];
     NT mvc = nodes[mls];
+    keys[mls] = INFINITY;                                 // the slot leaves the heap: +inf beyond the end (see pad())
     if (HYB && wballot(mhi) != 0) {
       if (mhi) {
         const HEnt e = ovf[ntr - CAP];
@@ -480,7 +486,7 @@ struct Heap {
     ntr--;
     // lane constants: position q, its depth dq and offset oq in the subtree; G = its proper ancestors' bits (bit a-1 per
     // position a), E = the directions those ancestors must choose to reach q, A = G + its own bit (all of them must move)
-    const int q = gl + 1;
+    const int q = gl == GP - 1 ? 1 : gl + 1;              // (the idle lane looks where lane 0 looks and never matches)
     const int dq = 31 - __clz(q), oq = q - (1 << dq);
     unsigned G = 0, E = 0;
     if (dq >= 1) { G |= 1u << ((q >> 1) - 1); E |= (unsigned)(q & 1) << ((q >> 1) - 1); }
@@ -493,14 +499,16 @@ struct Heap {
 #pragma unroll
     for (int b = 0; b < NSTEP; b++) {
       if (b > 0 && actm == 0) break;                      // wave-uniform: no group of this wavefront goes deeper
-      const bool active = b == 0 || lanes(actm);
-      // straight-line code: lanes with nothing to read use the pair at slot 0 (slot 0 is never a heap entry, slot 1 is only
-      // read), lanes with nothing to move write their entry to slot 0
+      // Straight-line code without validity tests (round 5): the keys beyond the heap's end are +inf (pad()), so a missing child
+      // loses every comparison by itself; a group whose hole has stopped looks at the children of the hole again, finds the same
+      // "not smaller than the moving key" and moves nothing; lanes with nothing to move write their entry to slot 0.  Only the
+      // last step, and only where its parents' children can lie beyond the LDS array (c0 < 2^(LV NSTEP + 1); the 512-slot forms
+      // never: 2^9), tests for that: such children do not exist, or live in the HBM level of a hybrid heap (below).
       const int s = (p << dq) + oq;                        // this lane's parent slot
       const int c0 = 2 * s;
-      const bool lds = !HYB || c0 < CAP;                   // (HYB: deeper levels live in HBM, see below)
-      const bool v0 = active && lds && c0 <= ntr, v1 = active && lds && c0 < ntr;
-      const int rs = v0 ? c0 : 0;
+      constexpr bool CHK = (1 << (LV * NSTEP + 1)) > CAP;
+      const bool lds = !(CHK && b == NSTEP - 1) || c0 < CAP;
+      const int rs = lds ? c0 : 0;
       const float2 kk = *reinterpret_cast<const float2 *>(&keys[rs]);
       int n0, n1;
       if (sizeof(NT) == 2) {
@@ -512,7 +520,7 @@ struct Heap {
         n0 = v.x;
         n1 = v.y;
       }
-      const float k0 = v0 ? kk.x : INFINITY, k1 = v1 ? kk.y : INFINITY;
+      const float k0 = lds ? kk.x : INFINITY, k1 = lds ? kk.y : INFINITY;
       const bool right = k0 > k1;                          // left child strictly greater -> the hole goes right
       const float ck = right ? k1 : k0;
       const int cn = right ? n1 : n0;
@@ -1326,6 +1334,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
           H.nodes[i] = (NT)A.ts_nodes[(size_t)q * CAP + i];
         }
         H.ntr = n0;
+        if (!SPILL) H.pad(gl, nl + 1);
         H.rec = rec_c;
         H.tsh = tsh_c;
         cbar();
@@ -1422,6 +1431,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         cbar();
         // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 ----
         H.ntr = 0;
+        if (!SPILL) H.pad(gl, 1);
         H.rec = rec_r;
         H.tsh = TSH_R;
         int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
@@ -1525,6 +1535,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         cbar();
         // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
         H.ntr = 0;
+        if (!SPILL) H.pad(gl, 1);
         H.rec = rec_c;
         H.tsh = tsh_c;
         for (int base = 0; base < nbox; base += GP) {
