@@ -23,6 +23,10 @@ struct dazim_csr {
   int ncb = 0, cbw = 0;                          // number of column blocks, block width
   int64_t *cbptr = nullptr;
   float vmax = 0.0f;                             // max |val|, sets the fixed-point scale
+  // rows [0, split_row) hold the long rows, the rows from split_row on are all shorter than SPLIT_SHORT entries (G: the ray rows,
+  // then the seven-entry regularisation rows) -- the blocked products give each part the lane grouping it wants.  m: no short tail.
+  int64_t split_row = 0;
+  double long_avg = 0.0;                         // entries per row in [0, split_row)
   // the same column indices in 16 bits: the two products of an LSMR iteration stream 6 instead of 8 bytes per stored entry.
   // col16_mod = 0: the column itself (n <= 65536, the S-256 matrix); col16_mod = 2*cbw > 0: the column relative to the first
   // column of its PAIR of column blocks (larger n: the scatter kernel works on one block, the blocked A*x on a pair).
@@ -401,6 +405,87 @@ __global__ void k_reorth(int64_t n, float *v, const float *lv_prev, const double
   }
   if (part_out) block_partial(acc, part_out);
 }
+// The same chain in ONE launch (round 5; the chain above is lim + 1 launches of ~5 us each on an n-float vector -- 54 of the 255 us
+// of a test4_Yunnan iteration).  At most RC_BLOCKS workgroups of 1024 threads hold v in registers (E elements per thread) and walk
+// the window in the reference's order -- d = v . lv_q, v -= d lv_q, modified Gram-Schmidt: each dot sees the subtractions before it
+// -- with a grid barrier between a step's partial dots and its subtraction.  The sums are taken in a fixed order (per block, then
+// over the blocks by every block alike), so the result does not depend on arrival order; it differs from the chain's only in the
+// grouping of the partial sums.  (Taking all dots of the window at once -- classical Gram-Schmidt, two launches -- was tried first:
+// the iterates leave the reference's within eight iterations, 1.2e-2 relative on the test system of tests/test_sparse_gpu.py.)
+// The barrier: one counter per solve, never reset, target = (barriers so far) x blocks; release / acquire at agent scope
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  All blocks are resident by construction (<= 64 blocks on 256 CUs).
+// Option lsmr.reorth_chain = 1: the chain; lsmr.reorth_blocks: at most that many workgroups.
+constexpr int RC_BLOCKS = 64, RC_THREADS = 1024, RC_EMAX = 16;
+template <int E>
+__global__ __launch_bounds__(RC_THREADS) void k_reorth_coop(int64_t n, float *__restrict__ v, const float *__restrict__ lv, int lim,
+                                                             double *__restrict__ part2, double *__restrict__ part_out,
+                                                             unsigned *bar, unsigned bar_base, const int *guard) {
+  const int G = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (guard && *guard) {   // skipped half-step: the counter still advances by what the host has booked for this launch
+    if (tid == 0 && G > 1) __hip_atomic_fetch_add(bar, (unsigned)lim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
+  __shared__ double s_w[RC_THREADS / 64];
+  __shared__ float s_d;
+  float vr[E];
+  int64_t idx[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    idx[e] = (int64_t)blockIdx.x * RC_THREADS + tid + (int64_t)e * G * RC_THREADS;
+    vr[e] = idx[e] < n ? v[idx[e]] : 0.0f;
+  }
+  for (int q = 0; q < lim; q++) {
+    float lr[E];
+    double acc = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+      lr[e] = idx[e] < n ? lv[(size_t)q * n + idx[e]] : 0.0f;
+      acc += (double)vr[e] * lr[e];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) s_w[w] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int i = 0; i < RC_THREADS / 64; i++) t += s_w[i];
+      part2[(size_t)(q & 1) * RC_BLOCKS + blockIdx.x] = t;
+      if (G > 1) {   // (one release fence, relaxed polls, one acquire fence: an acquiring load per poll invalidates caches every time)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = bar_base + (unsigned)(q + 1) * (unsigned)G;
+        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {   // the dot: the blocks' partials in block order, by every block alike
+      double t = 0.0;
+      for (int i = lane; i < G; i += 64) t += part2[(size_t)(q & 1) * RC_BLOCKS + i];
+      t = wave_sum(t);
+      if (tid == 0) s_d = (float)t;
+    }
+    __syncthreads();
+    const float d = s_d;
+#pragma unroll
+    for (int e = 0; e < E; e++) vr[e] = vr[e] - d * lr[e];
+  }
+  double sq = 0.0;
+#pragma unroll
+  for (int e = 0; e < E; e++)
+    if (idx[e] < n) {
+      v[idx[e]] = vr[e];
+      sq += (double)vr[e] * vr[e];
+    }
+  sq = wave_sum(sq);
+  __syncthreads();
+  if (lane == 0) s_w[w] = sq;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int i = 0; i < RC_THREADS / 64; i++) t += s_w[i];
+    part_out[blockIdx.x] = t;
+  }
+}
 // alpha = ||v|| (:499); v /= alpha; rotations; hbar = h - f1*hbar ; x += f2*hbar ; h = v - f3*h (:539-541); partials of ||x||^2.
 // Every block evaluates the recurrences from the (read-only here) state; k_tests commits them.
 __global__ void k_alpha_update(int64_t n, float *v, float *h, float *hbar, float *x, const double *part, int np,
@@ -541,6 +626,19 @@ __global__ void k_colblock_ptr(int64_t nrows, int ncb, int cbw, const int64_t *_
   }
   cbptr[t] = lo;
 }
+// 1 + the last row with at least `thresh` entries (0: none): behind it the matrix has only short rows
+constexpr int SPLIT_SHORT = 64;
+__global__ void k_last_long_row(int64_t nrows, const int64_t *__restrict__ ptr, int thresh, unsigned long long *res) {
+  unsigned long long best = 0;
+  for (int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * VB)
+    if (ptr[r + 1] - ptr[r] >= thresh) best = (unsigned long long)(r + 1);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long b = __shfl_xor(best, o);
+    best = b > best ? b : best;
+  }
+  if ((threadIdx.x & 63) == 0 && best) atomicMax(res, best);
+}
 constexpr int APART = 2048;   // partial maxima (enough workgroups to stream at HBM rate)
 // 32-bit -> 16-bit column indices, four per thread step; mod > 0: relative to the pair of column blocks (column mod 2*cbw)
 __global__ void k_narrow_cols(int64_t n, const int *__restrict__ col, unsigned short *__restrict__ col16, int mod) {
@@ -661,7 +759,7 @@ __device__ __forceinline__ void walk_rows(int64_t r_first, int64_t stride, int64
 // (The same pipeline applied to the LDS-staged A*x kernel made it 2 % slower -- that kernel streams whole rows and is bandwidth
 // bound already -- and pipelining fixed-size segments instead of rows made this one 6 % slower; same-box A/B runs.)
 template <int GL, int NG, class IT>
-__global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
+__global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nsplit, int64_t nrows, int nchunk, int ncb, int cbw, int64_t ncols,
                                                           const int64_t *__restrict__ cbptr, const IT *__restrict__ col,
                                                           const float *__restrict__ val, const float *__restrict__ y,
                                                           double scale, long long *__restrict__ part, const int *__restrict__ guard,
@@ -679,14 +777,24 @@ __global__ __launch_bounds__(64 * SCW) void spmvT_scatter(int64_t nrows, int nch
   // fixed point by the magic-number trick: for |t| < 2^51, the low mantissa bits of t + 1.5*2^52 hold round-to-nearest-even(t);
   // scale is a power of two, so the fused multiply-add rounds exactly like (v*y*scale) + magic would
   constexpr double MAGIC = 6755399441055744.0;
-  walk_rows<GL, NG, IT>(
-      ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nchunk * SCW * RPWV, nrows, lane, col, val,
-      [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb], cbptr[r * (ncb + 1) + cb + 1], y[r]}; },
-      [&](int c, float v, float yr) {
-        atomicAdd((unsigned long long *)&acc[c - csub],
-                  (unsigned long long)(__double_as_longlong(fma((double)(v * yr), scale, MAGIC)) - __double_as_longlong(MAGIC)));
-      },
-      [](int64_t, float) {});
+  // (two walks, round 5: the long rows [0, nsplit) with GL lanes per row, the short tail [nsplit, nrows) -- G's seven-entry
+  // regularisation rows behind its ray rows -- four rows per wavefront; one launch, one set of accumulators)
+  auto ptrf = [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb], cbptr[r * (ncb + 1) + cb + 1], y[r]}; };
+  auto elemf = [&](int c, float v, float yr) {
+    atomicAdd((unsigned long long *)&acc[c - csub],
+              (unsigned long long)(__double_as_longlong(fma((double)(v * yr), scale, MAGIC)) - __double_as_longlong(MAGIC)));
+  };
+  // (contiguous row ranges of equal entry counts per wavefront instead of this round-robin deal were measured in round 5: A*x 83 ->
+  // 108 us, A^T*y 103 -> 135 us on test4_Yunnan's system -- dealt round-robin, the wavefronts of the launch stream one moving
+  // window of the matrix together, which the memory system likes better than 2 048 separate streams)
+  walk_rows<GL, NG, IT>(((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nchunk * SCW * RPWV, nsplit, lane,
+                        col, val, ptrf, elemf, [](int64_t, float) {});
+  if (nsplit < nrows) {
+    constexpr int GS = 16, RS = 64 / GS;
+    const int lane_s = (threadIdx.x & 63) % GS, grp_s = (threadIdx.x & 63) / GS;
+    walk_rows<GS, 1, IT>(nsplit + ((int64_t)chunk + (int64_t)nchunk * (threadIdx.x >> 6)) * RS + grp_s, (int64_t)nchunk * SCW * RS, nrows,
+                         lane_s, col, val, ptrf, elemf, [](int64_t, float) {});
+  }
   __syncthreads();
   long long *dst = part + (size_t)chunk * ncols + c0;
   for (int i = threadIdx.x; i < width; i += 64 * SCW) dst[i] = acc[i];
@@ -719,7 +827,7 @@ __global__ void k_scatter_combine(int64_t ncols, int nchunk, const long long *__
 // cache-line gather that bounds the plain kernel.  A workgroup owns (row set x column-block pair) and writes the partial
 // dot product of each of its rows to part[pair][row]; k_rows_combine adds the pairs in a fixed order.
 template <int GL, int NG, class IT>
-__global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int nset, int npair, int ncb, int cbw, int64_t ncols,
+__global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nsplit, int64_t nrows, int nset, int npair, int ncb, int cbw, int64_t ncols,
                                                               const int64_t *__restrict__ cbptr, const IT *__restrict__ col,
                                                               const float *__restrict__ val, const float *__restrict__ x,
                                                               float *__restrict__ part, const int *__restrict__ guard, int pairlocal) {
@@ -736,17 +844,29 @@ __global__ __launch_bounds__(64 * SCW) void spmv_rows_blocked(int64_t nrows, int
   const int lane = (threadIdx.x & 63) % GL, grp = (threadIdx.x & 63) / GL;
   float acc = 0.0f;
   float *dst = part + (size_t)pr * nrows;
-  walk_rows<GL, NG, IT>(
-      ((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nset * SCW * RPWV, nrows, lane, col, val,
-      [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb0], cbptr[r * (ncb + 1) + cb1], 0.0f}; },
-      [&](int c, float v, float) { acc += v * xblk[c - csub]; },
-      [&](int64_t r, float) {
-        float a = acc;
+  auto ptrf = [&](int64_t r) { return RowPtr{cbptr[r * (ncb + 1) + cb0], cbptr[r * (ncb + 1) + cb1], 0.0f}; };
+  auto elemf = [&](int c, float v, float) { acc += v * xblk[c - csub]; };
+  walk_rows<GL, NG, IT>(((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RPWV + grp, (int64_t)nset * SCW * RPWV, nsplit, lane, col, val,
+                        ptrf, elemf, [&](int64_t r, float) {
+                          float a = acc;
 #pragma unroll
-        for (int o = GL / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0 && r < nrows) dst[r] = a;
-        acc = 0.0f;
-      });
+                          for (int o = GL / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                          if (lane == 0 && r < nsplit) dst[r] = a;
+                          acc = 0.0f;
+                        });
+  if (nsplit < nrows) {   // the short tail of the matrix (see spmvT_scatter): four rows per wavefront
+    constexpr int GS = 16, RS = 64 / GS;
+    const int lane_s = (threadIdx.x & 63) % GS, grp_s = (threadIdx.x & 63) / GS;
+    acc = 0.0f;
+    walk_rows<GS, 1, IT>(nsplit + ((int64_t)set + (int64_t)nset * (threadIdx.x >> 6)) * RS + grp_s, (int64_t)nset * SCW * RS, nrows, lane_s,
+                         col, val, ptrf, elemf, [&](int64_t r, float) {
+                           float a = acc;
+#pragma unroll
+                           for (int o = GS / 2; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                           if (lane_s == 0 && r < nrows) dst[r] = a;
+                           acc = 0.0f;
+                         });
+  }
 }
 // out[r] = beta*out[r] + sum_pairs part[pair][r] ; partial ||out||^2
 __global__ void k_rows_combine(int64_t nrows, int npair, const float *__restrict__ part, float *__restrict__ out,
@@ -907,6 +1027,21 @@ int build_colblocks(dazim_ctx *ctx, dazim_csr *A, int64_t changed_from = 0) {
   if ((rc = dz_scratch(ctx, "csr.absmax", (APART + 4) * 4, &p))) return rc;
   float *pm = (float *)p;
   A->vmax = 0.0f;
+  A->split_row = A->m;
+  A->long_avg = A->m > 0 ? (double)A->nnz / (double)A->m : 0.0;
+  if (A->m > 0 && A->nnz > 0) {   // where the short tail of the matrix begins (see dazim_csr::split_row)
+    unsigned long long *d_last = reinterpret_cast<unsigned long long *>(pm + APART + 2), h_last = 0;
+    DZ_HIP(hipMemsetAsync(d_last, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_last_long_row, dim3(nblk(A->m)), dim3(VB), 0, ctx->stream, A->m, A->rowptr, SPLIT_SHORT, d_last);
+    DZ_HIP(hipMemcpyAsync(&h_last, d_last, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    if ((int64_t)h_last < A->m && (int64_t)h_last > 0) {
+      int64_t at = 0;
+      DZ_HIP(hipMemcpy(&at, A->rowptr + h_last, 8, hipMemcpyDeviceToHost));
+      A->split_row = (int64_t)h_last;
+      A->long_avg = (double)at / (double)h_last;
+    }
+  }
   if (A->nnz > 0) {
     const int nb = nblk((A->nnz + 3) / 4, APART);
     hipLaunchKernelGGL(k_absmax, dim3(nb), dim3(VB), 0, ctx->stream, A->nnz, A->val, pm);
@@ -953,15 +1088,21 @@ int launch_spmvT(dazim_ctx *ctx, const dazim_csr *A, const float *y, float ymax,
   const double scale = ldexp(1.0, fb - e);
   const size_t lds = (size_t)A->cbw * 8;
   // short (row, column block) segments: four rows per wavefront (16 lanes each), else a whole wavefront per row
-  bool shortseg = A->nnz < (int64_t)400 * A->m * A->ncb;   // measured: 16 lanes win at 141 and 296 entries per segment, 64 at 553
+  // (entries per segment of the LONG rows: the short tail, if any, is walked four rows per wavefront anyway -- test4_Yunnan's joint
+  // matrix is 20 877 ray rows of 2 548 entries and 73 440 regularisation rows of seven, 284 per segment on average, 637 in the ray rows)
+  const bool split = !(ctx->opts.count("spmv.split") && !ctx->opts["spmv.split"]) && A->split_row < A->m;
+  const int64_t nsplit = split ? A->split_row : A->m;
+  bool shortseg = (split ? A->long_avg : (double)A->nnz / (double)A->m) < 400.0 * A->ncb;   // measured: 16 lanes win at 141 and 296 entries per segment, 64 at 553
   if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
+  ctx->ksec["spmvt.split_row"] = (double)nsplit;
   const dim3 sgrid(nchunk * A->ncb), sblock(64 * SCW);
 #define DZ_SCATTER(GL_, NG_, IT_, COLP_)                                                                                        \
   do {                                                                                                                          \
     DZ_HIP(hipFuncSetAttribute((const void *)spmvT_scatter<GL_, NG_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((spmvT_scatter<GL_, NG_, IT_>), sgrid, sblock, lds, ctx->stream, A->m, nchunk, A->ncb, A->cbw, A->n,       \
-                       A->cbptr, COLP_, A->val, y, scale, part, guard, (sizeof(IT_) == 2 && A->col16_mod > 0) ? 1 : 0);                               \
+    hipLaunchKernelGGL((spmvT_scatter<GL_, NG_, IT_>), sgrid, sblock, lds, ctx->stream, nsplit, A->m, nchunk, A->ncb, A->cbw, A->n, \
+                       A->cbptr, COLP_, A->val, y, scale, part, guard, (sizeof(IT_) == 2 && A->col16_mod > 0) ? 1 : 0);               \
   } while (0)
+  // (more or fewer 256-entry groups in flight per row segment -- 3 or 6 instead of 4 -- measured in round 5: no difference)
   if (A->col16) {   // 16-bit column indices: 6 bytes per stored entry
     if (shortseg) DZ_SCATTER(16, 2, unsigned short, A->col16); else DZ_SCATTER(64, 4, unsigned short, A->col16);
   } else {
@@ -1000,13 +1141,16 @@ int launch_spmvA(dazim_ctx *ctx, const dazim_csr *A, const float *x, float *out,
   if ((rc = dz_scratch(ctx, "spmv.part", (size_t)npair * A->m * 4, &p))) return rc;
   float *part = (float *)p;
   const size_t lds = (size_t)A->cbw * 2 * 4;
-  bool shortseg = A->nnz < (int64_t)600 * A->m * npair;    // measured: 16 lanes win at 282 and 519 entries per segment
+  const bool split = !(ctx->opts.count("spmv.split") && !ctx->opts["spmv.split"]) && A->split_row < A->m;
+  const int64_t nsplit = split ? A->split_row : A->m;
+  bool shortseg = (split ? A->long_avg : (double)A->nnz / (double)A->m) < 600.0 * npair;    // measured: 16 lanes win at 282 and 519 entries per segment
   if (ctx->opts.count("spmv.gl16") && ctx->opts["spmv.gl16"] >= 0) shortseg = ctx->opts["spmv.gl16"] != 0;
+  ctx->ksec["spmv.split_row"] = (double)nsplit;
   const dim3 bgrid(nset * npair), bblock(64 * SCW);
 #define DZ_BLOCKED(GL_, NG_, IT_, COLP_)                                                                                        \
   do {                                                                                                                          \
     DZ_HIP(hipFuncSetAttribute((const void *)spmv_rows_blocked<GL_, NG_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((spmv_rows_blocked<GL_, NG_, IT_>), bgrid, bblock, lds, ctx->stream, A->m, nset, npair, A->ncb, A->cbw, A->n, \
+    hipLaunchKernelGGL((spmv_rows_blocked<GL_, NG_, IT_>), bgrid, bblock, lds, ctx->stream, nsplit, A->m, nset, npair, A->ncb, A->cbw, A->n, \
                        A->cbptr, COLP_, A->val, x, part, guard, (sizeof(IT_) == 2 && A->col16_mod > 0) ? 1 : 0);                 \
   } while (0)
   if (A->col16) {   // 16-bit column indices: 6 bytes per stored entry
@@ -1646,7 +1790,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     const int npart = gm > gn ? (gm > NPART ? gm : NPART) : (gn > NPART ? gn : NPART);
     if ((r = dz_scratch(ctx, "lsmr.part", (size_t)npart * 8, &p))) return r;
     part = (double *)p;
-    if ((r = dz_scratch(ctx, "lsmr.part2", (size_t)NPART * 8 * 2, &p))) return r;
+    if ((r = dz_scratch(ctx, "lsmr.part2", (size_t)NPART * 8 * 2 + 64, &p))) return r;
     part2 = (double *)p;
     if ((r = dz_scratch(ctx, "lsmr.partx", (size_t)NPART * 8, &p))) return r;
     partx = (double *)p;
@@ -1799,6 +1943,8 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     const int *g1 = &S->stop, *g2 = &S->stop2;
     // one iteration, enqueued without any host synchronisation; k = its number (the reorthogonalisation window is a function
     // of k alone: localVEnqueue advances once per iteration, :723-731)
+    unsigned reorth_barriers = 0;   // arrivals booked at the grid barrier of k_reorth_coop so far (its counter is zeroed here, once)
+    DZ_HIP(hipMemsetAsync(part2 + 2 * NPART, 0, 64, ctx->stream));
     auto enqueue_iteration = [&](int k, hipEvent_t *tev) -> int {
       int r;
       if (tev) DZ_HIP(hipEventRecord(tev[0], ctx->stream));
@@ -1822,7 +1968,26 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
       if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
       const double *pa = part;
       int npa = gn_t;
-      if (localVecs > 0) {   // localVOrtho :733-748 (modified Gram-Schmidt, one launch per vector; the last one leaves ||v||^2)
+      const bool chain = ctx->opts.count("lsmr.reorth_chain") && ctx->opts["lsmr.reorth_chain"];
+      // localVOrtho :733-748 in one launch (k_reorth_coop) when v fits the registers of RC_BLOCKS workgroups
+      // as few workgroups as hold v with <= RC_EMAX elements per thread, eight where that is enough: a step's grid barrier is
+      // atomics on one word across XCDs (whose L2s do not share it), and its cost grows with the arrivals -- test4_Yunnan's
+      // 73 440-float v, ten vectors: 52 us with 64 workgroups (= the chain's eleven launches), 33 us with 8
+      int rcb = (int)((n + (int64_t)RC_THREADS * RC_EMAX - 1) / ((int64_t)RC_THREADS * RC_EMAX));
+      if (rcb < 8) rcb = 8;
+      if (rcb > (int)((n + RC_THREADS - 1) / RC_THREADS)) rcb = (int)((n + RC_THREADS - 1) / RC_THREADS);
+      if (rcb > RC_BLOCKS) rcb = RC_BLOCKS;
+      if (ctx->opts.count("lsmr.reorth_blocks") && ctx->opts["lsmr.reorth_blocks"] > 0 && ctx->opts["lsmr.reorth_blocks"] < rcb) rcb = ctx->opts["lsmr.reorth_blocks"];
+      const int64_t per_thread = (n + (int64_t)rcb * RC_THREADS - 1) / ((int64_t)rcb * RC_THREADS);
+      if (localVecs > 0 && lim > 0 && per_thread <= RC_EMAX && !chain) {
+        unsigned *bar = reinterpret_cast<unsigned *>(part2 + 2 * NPART);
+        const unsigned base = reorth_barriers;
+        reorth_barriers += (unsigned)lim * (unsigned)rcb;
+#define DZ_RC(E_) hipLaunchKernelGGL(k_reorth_coop<E_>, dim3(rcb), dim3(RC_THREADS), 0, ctx->stream, n, v, localV, lim, part2, part, bar, base, g2)
+        if (per_thread <= 1) DZ_RC(1); else if (per_thread <= 2) DZ_RC(2); else if (per_thread <= 4) DZ_RC(4); else if (per_thread <= 8) DZ_RC(8); else DZ_RC(16);
+#undef DZ_RC
+        npa = rcb;
+      } else if (localVecs > 0) {   // ... or as the chain: modified Gram-Schmidt, one launch per vector; the last one leaves ||v||^2
         for (int q = 0; q <= lim; q++) {
           const float *prev = q > 0 ? localV + (size_t)(q - 1) * n : nullptr;
           const float *next = q < lim ? localV + (size_t)q * n : nullptr;
