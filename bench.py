@@ -559,6 +559,7 @@ def main():
             stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
             stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
             stats["nranks"] = ctx.kernel_seconds("lsmr.nranks")
+            stats["collectives_per_iteration"] = ctx.kernel_seconds("lsmr.collectives_per_iteration")
             stats["host_syncs"] = ctx.kernel_seconds("lsmr.host_syncs")      # counted by the library around the iteration loop
         else:           # row-partitioned G, one RCCL all-reduce of G^T u (n floats) + one scalar per iteration
             t_l = time.perf_counter()
@@ -680,6 +681,8 @@ def main():
                      "m": m, "n": n, "nnz": nnz},
             "lsmr": {"driver": ("in-library RCCL (dazim_comm_init)" if native else "torch.distributed (backend nccl = RCCL)") if use_dist
                                else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
+                     # row-sharded solve: one grouped ncclAllReduce per iteration (the n floats of A_p^T u_p and the double ||u_p||^2)
+                     "collectives_per_iteration": (int(stats.get("collectives_per_iteration", 1)) if use_dist else 0),
                      "host_syncs_per_iteration": (stats["host_syncs"] / max(stats["lsmr_itn"], 1)) if stats.get("host_syncs", -1) >= 0 else None,
                      "host_syncs_note": "host waits on the device counted by the solver during its iteration loop / iterations"},
             "dispersion": ("model rows sharded over the ranks, tables joined by one all-gather (RCCL)" if shard_disp

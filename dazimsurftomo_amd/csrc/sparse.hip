@@ -354,12 +354,6 @@ __device__ __forceinline__ double block_total(const double *part, int np) {
   __syncthreads();
   return s_t;
 }
-// sum of the partials -> sum[0] (row-sharded solve: the squared norm of u before its all-reduce)
-__global__ void k_total(const double *part, int np, double *sum, const int *guard) {
-  if (guard && *guard) return;
-  const double t = block_total(part, np);
-  if (threadIdx.x == 0) sum[0] = t;
-}
 // beta = ||u|| from the partials of the product that wrote u (or from the all-reduced sum); u /= beta; localVEnqueue(v)
 // (:487-492).  beta == 0 skips the second half-step of this iteration (stop2).
 __global__ void k_beta_scal_u(int64_t m, float *u, const double *part, int np, const double *sum_in, int64_t n, const float *v,
@@ -376,6 +370,53 @@ __global__ void k_beta_scal_u(int64_t m, float *u, const double *part, int np, c
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < m; i += (int64_t)gridDim.x * VB) u[i] = a * u[i];
   if (lv_slot)
     for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) lv_slot[i] = v[i];
+}
+// Row-sharded solve, ONE collective per iteration (round 5).  The two all-reduces of an iteration used to depend on each other:
+// ||u||^2 had to be summed over the ranks before u could be scaled, and only the scaled u went into A_p^T u_p.  A^T is linear, so
+// each rank now scales its shard by its OWN norm (u_p / beta_p: entries <= 1, which the fixed-point scatter relies on), forms
+// w_p = beta_p A_p^T (u_p / beta_p) = A_p^T u_p, and one grouped all-reduce carries the n floats of w and the double beta_p^2;
+// afterwards beta = sqrt(sum beta_p^2), v = w / beta - beta v and u_p <- (u_p / beta_p) (beta_p / beta).
+// k_local_norm_scal: beta_p^2 -> sum[0], beta_p -> bp[0], u_p /= beta_p.
+__global__ void k_local_norm_scal(int64_t m, float *u, const double *part, int np, double *sum, float *bp, const LsmrState *S) {
+  if (S->stop) return;
+  const double t = block_total(part, np);
+  const float b = (float)sqrt(t);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sum[0] = t;
+    bp[0] = b;
+  }
+  if (!(b > 0.0f)) return;
+  const float a = 1.0f / b;
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < m; i += (int64_t)gridDim.x * VB) u[i] = a * u[i];
+}
+__global__ void k_scale_by(int64_t n, float *w, const float *f, const int *guard) {
+  if (guard && *guard) return;
+  const float a = f[0];
+  for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) w[i] = a * w[i];
+}
+// after the all-reduce: beta (:487), localVEnqueue(v) (:490-492), u_p = u / beta, v = A^T u - beta v (:496-497) from w = sum_p A_p^T u_p,
+// partials of ||v||^2.  beta == 0 skips the second half-step (stop2), as in k_beta_scal_u.
+__global__ void k_beta_axpby(int64_t m, float *u, int64_t n, float *v, const float *w, const double *sum, const float *bp,
+                             float *lv_slot, double *part, LsmrState *S) {
+  if (S->stop) return;
+  const float beta = (float)sqrt(sum[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    S->beta = beta;
+    S->stop2 = !(beta > 0.0f);
+  }
+  double sq = 0.0;
+  if (beta > 0.0f) {
+    const float rb = 1.0f / beta, ru = bp[0] * rb;
+    for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < m; i += (int64_t)gridDim.x * VB) u[i] = ru * u[i];
+    for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
+      const float vi = v[i];
+      if (lv_slot) lv_slot[i] = vi;
+      const float o = -beta * vi + rb * w[i];
+      v[i] = o;
+      sq += (double)o * o;
+    }
+  }
+  block_partial(sq, part);
 }
 // local reorthogonalisation step q (localVOrtho, inv/lsmrModule.f90:733-748), modified Gram-Schmidt:
 // d = sum(part_in) (the dot of v with lv_prev computed by the previous launch); v -= d*lv_prev;
@@ -1957,15 +1998,28 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
         slot = localV + (size_t)(ptr - 1) * n;
         lim = k >= localVecs ? localVecs : k + 1;     // localVQueueFull ? localVecs : localPointer (:738-742)
       }
-      if (comm) {
-        hipLaunchKernelGGL(k_total, dim3(1), dim3(64), 0, ctx->stream, part, gm_t, d_sum, g1);
+      if (comm) {   // one grouped all-reduce per iteration (see k_local_norm_scal)
+        float *d_bp = reinterpret_cast<float *>(d_sum + 4);
+        const int bmn = bm > bn ? bm : bn;
+        hipLaunchKernelGGL(k_local_norm_scal, dim3(bm), dim3(VB), 0, ctx->stream, m, u, part, gm_t, d_sum, d_bp, S);
+        if (tev) DZ_HIP(hipEventRecord(tev[2], ctx->stream));
+        DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
+        if ((r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr, g1))) return r;
+        hipLaunchKernelGGL(k_scale_by, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, d_bp, g1);
+        if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
+        DZ_NCCL(ncclGroupStart());
+        DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
         DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
+        DZ_NCCL(ncclGroupEnd());
+        hipLaunchKernelGGL(k_beta_axpby, dim3(bmn), dim3(VB), 0, ctx->stream, m, u, n, v, wbuf, d_sum, d_bp, slot, part, S);
+        gn_t = bmn;
+      } else {
+        hipLaunchKernelGGL(k_beta_scal_u, dim3(bm > bn ? bm : bn), dim3(VB), 0, ctx->stream, m, u, part, gm_t,
+                           (const double *)nullptr, n, v, slot, S);
+        if (tev) DZ_HIP(hipEventRecord(tev[2], ctx->stream));
+        if ((r = spmvT(&S->beta, -1.0f, g2))) return r;                                     // v = A^T u - beta v (:496-497)
+        if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
       }
-      hipLaunchKernelGGL(k_beta_scal_u, dim3(bm > bn ? bm : bn), dim3(VB), 0, ctx->stream, m, u, part, gm_t,
-                         comm ? d_sum : (const double *)nullptr, n, v, slot, S);
-      if (tev) DZ_HIP(hipEventRecord(tev[2], ctx->stream));
-      if ((r = spmvT(&S->beta, -1.0f, g2))) return r;                                       // v = A^T u - beta v (:496-497)
-      if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
       const double *pa = part;
       int npa = gn_t;
       const bool chain = ctx->opts.count("lsmr.reorth_chain") && ctx->opts["lsmr.reorth_chain"];
@@ -2052,6 +2106,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
   ctx->ksec["lsmr.normb"] = normb;
   ctx->ksec["lsmr.host_syncs"] = host_syncs;
+  ctx->ksec["lsmr.collectives_per_iteration"] = comm ? 1.0 : 0.0;   // (a grouped all-reduce: the n floats of A^T u and the double ||u_p||^2)
   {
     int nr = 1;
     if (comm) (void)ncclCommCount(comm, &nr);

@@ -7,13 +7,17 @@ the curves of a block of rows of the model and one all-gather hands every rank t
 (`depthkernel_sharded`: the eikonal solve needs every column's phase velocity, the G rows every
 column's kernels -- a real exchange step, 13 MB at 54 x 54 x 12 x 16 periods).  Solve: G is row-partitioned exactly as its rows were produced (each rank keeps the rows of
 its own rays; the Tikhonov rows are split evenly, `shard_rows`), and LSMR (inv/lsmrModule.f90:36)
-needs per iteration one all-reduce of the n-vector A^T u and one scalar all-reduce for ||u||^2;
-everything n-sized (v, h, hbar, x, localV) is replicated and updated redundantly, so no other
+needs per iteration ONE all-reduce: each rank scales its shard of u by its own norm beta_p and sends
+w_p = beta_p A_p^T (u_p / beta_p) together with beta_p^2 (n + 1 values; A^T is linear, beta = sqrt(sum beta_p^2) scales
+afterwards).  Everything n-sized (v, h, hbar, x, localV) is replicated and updated redundantly, so no other
 exchange exists.  At n <= 350 k floats the message is <= 1.4 MB: latency-bound, one ring pass.
 
-`lsmr_distributed` is the driver; the local products come from a `LocalOps` object: on GPUs
-`GpuLocalOps` (the HIP SpMV kernels through the C ABI on torch CUDA tensors), in the CPU gloo tests a
-test double backed by the oracle.  The scalar recurrences are the reference's, in fp32.
+The PRODUCT path is the solve inside the library (`dazim_comm_init` + `dazim_lsmr`, csrc/sparse.hip: device-side recurrences,
+one grouped ncclAllReduce per iteration).  `lsmr_distributed` below is its TEST MIRROR: the same formulation statement by
+statement in torch, so that the world-size-2 / 3 gloo tests (tests/test_distributed_cpu.py) check the algebra of the fused
+collective where no second GPU exists; bench.py falls back to it only when a rank cannot join the RCCL communicator.  The local
+products come from a `LocalOps` object: on GPUs `GpuLocalOps` (the HIP SpMV kernels through the C ABI on torch CUDA tensors),
+in the CPU gloo tests a test double backed by the oracle.  The scalar recurrences are the reference's, in fp32.
 """
 import numpy as np
 
@@ -179,23 +183,31 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
     normA = condA = normx = _f32(0)
     w = torch.empty(n, dtype=f32, device=dev)
     syncs[0] = 0                                      # counted over the iteration loop only
+    collectives = [0]
     while True:
         itn += 1
         u.mul_(float(-alpha))
         ops.aprod1(v, u)                              # u = A_p v - alpha u   (local rows only)
-        beta = gnorm_u(u)                             # scalar all-reduce
+        # ONE collective per iteration, as in the library (sparse.hip, k_local_norm_scal): the shard is scaled by its own norm,
+        # w_p = beta_p A_p^T (u_p / beta_p), and the n values of w travel with beta_p^2 in one all-reduce
+        bp2 = (u.double() ** 2).sum().reshape(1)      # local ||u_p||^2, stays on the device
+        bp = torch.sqrt(bp2).to(f32)
+        u.mul_(torch.where(bp > 0, 1.0 / bp, torch.ones_like(bp)))
+        w.zero_()
+        ops.aprod2(w, u)                              # A_p^T (u_p / beta_p)
+        pack = torch.cat([(w * bp).double(), bp2])    # [n + 1] doubles: w_p and beta_p^2
+        allsum_(pack)                                 # RCCL all-reduce over xGMI
+        collectives[0] += 1
+        beta = _f32(np.sqrt(host(pack[n])))
         if beta > 0:
-            u.mul_(float(_f32(1) / beta))
+            u.mul_(bp * float(_f32(1) / beta))        # u_p = u / beta
             if localVecs > 0:                         # localVEnqueue
                 if localPointer < localVecs:
                     localPointer += 1
                 else:
                     localPointer, localVQueueFull = 1, True
                 localV[localPointer - 1].copy_(v)
-            w.zero_()
-            ops.aprod2(w, u)                          # w = A_p^T u_p
-            allsum_(w)                                # RCCL all-reduce of G^T u over xGMI
-            v.mul_(float(-beta)).add_(w)
+            v.mul_(float(-beta)).add_(pack[:n].to(f32) * float(_f32(1) / beta))
             if localVecs > 0:                         # localVOrtho, modified Gram-Schmidt
                 lim = localVecs if localVQueueFull else localPointer
                 for q in range(lim):
@@ -263,5 +275,5 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
     if damp > 0 and istop == 2:
         istop = 3
     info.update(istop=int(istop), itn=itn, normA=float(normA), condA=float(condA), normr=float(normr),
-                normAr=float(normAr), normx=float(normx), host_syncs=syncs[0])
+                normAr=float(normAr), normx=float(normx), host_syncs=syncs[0], collectives=collectives[0])
     return x, info

@@ -72,6 +72,7 @@ def _worker(rank, world, port, cfg, out):
             xo, io = orc.lsmr(m, n, irow, icol, rw, b, *cfg)
             out["ok"] = (info["istop"] == io["istop"], abs(info["itn"] - io["itn"]),
                          float(np.linalg.norm(x.numpy() - xo) / np.linalg.norm(xo)), info["itn"])
+            out["collectives"] = (info["collectives"], info["itn"])   # the fused form: ONE all-reduce per iteration (n + 1 values)
         # replicated result: every rank must hold the same x bit for bit
         xs = [torch.zeros_like(x) for _ in range(world)]
         dist.all_gather(xs, x)
@@ -91,6 +92,7 @@ def test_lsmr_distributed_world2_gloo(orc, cfg):
     same_istop, ditn, rel, itn = out["ok"]
     assert same_istop and ditn <= 3 and rel <= 1e-3, (out["ok"],)
     assert out["same0"] and out["same1"]
+    assert out["collectives"][0] == out["collectives"][1], out["collectives"]
 
 
 def _oracle_depthkernel(orc):
