@@ -114,6 +114,17 @@ class Context:
         buf = C.create_string_buffer(bytes(uid), 128)
         self._check(self.lib.dazim_comm_init(self._h, int(nranks), int(rank), buf))
 
+    def comm_init_files(self, nranks, rank, directory):
+        """the same communicator with every collective staged through files in `directory` (tests: several ranks on ONE GPU)"""
+        self._check(self.lib.dazim_comm_init_files(self._h, int(nranks), int(rank), str(directory).encode()))
+
+    def comm_allreduce(self, arr, op="sum"):
+        """in-place sum / max over the ranks of a numpy array (float32, float64 or int64); nothing happens without a communicator"""
+        dt = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int64): 2}[arr.dtype]
+        assert arr.flags.c_contiguous
+        self._check(self.lib.dazim_comm_allreduce(self._h, C.c_void_p(arr.ctypes.data), C.c_int64(arr.size), dt, 0 if op == "sum" else 1))
+        return arr
+
     def comm_free(self):
         self._check(self.lib.dazim_comm_free(self._h))
 

@@ -8,6 +8,11 @@
 #include "dazim_internal.h"
 
 #include <rccl/rccl.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <string>
+#include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -1747,6 +1752,74 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
     if (r_ != ncclSuccess) return dz_fail(ctx, -2000 - (int)r_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
   } while (0)
 
+// ---- the communicator of a row-sharded run -------------------------------------------------------------------------------------
+// Two transports behind one interface (round 5).  RCCL (dazim_comm_init): ncclAllReduce on the context's stream, over xGMI -- the
+// product.  Files (dazim_comm_init_files): every collective is staged through the host and a directory all ranks can see -- each
+// rank publishes its buffer as <dir>/ar<seq>.<rank> (written under a temporary name, then renamed), waits for the others' and
+// adds them up in rank order, so that every rank gets the same bits.  Slow (a stream synchronisation and a few file operations
+// per collective) and only there so that the WHOLE multi-rank path -- the library's sharded LSMR, the sharded host program --
+// runs with two or three processes on a box with ONE GPU, where RCCL refuses a device used twice (tests/test_multirank_files_gpu.py).
+struct DzComm {
+  ncclComm_t nccl = nullptr;
+  std::string dir;        // non-empty: the file transport
+  unsigned seq = 0;
+  int nranks = 1, rank = 0;
+};
+enum { DZ_F32 = 0, DZ_F64 = 1, DZ_I64 = 2, DZ_SUM = 0, DZ_MAX = 1 };
+static int dz_files_allreduce(dazim_ctx *ctx, DzComm *c, void *host, size_t count, int dtype, int op) {
+  const size_t esz = dtype == DZ_F32 ? 4 : 8, bytes = count * esz;
+  const unsigned seq = ++c->seq;
+  auto path = [&](unsigned s_, int r) { return c->dir + "/ar" + std::to_string(s_) + "." + std::to_string(r); };
+  {
+    const std::string tmp = path(seq, c->rank) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f || fwrite(host, 1, bytes, f) != bytes) { if (f) fclose(f); return dz_fail(ctx, -2100, "file transport: cannot write %s", tmp.c_str()); }
+    fclose(f);
+    if (rename(tmp.c_str(), path(seq, c->rank).c_str()) != 0) return dz_fail(ctx, -2100, "file transport: cannot publish %s", tmp.c_str());
+  }
+  std::vector<char> acc(bytes), in(bytes);
+  for (int r = 0; r < c->nranks; r++) {   // rank order: the same sum on every rank
+    const std::string pr = path(seq, r);
+    FILE *f = nullptr;
+    for (int spin = 0; spin < 600000 && !(f = fopen(pr.c_str(), "rb")); spin++) usleep(200);   // <= 120 s
+    if (!f) return dz_fail(ctx, -2101, "file transport: rank %d never published collective %u (%s)", r, seq, pr.c_str());
+    const size_t got = fread(in.data(), 1, bytes, f);
+    fclose(f);
+    if (got != bytes) return dz_fail(ctx, -2102, "file transport: %s holds %zu bytes, %zu expected (the ranks disagree on a size)", pr.c_str(), got, bytes);
+    if (r == 0) { memcpy(acc.data(), in.data(), bytes); continue; }
+    for (size_t i = 0; i < count; i++) {
+      if (dtype == DZ_F32) { float *a = (float *)acc.data(); const float b = ((const float *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
+      else if (dtype == DZ_F64) { double *a = (double *)acc.data(); const double b = ((const double *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
+      else { long long *a = (long long *)acc.data(); const long long b = ((const long long *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
+    }
+  }
+  memcpy(host, acc.data(), bytes);
+  // every rank has published collective `seq`, hence finished reading collective seq - 1: this rank's file of it can go
+  if (seq > 1) (void)remove(path(seq - 1, c->rank).c_str());
+  return 0;
+}
+// in-place all-reduce of a DEVICE buffer on the context's stream (RCCL), or staged through the host (files)
+static int dz_allreduce(dazim_ctx *ctx, DzComm *c, void *dbuf, size_t count, int dtype, int op) {
+  if (c->dir.empty()) {
+    const ncclDataType_t t = dtype == DZ_F32 ? ncclFloat : (dtype == DZ_F64 ? ncclDouble : ncclInt64);
+    const ncclResult_t r = ncclAllReduce(dbuf, dbuf, count, t, op == DZ_SUM ? ncclSum : ncclMax, c->nccl, ctx->stream);
+    if (r != ncclSuccess) return dz_fail(ctx, -2000 - (int)r, "ncclAllReduce -> %s", ncclGetErrorString(r));
+    return 0;
+  }
+  const size_t bytes = count * (dtype == DZ_F32 ? 4 : 8);
+  std::vector<char> h(bytes);
+  DZ_HIP(hipMemcpyAsync(h.data(), dbuf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  const int rc = dz_files_allreduce(ctx, c, h.data(), count, dtype, op);
+  if (rc) return rc;
+  DZ_HIP(hipMemcpyAsync(dbuf, h.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+static void dz_comm_group(DzComm *c, bool begin) {
+  if (c->dir.empty()) { if (begin) (void)ncclGroupStart(); else (void)ncclGroupEnd(); }
+}
+
 int dazim_comm_unique_id(void *id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   if (!id128) return DAZIM_E_BAD_ARG;
@@ -1763,8 +1836,25 @@ int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128) {
   memcpy(&id, id128, sizeof id);
   ncclComm_t comm;
   DZ_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
-  ctx->comm = (void *)comm;
-  ctx->comm_release = [](dazim_ctx *c) { (void)dazim_comm_free(c); };
+  DzComm *c = new DzComm;
+  c->nccl = comm;
+  c->nranks = nranks;
+  c->rank = rank;
+  ctx->comm = (void *)c;
+  ctx->comm_release = [](dazim_ctx *cx) { (void)dazim_comm_free(cx); };
+  ctx->nranks = nranks;
+  ctx->rank = rank;
+  return 0;
+}
+int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir) {
+  if (!ctx || !dir || !dir[0] || nranks < 1 || rank < 0 || rank >= nranks) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_init_files");
+  if (ctx->comm) return dz_fail(ctx, DAZIM_E_BAD_ARG, "a communicator is already attached");
+  DzComm *c = new DzComm;
+  c->dir = dir;
+  c->nranks = nranks;
+  c->rank = rank;
+  ctx->comm = (void *)c;
+  ctx->comm_release = [](dazim_ctx *cx) { (void)dazim_comm_free(cx); };
   ctx->nranks = nranks;
   ctx->rank = rank;
   return 0;
@@ -1772,12 +1862,42 @@ int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128) {
 int dazim_comm_free(dazim_ctx *ctx) {
   if (!ctx) return DAZIM_E_BAD_ARG;
   if (ctx->comm) {
+    DzComm *c = (DzComm *)ctx->comm;
     DZ_HIP(hipStreamSynchronize(ctx->stream));
-    DZ_NCCL(ncclCommDestroy((ncclComm_t)ctx->comm));
+    if (c->nccl) DZ_NCCL(ncclCommDestroy(c->nccl));
+    delete c;
   }
   ctx->comm = nullptr;
   ctx->nranks = 1;
   ctx->rank = 0;
+  return 0;
+}
+// sum / max over the ranks of `count` values, in place; buf is a host or a device pointer.  dtype: 0 fp32, 1 fp64, 2 int64; op: 0 sum,
+// 1 max.  Without a communicator (one rank) nothing happens.  What the sharded host program reduces with: residual statistics,
+// column sums, the predicted times it writes out.
+int dazim_comm_allreduce(dazim_ctx *ctx, void *buf, int64_t count, int dtype, int op) {
+  if (!ctx || !buf || count < 0 || dtype < 0 || dtype > 2 || op < 0 || op > 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_allreduce");
+  if (!ctx->comm || count == 0) return 0;
+  DzComm *c = (DzComm *)ctx->comm;
+  DZ_HIP(hipSetDevice(ctx->device));
+  hipPointerAttribute_t at;
+  const bool dev = hipPointerGetAttributes(&at, buf) == hipSuccess && at.type == hipMemoryTypeDevice;
+  if (!dev) (void)hipGetLastError();
+  const size_t bytes = (size_t)count * (dtype == DZ_F32 ? 4 : 8);
+  if (dev) {
+    const int rc = dz_allreduce(ctx, c, buf, (size_t)count, dtype, op);
+    if (rc) return rc;
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
+  if (!c->dir.empty()) return dz_files_allreduce(ctx, c, buf, (size_t)count, dtype, op);
+  void *p;
+  int rc;
+  if ((rc = dz_scratch(ctx, "comm.stage", bytes, &p))) return rc;
+  DZ_HIP(hipMemcpyAsync(p, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = dz_allreduce(ctx, c, p, (size_t)count, dtype, op))) return rc;
+  DZ_HIP(hipMemcpyAsync(buf, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
@@ -1794,7 +1914,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   const int64_t m = A->m, n = A->n;
   DzBuf<float> b, x;
   int rc;
-  ncclComm_t comm = (ncclComm_t)ctx->comm;   // non-null: A, b are this rank's rows of one global system
+  DzComm *comm = (DzComm *)ctx->comm;   // non-null: A, b are this rank's rows of one global system
   void *p;
   double *d_sum = nullptr;
   long long *d_cons = nullptr;
@@ -1857,7 +1977,8 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   // (every pending and future collective on it returns an error on every rank) and detach it
   auto leave = [&](int code) -> int {
     if (comm) {
-      (void)ncclCommAbort(comm);
+      if (comm->nccl) (void)ncclCommAbort(comm->nccl);
+      delete comm;
       ctx->comm = nullptr;
       ctx->nranks = 1;
       ctx->rank = 0;
@@ -1872,13 +1993,13 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     if (!dv) return leave(rc ? rc : dz_fail(ctx, -3, "row-sharded LSMR: no memory for the consensus buffer"));
     (void)hipMemcpyAsync(dv, hv, sizeof hv, hipMemcpyHostToDevice, ctx->stream);
     (void)hipMemcpyAsync(dv + 4, &hm, 8, hipMemcpyHostToDevice, ctx->stream);
-    ncclResult_t r1 = ncclAllReduce(dv, dv, 3, ncclInt64, ncclMax, comm, ctx->stream);
-    ncclResult_t r2 = ncclAllReduce(dv + 4, dv + 4, 1, ncclDouble, ncclSum, comm, ctx->stream);
+    const int r1 = dz_allreduce(ctx, comm, dv, 3, DZ_I64, DZ_MAX);
+    const int r2 = dz_allreduce(ctx, comm, dv + 4, 1, DZ_F64, DZ_SUM);
     (void)hipMemcpyAsync(hv, dv, sizeof hv, hipMemcpyDeviceToHost, ctx->stream);
     (void)hipMemcpyAsync(&hm, dv + 4, 8, hipMemcpyDeviceToHost, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (rc) return rc;
-    if (r1 != ncclSuccess || r2 != ncclSuccess || e != hipSuccess) return dz_fail(ctx, -2000, "row-sharded LSMR: consensus all-reduce failed");
+    if (r1 != 0 || r2 != 0 || e != hipSuccess) return dz_fail(ctx, -2000, "row-sharded LSMR: consensus all-reduce failed");
     if (hv[0]) return dz_fail(ctx, -2001, "row-sharded LSMR: another rank failed during set-up");
     if (hv[1] != -hv[2]) return dz_fail(ctx, DAZIM_E_BAD_ARG, "row-sharded LSMR: the ranks disagree on the number of columns (%lld here, %lld elsewhere)", (long long)n, hv[1]);
     m_glob = (int64_t)hm;
@@ -1918,7 +2039,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   auto norm_to_host = [&](const double *pp, int np, float *res, bool rowwise = false) -> int {
     if (comm && rowwise) {
       hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, d_sum);
-      DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
+      { const int rr = dz_allreduce(ctx, comm, d_sum, 1, DZ_F64, DZ_SUM); if (rr) return rr; }
       hipLaunchKernelGGL(k_sqrt_sum, dim3(1), dim3(1), 0, ctx->stream, d_sum, d_scal);
     } else {
       hipLaunchKernelGGL(finish_norm, dim3(1), dim3(64), 0, ctx->stream, pp, np, d_scal, (double *)nullptr);
@@ -1937,7 +2058,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
     int r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr, g);
     if (r) return r;
-    DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
+    { const int rr = dz_allreduce(ctx, comm, wbuf, (size_t)n, DZ_F32, DZ_SUM); if (rr) return rr; }
     hipLaunchKernelGGL(k_axpby_norm, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, v, beta_p, sign, part, g);
     gn_t = bn;
     return 0;
@@ -2007,10 +2128,10 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
         if ((r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr, g1))) return r;
         hipLaunchKernelGGL(k_scale_by, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, d_bp, g1);
         if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
-        DZ_NCCL(ncclGroupStart());
-        DZ_NCCL(ncclAllReduce(wbuf, wbuf, n, ncclFloat, ncclSum, comm, ctx->stream));
-        DZ_NCCL(ncclAllReduce(d_sum, d_sum, 1, ncclDouble, ncclSum, comm, ctx->stream));
-        DZ_NCCL(ncclGroupEnd());
+        dz_comm_group(comm, true);
+        const int ra = dz_allreduce(ctx, comm, wbuf, (size_t)n, DZ_F32, DZ_SUM), rb = dz_allreduce(ctx, comm, d_sum, 1, DZ_F64, DZ_SUM);
+        dz_comm_group(comm, false);
+        if (ra || rb) return ra ? ra : rb;
         hipLaunchKernelGGL(k_beta_axpby, dim3(bmn), dim3(VB), 0, ctx->stream, m, u, n, v, wbuf, d_sum, d_bp, slot, part, S);
         gn_t = bmn;
       } else {
@@ -2109,8 +2230,10 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   ctx->ksec["lsmr.collectives_per_iteration"] = comm ? 1.0 : 0.0;   // (a grouped all-reduce: the n floats of A^T u and the double ||u_p||^2)
   {
     int nr = 1;
-    if (comm) (void)ncclCommCount(comm, &nr);
-    ctx->ksec["lsmr.nranks"] = nr;     // ranks the RCCL communicator of this solve really has
+    if (comm && comm->nccl) (void)ncclCommCount(comm->nccl, &nr);
+    else if (comm) nr = comm->nranks;
+    ctx->ksec["lsmr.nranks"] = nr;     // ranks the communicator of this solve really has
+    ctx->ksec["lsmr.transport"] = comm ? (comm->nccl ? 1.0 : 2.0) : 0.0;   // 1 RCCL, 2 files (tests)
   }
   if (istop_o) *istop_o = istop;
   if (itn_o) *itn_o = itn;

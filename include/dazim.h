@@ -291,11 +291,19 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y
  * dazim_comm_unique_id: rank 0 makes the 128-byte RCCL id and hands it to the other ranks (any transport: MPI,
  * torch.distributed, a file); dazim_comm_init: every rank joins with the same id (ncclCommInitRank on the ctx's device).
  * While a communicator is attached, dazim_lsmr treats A and b as THIS rank's row shard of one global system: per iteration
- * one scalar all-reduce for ||u|| and one ncclAllReduce(sum) of the n fp32 of A_p^T u_p on the ctx stream; x, v, h, hbar and
- * the reorthogonalisation window are replicated, so every rank returns the same x.  dazim_comm_free detaches.       */
+ * ONE grouped ncclAllReduce(sum) on the ctx stream -- the n fp32 of A_p^T u_p and the double ||u_p||^2 (each rank scales its
+ * shard of u by its own norm first; beta follows the collective) --; x, v, h, hbar and the reorthogonalisation window are
+ * replicated, so every rank returns the same x.  dazim_comm_free detaches.                                          */
 int dazim_comm_unique_id(void *id128);
 int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128);
 int dazim_comm_free(dazim_ctx *ctx);
+/* The same communicator over FILES in a directory every rank sees (each collective staged through the host): for tests -- the
+ * whole multi-rank path with two or three processes on ONE GPU, which RCCL refuses -- not for production.                      */
+int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir);
+/* sum (op 0) / max (op 1) over the ranks of `count` values in place; buf: host or device pointer; dtype 0 fp32, 1 fp64, 2 int64.
+ * No communicator attached: nothing happens.  What a sharded host program reduces its statistics and outputs with
+ * (host/dazim_main.f90, DAZIM_NGPU; the reference has no counterpart: inv/Main_Jt.f90 is one process).                         */
+int dazim_comm_allreduce(dazim_ctx *ctx, void *buf, int64_t count, int dtype, int op);
 
 /* = LSMR (inv/lsmrModule.f90:36), fp32 like the reference; b[m] in, x[n] out.                     */
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,

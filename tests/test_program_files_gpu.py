@@ -303,8 +303,8 @@ def test_inversion_program_on_test4_yunnan_matches_the_reference_program(tmp_pat
     check("test4", got, ref, spec)
 
 
-# measured on MI355X (round 4), max |ours - reference program| over the whole file (the golden's DAzimSurfTomo ran with 6 OpenMP
-# threads in depthkernel, 1 098 s): Vs 1e-4 km/s = one unit of the last printed digit in DSurfTomo.inv, MOD_Ref and Gc_Gs_model.inv,
+# measured on MI355X (round 4), max |ours - reference program| over the whole file (the golden's DAzimSurfTomo runs with ONE OpenMP
+# thread, the documented recipe, 3 918 s; round 4's 6-thread file was byte-identical in every output file): Vs 1e-4 km/s = one unit of the last printed digit in DSurfTomo.inv, MOD_Ref and Gc_Gs_model.inv,
 # Gc/L 1.1e-3 %, Gs/L 7e-4 %, period maps <= 2e-5, period_phaseVMOD.dat identical, lsmr.txt 4.3e-4 relative on the first ten
 # iterations of each of the five solves.  Bars = 2 x measured (compare_text adds one unit of the last printed digit).
 T4_SPEC = {
