@@ -1256,21 +1256,22 @@ __global__ __launch_bounds__(256) void k_threshold_rows(int64_t m, const int64_t
   if (!FILL && lane == 0) cnt[r] = kept;
 }
 
-__global__ void k_tikh_count(int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, long *cnt) {
+// (r0: the first regularisation row of this call -- a rank of a row-sharded run appends its share [r0, r0 + nrow) of them)
+__global__ void k_tikh_count(int64_t r0, int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, long *cnt) {
   const int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x;
   if (r > nrow) return;
   int i, j, k;
-  cnt[r] = r == nrow ? 0 : (tikh_face((int)(r % maxvp), nvx, nvz, nzm1, i, j, k) ? 1 : 7);
+  cnt[r] = r == nrow ? 0 : (tikh_face((int)((r0 + r) % maxvp), nvx, nvz, nzm1, i, j, k) ? 1 : 7);
 }
 // entries written with ascending columns (the canonical order every other row of the matrix has)
-__global__ void k_tikh_fill(int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, const long *off, int64_t nnz0,
+__global__ void k_tikh_fill(int64_t r0, int64_t nrow, int maxvp, int nvx, int nvz, int nzm1, const long *off, int64_t nnz0,
                             const float *__restrict__ w, int64_t *__restrict__ rowptr, int *__restrict__ col,
                             float *__restrict__ val) {
   const int64_t r = (int64_t)blockIdx.x * VB + threadIdx.x;
   if (r > nrow) return;
   rowptr[r] = nnz0 + off[r];
   if (r == nrow) return;
-  const int blk = (int)(r / maxvp), cell = (int)(r - (int64_t)blk * maxvp);
+  const int blk = (int)((r0 + r) / maxvp), cell = (int)((r0 + r) - (int64_t)blk * maxvp);
   int i, j, k;
   const bool face = tikh_face(cell, nvx, nvz, nzm1, i, j, k);
   const float wt = w[blk];
@@ -1820,6 +1821,7 @@ static void dz_comm_group(DzComm *c, bool begin) {
   if (c->dir.empty()) { if (begin) (void)ncclGroupStart(); else (void)ncclGroupEnd(); }
 }
 
+static int dz_files_or_stage_allreduce(dazim_ctx *ctx, double *host, int count);
 int dazim_comm_unique_id(void *id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   if (!id128) return DAZIM_E_BAD_ARG;
@@ -1899,6 +1901,10 @@ int dazim_comm_allreduce(dazim_ctx *ctx, void *buf, int64_t count, int dtype, in
   DZ_HIP(hipMemcpyAsync(buf, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
+}
+
+static int dz_files_or_stage_allreduce(dazim_ctx *ctx, double *host, int count) {   // sum of a few host doubles over the ranks
+  return dazim_comm_allreduce(ctx, host, count, DZ_F64, DZ_SUM);
 }
 
 // LSMR, inv/lsmrModule.f90:36-750.  Vectors AND scalars live on the device (LsmrState above); the host enqueues
@@ -2262,9 +2268,16 @@ int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, float damp,
 // = TikhonovRegularization / TikhRegul_joint (inv/TikhRegul.f90:2-104, :107-209): nblock*maxvp rows appended to the resident
 // matrix, generated on the device (block b regularises columns b*maxvp+1.., weight w[b])
 int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int nz, int nblock, const float *w_host) {
+  if (nblock < 1 || nx < 3 || ny < 3 || nz < 2) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_append_tikhonov");
+  return dazim_csr_append_tikhonov_rows(ctx, A, nx, ny, nz, nblock, w_host, 0, (int64_t)(nx - 2) * (ny - 2) * (nz - 1) * nblock);
+}
+// rows [row_lo, row_hi) of the same nblock*maxvp regularisation rows: the share of one rank of a row-sharded system
+int dazim_csr_append_tikhonov_rows(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int nz, int nblock, const float *w_host,
+                                   int64_t row_lo, int64_t row_hi) {
   if (!ctx || !A || !w_host || nblock < 1 || nx < 3 || ny < 3 || nz < 2) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_csr_append_tikhonov");
   const int nvx = nx - 2, nvz = ny - 2, nzm1 = nz - 1;
-  const int64_t maxvp = (int64_t)nvx * nvz * nzm1, nrow = maxvp * nblock;
+  const int64_t maxvp = (int64_t)nvx * nvz * nzm1, nrow = row_hi - row_lo;
+  if (row_lo < 0 || row_hi < row_lo || row_hi > maxvp * nblock) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad row range of the regularisation block");
   if (maxvp * nblock > A->n || maxvp > 0x7ffffff0) return dz_fail(ctx, DAZIM_E_BAD_ARG, "regularisation blocks do not fit the %lld columns", (long long)A->n);
   DZ_HIP(hipSetDevice(ctx->device));
   int rc;
@@ -2278,7 +2291,7 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   if (nblock > 64) return dz_fail(ctx, DAZIM_E_BAD_ARG, "too many regularisation blocks");
   DZ_HIP(hipMemcpyAsync(dw, w_host, (size_t)nblock * 4, hipMemcpyHostToDevice, ctx->stream));
   const unsigned nb = (unsigned)((nrow + 1 + VB - 1) / VB);
-  hipLaunchKernelGGL(k_tikh_count, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, cnt);
+  hipLaunchKernelGGL(k_tikh_count, dim3(nb), dim3(VB), 0, ctx->stream, row_lo, nrow, (int)maxvp, nvx, nvz, nzm1, cnt);
   size_t tb = 0;
   DZ_HIP(rocprim::exclusive_scan(nullptr, tb, cnt, off, 0l, (size_t)(nrow + 1), rocprim::plus<long>(), ctx->stream));
   if ((rc = dz_scratch(ctx, "tikh.scan", tb + 256, &p))) return rc;
@@ -2290,7 +2303,7 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   if (nz2 > 0xfffffff0ll) return dz_fail(ctx, DAZIM_E_NNZ_OVERFLOW, "too many stored entries");
   if (A->cap_m >= m2 && A->cap_nnz >= nz2) {   // dazim_rays_build_G left room for these rows: generate them behind the ray rows
     const int64_t nnz1 = A->nnz;
-    hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
+    hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, row_lo, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
                        A->rowptr + A->m, A->col, A->val);
     DZ_HIP(hipGetLastError());
     A->m = m2;
@@ -2309,7 +2322,7 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
   DZ_HIP(hipMemcpyAsync(rowptr, A->rowptr, (size_t)A->m * 8, hipMemcpyDeviceToDevice, ctx->stream));
   DZ_HIP(hipMemcpyAsync(col, A->col, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
   DZ_HIP(hipMemcpyAsync(val, A->val, (size_t)A->nnz * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
+  hipLaunchKernelGGL(k_tikh_fill, dim3(nb), dim3(VB), 0, ctx->stream, row_lo, nrow, (int)maxvp, nvx, nvz, nzm1, off, A->nnz, dw,
                      rowptr + A->m, col, val);
   DZ_HIP(hipGetLastError());
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -2331,8 +2344,17 @@ int dazim_csr_append_tikhonov(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int 
 // mean weight; mean |weighted residual|.
 int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *obst_u, const float *dsyn_u, float *res_u,
                       float *wgt_u, float *rhs_u, float *stats) {
-  if (!ctx || dall < 1 || !obst_u || !dsyn_u || !res_u || !wgt_u || !rhs_u || (G && G->m < dall))
+  return dazim_weight_data_sharded(ctx, G, dall, 0, dall, obst_u, dsyn_u, res_u, wgt_u, rhs_u, stats);
+}
+// The same for one rank's data rows [row0, row0 + dall) of dall_glob (communicator attached): meandeltaT / stddeltaT are the
+// reference's two sequential fp32 sums over ALL data, so the relative residuals of all ranks are put together first (an
+// all-reduce of the zero-padded vector: exact, every other rank adds zeros) and every rank runs the same sums; the statistics
+// returned are those of the whole data set.
+int dazim_weight_data_sharded(dazim_ctx *ctx, dazim_csr *G, int64_t dall, int64_t row0, int64_t dall_glob, const float *obst_u,
+                              const float *dsyn_u, float *res_u, float *wgt_u, float *rhs_u, float *stats) {
+  if (!ctx || dall < 1 || !obst_u || !dsyn_u || !res_u || !wgt_u || !rhs_u || (G && G->m < dall) || row0 < 0 || row0 + dall > dall_glob)
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_weight_data");
+  const bool sharded = ctx->comm && dall_glob > dall;
   DZ_HIP(hipSetDevice(ctx->device));
   DzBuf<float> obst, dsyn, res, wgt, rhs;
   int rc;
@@ -2349,7 +2371,16 @@ int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *o
   double *part = (double *)p;
   const int nb = nblk(dall, NPART);
   hipLaunchKernelGGL(k_residual, dim3(nb), dim3(VB), 0, ctx->stream, dall, obst.dev, dsyn.dev, res.dev, rel);
-  hipLaunchKernelGGL(k_sigma_stats, dim3(1), dim3(VB), 0, ctx->stream, dall, rel, ms);
+  if (sharded) {
+    if ((rc = dz_scratch(ctx, "wd.relg", (size_t)dall_glob * 4, &p))) return rc;
+    float *relg = (float *)p;
+    DZ_HIP(hipMemsetAsync(relg, 0, (size_t)dall_glob * 4, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(relg + row0, rel, (size_t)dall * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = dz_allreduce(ctx, (DzComm *)ctx->comm, relg, (size_t)dall_glob, DZ_F32, DZ_SUM))) return rc;
+    hipLaunchKernelGGL(k_sigma_stats, dim3(1), dim3(VB), 0, ctx->stream, dall_glob, relg, ms);
+  } else {
+    hipLaunchKernelGGL(k_sigma_stats, dim3(1), dim3(VB), 0, ctx->stream, dall, rel, ms);
+  }
   hipLaunchKernelGGL(k_sigma_weights, dim3(nb), dim3(VB), 0, ctx->stream, dall, obst.dev, res.dev, rel, ms, wgt.dev, rhs.dev);
   hipLaunchKernelGGL(k_weight_sums, dim3(nb), dim3(VB), 0, ctx->stream, dall, res.dev, wgt.dev, rhs.dev, part);
   DZ_HIP(hipGetLastError());
@@ -2368,7 +2399,8 @@ int dazim_weight_data(dazim_ctx *ctx, dazim_csr *G, int64_t dall, const float *o
     double a[5] = {0, 0, 0, 0, 0};
     for (int b = 0; b < nb; b++)
       for (int q = 0; q < 5; q++) a[q] += hp[(size_t)b * 5 + q];
-    const double n = (double)dall, mean = a[0] / n;
+    if (sharded && (rc = dz_files_or_stage_allreduce(ctx, a, 5))) return rc;
+    const double n = (double)dall_glob, mean = a[0] / n;
     stats[0] = (float)mean;
     stats[1] = (float)sqrt(fmax(a[2] / n - mean * mean, 0.0));
     stats[2] = (float)(a[1] / n);

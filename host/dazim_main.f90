@@ -44,6 +44,13 @@ program DAzimSurfTomo_amd
   real :: wstats(8)
   real, allocatable :: ustats(:, :, :)       ! (3: min, max, sum |.| ; nz-1 ; block) of the update, from dazim_model_update
   integer(8) :: tk0, tk1, tkrate
+  ! several GPUs (one process per GPU, dazim_ranks_init): this rank's contiguous share of the (period, source) fields -- its
+  ! sources with their receivers (the *_l arrays, what the G assembly sees), its dloc data rows starting behind row d0 of the dall,
+  ! its rows [treg0, treg1) of the regularisation block.  Everything the diagnostics and the output files read (dsyn, Tdata,
+  ! datweight, fwdTvs, fwdTaa, the DWS) is put together over the ranks, so that every rank writes the same files.
+  real, allocatable :: scxf_l(:, :), sczf_l(:, :), rcxf_l(:, :, :), rczf_l(:, :, :), dsyn_l(:)
+  integer, allocatable :: periods_l(:, :), nrc1_l(:, :), nsrc1_l(:), wfield(:)
+  integer :: nfield_all, f0, f1, fidx, d0, dloc, sl, treg0, treg1, nregblk
   real(8) :: tph(9) = 0                      ! wall seconds per phase, printed when DAZIM_TIMING is set (tools/run_test4_program.sh)
   character(len=8) :: timing_env
 
@@ -210,7 +217,41 @@ program DAzimSurfTomo_amd
 
   allocate (ustats(3, nz - 1, 3))
   call tick(1)                               ! inputs read
-  call dazim_init(0)
+  call dazim_ranks_init()
+  ! ---- this rank's share of the fields (all of them with one rank) ----
+  nfield_all = sum(nsrc1(1:kmax))
+  allocate (wfield(max(nfield_all, 1)))
+  fidx = 0
+  do k = 1, kmax
+    do i = 1, nsrc1(k)
+      fidx = fidx + 1
+      wfield(fidx) = nrc1(i, k)
+    end do
+  end do
+  call dazim_shard_fields(nfield_all, wfield, dazim_nranks, dazim_rank, f0, f1)
+  allocate (scxf_l(nsrc, kmax), sczf_l(nsrc, kmax), rcxf_l(nrc, nsrc, kmax), rczf_l(nrc, nsrc, kmax))
+  allocate (periods_l(nsrc, kmax), nrc1_l(nsrc, kmax), nsrc1_l(kmax))
+  scxf_l = 0; sczf_l = 0; rcxf_l = 0; rczf_l = 0; periods_l = 0; nrc1_l = 0; nsrc1_l = 0
+  fidx = 0; d0 = 0; dloc = 0
+  do k = 1, kmax
+    do i = 1, nsrc1(k)
+      if (fidx >= f0 .and. fidx < f1) then
+        nsrc1_l(k) = nsrc1_l(k) + 1
+        sl = nsrc1_l(k)
+        scxf_l(sl, k) = scxf(i, k); sczf_l(sl, k) = sczf(i, k)
+        rcxf_l(:, sl, k) = rcxf(:, i, k); rczf_l(:, sl, k) = rczf(:, i, k)
+        periods_l(sl, k) = periods(i, k); nrc1_l(sl, k) = nrc1(i, k)
+        dloc = dloc + nrc1(i, k)
+      else if (fidx < f0) then
+        d0 = d0 + nrc1(i, k)
+      end if
+      fidx = fidx + 1
+    end do
+  end do
+  if (dloc < 1) stop 'this rank has no data: more ranks than (period, source) fields'
+  allocate (dsyn_l(dloc))
+  if (dazim_nranks > 1) write (*, '(a,i3,a,i3,a,i8,a,i8,a,i8)') '  rank ', dazim_rank, ' of ', dazim_nranks, ': fields ', f0 + 1, ' ..', f1, &
+    ', data rows ', dloc
   call tick(2)                               ! HIP context
   open (34, file='IterVel.out')
   do iter = 1, maxiter
@@ -237,9 +278,11 @@ program DAzimSurfTomo_amd
     ! |fdm| >= ftol, the dVs block with the Brocher derivatives left over from the last such cell (:1369-1378).  Option
     ! rays.dense_twin makes the library build that second matrix from the same cell lists: Gd, resident, never scaled.
     call dazim_check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 1_c_int), 'option')
-    call dazim_assemble_G(.not. iso_mod, nx, ny, nz, vsf, dsyn, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods, depz, &
-                          minthk, scxf, sczf, rcxf, rczf, nrc1, nsrc1, kmax, nsrc, nrc, G, nar, pv, &
+    call dazim_assemble_G(.not. iso_mod, nx, ny, nz, vsf, dsyn_l, Lsen_Gsc, goxd, gozd, dvxd, dvzd, kmaxRc, tRc, periods_l, depz, &
+                          minthk, scxf_l, sczf_l, rcxf_l, rczf_l, nrc1_l, nsrc1_l, kmax, nsrc, nrc, G, nar, pv, &
                           ti_here=(.not. iso_mod .and. ti_kernels_on_device()))
+    dsyn(d0 + 1:d0 + dloc) = dsyn_l(1:dloc)   ! (dsyn = 0 above: the other ranks' predicted times arrive with the sum)
+    call dazim_allsum(dsyn, dall)
     call dazim_check(dazim_set_option(dazim_handle, 'rays.dense_twin'//c_null_char, 0_c_int), 'option')
     call dazim_check(dazim_csr_take_twin(dazim_handle, G, Gd), 'dense twin')
     if (.not. iso_mod) then                       ! inv/CalSurfGAniso_Joint.f90:801-811 (the iso branch leaves tRcV = 0)
@@ -260,8 +303,14 @@ program DAzimSurfTomo_amd
 
     ! ---- residuals, CalDdatSigma weights, weighted right-hand side and row scaling on the device, inv/Main_Jt.f90:432-470 ----
     cbst = 0                                  ! (the rows of the regularisation block keep a zero right-hand side)
-    call dazim_check(dazim_weight_data(dazim_handle, G, int(dall, c_int64_t), obst, dsyn, Tdata, datweight, cbst, wstats), &
+    if (dazim_nranks > 1) then
+      Tdata = 0; datweight = 0
+    end if
+    call dazim_check(dazim_weight_data_sharded(dazim_handle, G, int(dloc, c_int64_t), int(d0, c_int64_t), int(dall, c_int64_t), &
+                                               obst(d0 + 1:), dsyn(d0 + 1:), Tdata(d0 + 1:), datweight(d0 + 1:), cbst, wstats), &
                      'data weights')
+    call dazim_allsum(Tdata, dall)
+    call dazim_allsum(datweight, dall)
     meandeltaT = wstats(5)
     write (6, '(a, f12.4,a,f10.2,a,f10.2,a)') '  Before Inversion: abs mean, std, RMS of Res:', wstats(3), ' s ', &
       wstats(2), ' s ', wstats(4), ' s'
@@ -271,7 +320,10 @@ program DAzimSurfTomo_amd
       ' |  abs data mean with weight:', wstats(8), 's  |  dt/t0:', meandeltaT*100, ' %'
     write (66, '(a, f8.3, a, f8.3,a, f7.3, a)') '  mean data weight:', wstats(7), &
       ' |  abs data mean with weight:', wstats(8), 's  |  dt/t0:', meandeltaT*100, ' %'
-    if (iso_mod) call dazim_check(dazim_csr_col_abs_sums(dazim_handle, G, norm), 'DWS')   ! inv/Main_Jt.f90:477-481
+    if (iso_mod) then
+      call dazim_check(dazim_csr_col_abs_sums(dazim_handle, G, norm), 'DWS')   ! inv/Main_Jt.f90:477-481
+      call dazim_allsum(norm, maxvp)
+    end if
 
     call tick(4)                             ! residuals, weights, row scaling, DWS
     ! ---- regularisation rows appended to the resident matrix, inv/Main_Jt.f90:483-500 ----------------------------
@@ -287,11 +339,14 @@ program DAzimSurfTomo_amd
     end if
     nar = nar1 + nreg
     if (int(nar, 8) > maxnar) stop 'increase sparsity fraction(spfra)'                   ! inv/Main_Jt.f90:523
+    nregblk = merge(1, 3, iso_mod)
+    call dazim_shard_rows(nregblk*maxvp, dazim_nranks, dazim_rank, treg0, treg1)   ! (all of them with one rank)
     if (iso_mod) then
-      call dazim_check(dazim_csr_append_tikhonov(dazim_handle, G, nx, ny, nz, 1_c_int, [weightVs]), 'Tikhonov rows')
+      call dazim_check(dazim_csr_append_tikhonov_rows(dazim_handle, G, nx, ny, nz, 1_c_int, [weightVs], int(treg0, c_int64_t), &
+                                                      int(treg1, c_int64_t)), 'Tikhonov rows')
     else
-      call dazim_check(dazim_csr_append_tikhonov(dazim_handle, G, nx, ny, nz, 3_c_int, [weightVs, weightGcs, weightGcs]), &
-                       'Tikhonov rows')
+      call dazim_check(dazim_csr_append_tikhonov_rows(dazim_handle, G, nx, ny, nz, 3_c_int, [weightVs, weightGcs, weightGcs], &
+                                                      int(treg0, c_int64_t), int(treg1, c_int64_t)), 'Tikhonov rows')
     end if
     write (*, '(a,3f8.2)') '  damp,  lamebda Gsc, lamebda Vs: ', damp, weightGcs, weightVs
     write (66, '(a,3f8.2)') '  damp,  lamebda Gsc, lamebda Vs: ', damp, weightGcs, weightVs
@@ -577,15 +632,18 @@ contains
     real :: mabs
     allocate (resW(dall))
     xtmp(1:n) = 0; xtmp(1:maxvp) = dv(1:maxvp)
-    yfull(1:dall) = 0
+    yfull(1:dloc) = 0                         ! (Gd holds this rank's data rows; the sum over the ranks puts the vector together)
     call dazim_check(dazim_aprod(dazim_handle, 1, Gd, xtmp, yfull), 'aprod')
-    fwdTvs(1:dall) = yfull(1:dall)
+    fwdTvs = 0
+    fwdTvs(d0 + 1:d0 + dloc) = yfull(1:dloc)
+    call dazim_allsum(fwdTvs, dall)
     fwdTaa = 0
     if (.not. iso_mod) then
       xtmp(1:n) = dv(1:n); xtmp(1:maxvp) = 0
-      yfull(1:dall) = 0
+      yfull(1:dloc) = 0
       call dazim_check(dazim_aprod(dazim_handle, 1, Gd, xtmp, yfull), 'aprod')
-      fwdTaa(1:dall) = yfull(1:dall)
+      fwdTaa(d0 + 1:d0 + dloc) = yfull(1:dloc)
+      call dazim_allsum(fwdTaa, dall)
     end if
     do q = 1, dall
       resbst(q) = Tdata(q) - fwdTaa(q) - fwdTvs(q)

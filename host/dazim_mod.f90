@@ -26,6 +26,11 @@ module dazim_mod
   public :: dazim_lsen_gsc, dazim_assemble_G, dazim_check, dazim_set_option, dazim_csr_scale_rows, dazim_csr_append_coo, dazim_csr_col_abs_sums, &
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
             dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin, dazim_ray_paths_dims, dazim_ray_paths_copy
+  ! several GPUs: one process per GPU (DAZIM_NGPU / DAZIM_RANK), rows of [G; L] sharded over them, see dazim_ranks_init
+  public :: dazim_comm_unique_id, dazim_comm_init, dazim_comm_init_files, dazim_comm_free, dazim_comm_allreduce, &
+            dazim_csr_append_tikhonov_rows, dazim_weight_data_sharded, dazim_ranks_init, dazim_nranks, dazim_rank, &
+            dazim_shard_fields, dazim_shard_rows, dazim_allsum
+  integer, save :: dazim_nranks = 1, dazim_rank = 0
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
   ! the matrix of the last aprod call (see aprod) and how often it had to be (re)built
@@ -211,6 +216,47 @@ module dazim_mod
       integer(c_int), value :: nx, ny, nz, nblock
       real(c_float) :: w(*)
     end function
+    integer(c_int) function dazim_csr_append_tikhonov_rows(ctx, A, nx, ny, nz, nblock, w, row_lo, row_hi) &
+        bind(C, name="dazim_csr_append_tikhonov_rows")
+      import
+      type(c_ptr), value :: ctx, A
+      integer(c_int), value :: nx, ny, nz, nblock
+      real(c_float) :: w(*)
+      integer(c_int64_t), value :: row_lo, row_hi
+    end function
+    integer(c_int) function dazim_weight_data_sharded(ctx, G, dall, row0, dall_glob, obst, dsyn, res, datweight, rhs, stats) &
+        bind(C, name="dazim_weight_data_sharded")
+      import
+      type(c_ptr), value :: ctx, G
+      integer(c_int64_t), value :: dall, row0, dall_glob
+      real(c_float) :: obst(*), dsyn(*), res(*), datweight(*), rhs(*), stats(8)
+    end function
+    integer(c_int) function dazim_comm_unique_id(id128) bind(C, name="dazim_comm_unique_id")
+      import
+      character(kind=c_char) :: id128(128)
+    end function
+    integer(c_int) function dazim_comm_init(ctx, nranks, rank, id128) bind(C, name="dazim_comm_init")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nranks, rank
+      character(kind=c_char) :: id128(128)
+    end function
+    integer(c_int) function dazim_comm_init_files(ctx, nranks, rank, dir) bind(C, name="dazim_comm_init_files")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nranks, rank
+      character(kind=c_char) :: dir(*)
+    end function
+    integer(c_int) function dazim_comm_free(ctx) bind(C, name="dazim_comm_free")
+      import
+      type(c_ptr), value :: ctx
+    end function
+    integer(c_int) function dazim_comm_allreduce(ctx, buf, count, dtype, op) bind(C, name="dazim_comm_allreduce")
+      import
+      type(c_ptr), value :: ctx, buf
+      integer(c_int64_t), value :: count
+      integer(c_int), value :: dtype, op
+    end function
     integer(c_int) function dazim_weight_data(ctx, G, dall, obst, dsyn, res, datweight, rhs, stats) bind(C, name="dazim_weight_data")
       import
       type(c_ptr), value :: ctx, G
@@ -262,9 +308,123 @@ contains
     if (dazim_create(dazim_handle, int(device, c_int)) /= 0) stop 'dazim_create failed: no MI355X visible'
   end subroutine
 
+  ! Several GPUs, one process per GPU (the reference is one process: inv/Main_Jt.f90; north_star: "sources shard across the 8 GPUs
+  ! of one node", SURVEY 8e).  Environment: DAZIM_NGPU = number of ranks, DAZIM_RANK = this process (0-based), DAZIM_COMM_DIR = a
+  ! directory all ranks see, DAZIM_TRANSPORT = rccl (default: the 128-byte RCCL id goes from rank 0 to the others through a file in
+  ! that directory) or files (every collective through that directory: tests on a one-GPU box), DAZIM_DEVICE = the GPU of this
+  ! process (default: the rank).  Creates the context on that GPU and attaches the communicator; without DAZIM_NGPU (or with 1 and
+  ! no DAZIM_COMM_DIR) it is dazim_init(0).
+  subroutine dazim_ranks_init()
+    character(len=256) :: val, dir
+    character(len=16) :: transport
+    character(kind=c_char) :: id(128)
+    integer :: device, u, q, ios
+    logical :: ex
+    if (c_associated(dazim_handle)) return
+    dazim_nranks = 1; dazim_rank = 0
+    call get_environment_variable('DAZIM_NGPU', val)
+    if (len_trim(val) > 0) read (val, *) dazim_nranks
+    call get_environment_variable('DAZIM_RANK', val)
+    if (len_trim(val) > 0) read (val, *) dazim_rank
+    device = dazim_rank
+    call get_environment_variable('DAZIM_DEVICE', val)
+    if (len_trim(val) > 0) read (val, *) device
+    call get_environment_variable('DAZIM_COMM_DIR', dir)
+    call get_environment_variable('DAZIM_TRANSPORT', transport)
+    if (dazim_nranks < 1 .or. dazim_rank < 0 .or. dazim_rank >= dazim_nranks) stop 'DAZIM_NGPU / DAZIM_RANK: bad values'
+    call dazim_init(device)
+    if (len_trim(dir) == 0) then
+      if (dazim_nranks > 1) stop 'DAZIM_NGPU > 1 needs DAZIM_COMM_DIR (a directory every rank sees)'
+      return
+    end if
+    if (trim(transport) == 'files') then
+      call check(dazim_comm_init_files(dazim_handle, int(dazim_nranks, c_int), int(dazim_rank, c_int), trim(dir)//c_null_char), 'communicator (files)')
+      return
+    end if
+    if (dazim_rank == 0) then
+      call check(dazim_comm_unique_id(id), 'RCCL id')
+      open (newunit=u, file=trim(dir)//'/rccl_id', access='stream', form='unformatted', status='replace')
+      write (u) id
+      close (u)
+      open (newunit=u, file=trim(dir)//'/rccl_id.ready', status='replace')   ! (the marker appears after the id file is complete)
+      write (u, *) 1
+      close (u)
+    else
+      do q = 1, 600000
+        inquire (file=trim(dir)//'/rccl_id.ready', exist=ex)
+        if (ex) exit
+        call sleep_ms(1)
+      end do
+      if (.not. ex) stop 'rank 0 never published the RCCL id'
+      open (newunit=u, file=trim(dir)//'/rccl_id', access='stream', form='unformatted', status='old', iostat=ios)
+      if (ios /= 0) stop 'cannot read the RCCL id'
+      read (u) id
+      close (u)
+    end if
+    call check(dazim_comm_init(dazim_handle, int(dazim_nranks, c_int), int(dazim_rank, c_int), id), 'communicator (RCCL)')
+  end subroutine
+
+  subroutine sleep_ms(ms)
+    integer, intent(in) :: ms
+    integer(8) :: t0, t1, rate
+    call system_clock(t0, rate)
+    do
+      call system_clock(t1)
+      if (real(t1 - t0, 8)/real(rate, 8) >= 1.0d-3*ms) exit
+    end do
+  end subroutine
+
+  ! the contiguous range [f0, f1) of nfield items with weights w that rank `rank` of `world` takes: the rule of
+  ! dazimsurftomo_amd/distributed.py shard_fields (balanced by weight, contiguous, monotone)
+  subroutine dazim_shard_fields(nfield, w, world, rank, f0, f1)
+    integer, intent(in) :: nfield, w(nfield), world, rank
+    integer, intent(out) :: f0, f1
+    real(8) :: total, target, c
+    integer :: r, i, b(0:world)
+    total = 0
+    do i = 1, nfield
+      total = total + w(i)
+    end do
+    b(0) = 0
+    do r = 1, world
+      target = total*r/world
+      c = 0; b(r) = nfield
+      do i = 0, nfield                          ! first i with c_i >= target, c_i = sum of the first i weights
+        if (i > 0) c = c + w(i)
+        if (c >= target) then
+          b(r) = i
+          exit
+        end if
+      end do
+      if (b(r) < b(r - 1)) b(r) = b(r - 1)
+    end do
+    b(world) = nfield
+    f0 = b(rank); f1 = b(rank + 1)
+  end subroutine
+
+  ! even contiguous split of nrows rows (the regularisation block): shard_rows of distributed.py
+  subroutine dazim_shard_rows(nrows, world, rank, r0, r1)
+    integer, intent(in) :: nrows, world, rank
+    integer, intent(out) :: r0, r1
+    integer :: base, rem
+    base = nrows/world; rem = mod(nrows, world)
+    r0 = rank*base + min(rank, rem)
+    r1 = r0 + base
+    if (rank < rem) r1 = r1 + 1
+  end subroutine
+
+  ! sum over the ranks of a real array, in place (nothing happens with one rank)
+  subroutine dazim_allsum(x, n)
+    integer, intent(in) :: n
+    real, target :: x(n)
+    if (dazim_nranks <= 1 .or. n < 1) return
+    call check(dazim_comm_allreduce(dazim_handle, c_loc(x), int(n, c_int64_t), 0_c_int, 0_c_int), 'all-reduce')
+  end subroutine
+
   subroutine dazim_finalize()
     integer :: q
     integer(c_int) :: rc
+    if (c_associated(dazim_handle)) rc = dazim_comm_free(dazim_handle)
     if (c_associated(dazim_handle)) then
       call dazim_aprod_forget()
       do q = 1, size(fld_ptr)

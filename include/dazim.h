@@ -304,6 +304,14 @@ int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir)
  * No communicator attached: nothing happens.  What a sharded host program reduces its statistics and outputs with
  * (host/dazim_main.f90, DAZIM_NGPU; the reference has no counterpart: inv/Main_Jt.f90 is one process).                         */
 int dazim_comm_allreduce(dazim_ctx *ctx, void *buf, int64_t count, int dtype, int op);
+/* The two N4 calls for one rank's share of a row-sharded system (host/dazim_main.f90 with DAZIM_NGPU): the regularisation rows
+ * [row_lo, row_hi) of the nblock*maxvp (inv/TikhRegul.f90:2-209), and the data weights of the data rows [row0, row0 + dall) of
+ * dall_glob -- meandeltaT / stddeltaT (inv/CalSigamNorm.f90:20-31) are taken over ALL data in the reference's summation order on
+ * every rank, the statistics returned are the whole data set's.                                                                */
+int dazim_csr_append_tikhonov_rows(dazim_ctx *ctx, dazim_csr *A, int nx, int ny, int nz, int nblock, const float *w,
+                                   int64_t row_lo, int64_t row_hi);
+int dazim_weight_data_sharded(dazim_ctx *ctx, dazim_csr *G, int64_t dall, int64_t row0, int64_t dall_glob, const float *obst,
+                              const float *dsyn, float *res, float *wgt, float *rhs, float *stats);
 
 /* = LSMR (inv/lsmrModule.f90:36), fp32 like the reference; b[m] in, x[n] out.                     */
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,

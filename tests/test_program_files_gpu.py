@@ -286,6 +286,101 @@ def test_forward_program_files_match_the_reference_program(tmp_path, tag):
     check(tag, got, ref, spec)
 
 
+def run_ranks(exe, inputs, tmp_path, world, transport="files"):
+    """`world` processes of the host program, one per rank (each in its own directory with its own copy of the inputs), DAZIM_NGPU /
+    DAZIM_RANK / DAZIM_COMM_DIR set; all on GPU 0 with the file transport, rank r on GPU r with RCCL.  Returns every rank's files."""
+    import dazimsurftomo_amd as dz
+    dz.build()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "host"), "all"])
+    comm = tmp_path / "comm"
+    comm.mkdir()
+    procs = []
+    for r in range(world):
+        d = tmp_path / f"rank{r}"
+        d.mkdir()
+        for name, text in inputs.items():
+            (d / name).write_text(text)
+        env = dict(os.environ, DAZIM_NGPU=str(world), DAZIM_RANK=str(r), DAZIM_COMM_DIR=str(comm), DAZIM_TRANSPORT=transport,
+                   DAZIM_DEVICE="0" if transport == "files" else str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([exe, "para.in"], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [(o[0][-1500:], o[1][-1500:]) for o in outs]
+    res = []
+    for r in range(world):
+        files = {"__stdout__": outs[r][0]}
+        for name in sorted(os.listdir(tmp_path / f"rank{r}")):
+            if name not in inputs:
+                files[name] = open(tmp_path / f"rank{r}" / name, errors="replace").read()
+        res.append(files)
+    return res
+
+
+def widened(spec, factor):
+    """the single-process bars x factor: a sharded solve adds its products and norms in another order, and the joint system's LSMR
+    (10-vector window, ~170 iterations) carries that into the fourth digit of Gc / Gs (measured with 2 ranks: Gc 2.1e-2 %, period
+    maps 2.3e-4, against 0.9e-2 / 1.6e-4 single-process)"""
+    def w(b):
+        if callable(b):
+            return lambda v, b=b: factor * b(v)
+        if isinstance(b, bool) or not isinstance(b, (int, float)):
+            return b
+        return factor * b
+    return {name: ({k: w(v) for k, v in cols.items()}, w(default), so) for name, (cols, default, so) in spec.items()}
+
+
+RCCL_BANNER = ("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl path")   # what RCCL prints when a communicator is made
+
+
+def strip_rank_lines(text):
+    return "\n".join(ln for ln in text.splitlines() if not ln.lstrip().startswith(("rank ",) + RCCL_BANNER)) + "\n"
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(INV_EXE), reason="no flang and no prebuilt host")
+@pytest.mark.parametrize("tag,world", [("iso", 2), ("joint", 2), ("joint", 3)])
+def test_inversion_program_sharded_over_ranks_on_one_gpu(tmp_path, tag, world):
+    """The Fortran host with its (period, source) fields sharded over `world` processes (DAZIM_NGPU; host/dazim_main.f90,
+    dazim_ranks_init): rows of [G; L] row-sharded, the library's LSMR with one collective per iteration, statistics and per-datum
+    outputs put together over the ranks -- on ONE GPU through the file transport, so that the N >= 2 program path runs where the
+    tests run.  Every rank writes the same files (compared rank against rank: equal text apart from its own `rank` line and the
+    timing line), and rank 0's files meet the reference program's golden with the single-process bars."""
+    ins, ref = load(tag)
+    res = run_ranks(INV_EXE, ins, tmp_path, world)
+    for r in range(1, world):
+        for name in res[0]:
+            if name in ("__stdout__", "para.in_inv.log"):
+                a = [ln for ln in strip_rank_lines(res[0][name]).splitlines() if "time cost" not in ln]
+                b = [ln for ln in strip_rank_lines(res[r][name]).splitlines() if "time cost" not in ln]
+                assert a == b, (name, r)
+            else:
+                assert res[r][name] == res[0][name], (name, r)
+    got = dict(res[0])
+    got["__stdout__"] = strip_rank_lines(got["__stdout__"])
+    check(f"{tag} x{world}", got, ref, widened(inversion_spec(tag == "joint"), 2.0 if tag == "joint" else 1.0))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(INV_EXE), reason="no flang and no prebuilt host")
+def test_inversion_program_one_rank_through_rccl(tmp_path):
+    """DAZIM_NGPU=1 with a communicator: the same program through the RCCL code (a communicator of one rank, id exchanged through
+    the file) -- what a one-GPU box can run of the RCCL transport"""
+    ins, ref = load("joint")
+    res = run_ranks(INV_EXE, ins, tmp_path, 1, transport="rccl")
+    got = dict(res[0])
+    got["__stdout__"] = strip_rank_lines(got["__stdout__"])
+    check("joint rccl x1", got, ref, inversion_spec(True))
+
+
+def test_inversion_program_two_gpus_rccl(tmp_path):
+    """two processes, two GPUs, RCCL over xGMI (skipped on one-GPU boxes)"""
+    import torch
+    if torch.cuda.device_count() < 2 or not os.path.exists(INV_EXE):
+        pytest.skip("needs >= 2 GPUs (the round-end multi-GPU node)")
+    ins, ref = load("joint")
+    res = run_ranks(INV_EXE, ins, tmp_path, 2, transport="rccl")
+    got = dict(res[0])
+    got["__stdout__"] = strip_rank_lines(got["__stdout__"])
+    check("joint rccl x2", got, ref, widened(inversion_spec(True), 2.0))
+
+
 GOLD_T4 = os.path.join(GOLD, "program_test4.npz")
 
 
