@@ -101,6 +101,13 @@ class Context:
     def kernel_seconds(self, name):
         return self.lib.dazim_last_kernel_seconds(self._h, name.encode())
 
+    def stat(self, name):
+        """dazim_get_stat: a time or a count the last calls reported (docs/OPTIONS.md); KeyError for an unknown name"""
+        v = C.c_double()
+        if self.lib.dazim_get_stat(self._h, name.encode(), C.byref(v)) != 0:
+            raise KeyError(name)
+        return v.value
+
     def set_option(self, name, value):
         self._check(self.lib.dazim_set_option(self._h, name.encode(), int(value)))
 

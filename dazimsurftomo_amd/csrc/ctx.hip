@@ -356,6 +356,19 @@ double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name) {
   auto it = ctx->ksec.find(name);
   return it == ctx->ksec.end() ? -1.0 : it->second;
 }
+int dazim_get_stat(const dazim_ctx *ctx, const char *name, double *value) {
+  if (!ctx || !name || !value) return DAZIM_E_BAD_ARG;
+  if (std::string(name) == "disp.copies") {
+    const double v = dazim_last_kernel_seconds(ctx, name);
+    if (v < 0) return DAZIM_E_BAD_ARG;
+    *value = v;
+    return 0;
+  }
+  auto it = ctx->ksec.find(name);
+  if (it == ctx->ksec.end()) return DAZIM_E_BAD_ARG;
+  *value = it->second;
+  return 0;
+}
 
 // inv/CalSurfG.f90:1005-1038 (gdx = gdz = 5, fp32 pi = 3.1415926535898 as in MODULE globalp :166)
 int dazim_geometry(int nx, int ny, float goxd, float gozd, float dvxd, float dvzd, dazim_geom *g) {

@@ -71,51 +71,12 @@ void *dazim_stream(dazim_ctx *ctx); /* the hipStream_t every kernel of this ctx 
 /* seconds spent in the last call's kernels, measured with HIP events on the ctx stream; name
  * selects the kernel ("fmm", "gridder", "disp", "ti", "rays", "spmv", "spmvt", "lsmr"); <0 if unknown */
 double dazim_last_kernel_seconds(const dazim_ctx *ctx, const char *name);
-/* tuning / test knobs.  "fmm.cap": LDS heap slots per field (0 = automatic from the grid size; 64
- * exercises the HBM spill path on small grids); "fmm.force_spill": 1 = run every field through
- * the spill kernel.  "rays.keep_small": 1 = dazim_rays_build_G* keep every non-zero entry of the cells with
- * |fdm| >= ftol (what the forward program's dense GGc/GGs hold, fwd/FwdTraveltimeCPS.f90:694-712) instead of
- * applying the inversion's second threshold |row| > ftol (inv/CalSurfG.f90:1353).  "rays.lcap": capacity of the per-ray LDS
- * cell list (default min(cells, 1024)); small values exercise the full-grid-sweep and retrace fallbacks.
- * "spmv.ldsx", "spmv.blocked", "spmv.scatter": 0 = do not use the LDS-staged A*x (whole x / per column-block pair) or
- * the fixed-point scatter A^T*y, i.e. fall back to the plain wavefront-per-row gather kernels (tests compare the two).
- * "spmv.col16": 0 = keep 32-bit column indices in the products (default: a 16-bit copy is streamed -- the column itself
- * when n <= 65536, else the column relative to its pair of column blocks).
- * "csr.reserve_rows" / "csr.reserve_nnz": rows / entries the caller is going to append to the next matrix that
- * dazim_rays_build_G* returns, if more than the default of one 7-entry regularisation row per model parameter: its arrays
- * get that much room and dazim_csr_append_coo / dazim_csr_append_tikhonov append in place instead of copying the matrix.
- * "rays.sort": 0 = deal the rays to the wavefronts in input order (default: by field, then by source-receiver distance, so
- * that the rays a wavefront traces in lockstep have similar lengths; results do not depend on it).
- * "fmm.sort": 0 = fields of a period marched in input order (default: by how central the source is; speed only).
- * "fmm.no_hybrid": 1 = all-LDS heap also on grids of 342..682 nodes a side (default: levels 1-10 in LDS, level 11 in HBM).
- * "fmm.ts": 1 / 2 = march every batch in stages that any workgroup may continue (time slicing) / never
- * (default 0: when the batch is larger than the resident slots); "fmm.ts_stages": coarse-march stages per field (default 2 on
- * the 512-slot hybrid heap with 16-bit node ids = S-256, 8 on the 512-slot heap with two HBM levels = S-512, 4 elsewhere).
- * "fmm.ieee": 1 = the compiler's IEEE division / square root in the quadrant solve on every grid (default: the short exact forms
- * where node spacings are 2 .. 4096 km and velocities 0.125 .. 16 km/s; same bits either way).
- * "fmm.prio": 1 / 2 = the eikonal kernel's wavefronts raise their issue priority always / never (default 0: when the batch
- * occupies at most half of the resident workgroups, i.e. runs at one field's latency beside the dispersion copies).  Speed only.
- * "fmm.gp8": 1 / 2 = eight fields per wavefront on grids up to 256 nodes a side (8 lanes per field, two quadrants per lane) with
- * the heap the batch would take anyway / with 255 LDS slots + two HBM levels.  Bit-identical; measured slower than the default
- * four fields per wavefront, kept for experiments.
- * The environment variable DAZIM_OPTS=name=value,name=value sets options when a context is created (for callers that do not
- * call dazim_set_option themselves, e.g. the Fortran programs).  "fmm.hyb512": 1 / 2 = on grids of 171..256 nodes a side keep heap levels 1-9 in LDS
- * and level 10 in HBM always / never (default 0: for batches larger than the 768-slot heaps hold at once).  "fmm.hyb2": 1 / 2 =
- * on grids above 256 nodes a side the heaps with few levels in LDS and two in HBM (512 slots up to 682 nodes, 1024 above) always /
- * never (default 0: for batches of more than 2.5 workgroups per CU, and above 768 nodes).  Speed only, all four.
- * "disp.async": 1 (where it pays: at most two rounds of workgroups) or 2 (always) = dazim_dispersion_kernels (device-resident
- * arrays, depth kernels wanted) returns when pvRc is complete and
- * leaves the 6*nz perturbed copies of every column -- which only sen_* need -- running on the context's auxiliary stream, beside
- * whatever is called next (the eikonal fields); dazim_rays_build_G*, the next dazim_dispersion_kernels, dazim_memcpy_h2d /
- * _d2h, dazim_free and dazim_sync join that stream.  Until one of them has been called sen_* are incomplete and vel must not be
- * overwritten (by anything but dazim_memcpy_h2d).
- * dazim_last_kernel_seconds("disp") is then the main stream's part, ("disp.copies") the auxiliary stream's (waits for it).
- * "disp.team": 1 / 2 = the column curves of such a call are / are not searched by 16 lanes per column, 16 grid points of the
- * bracket search at a time (default 0: when curves and copies together leave the chip under-filled; identical results).
- * "fmm.wg_per_cu": resident eikonal workgroups per CU (measurement).  "disp.ffwd": 0 = the first period's bracket search goes
- * step by step from its start value like the reference's (default: it jumps to the bracket that a parallel evaluation of the
- * same grid points found for the column's model; identical results).  "disp.pchunk": periods per
- * task of the dispersion kernel (default: all).  "disp.rden": 0 = keep the divisions of the sub-layer interpolation. */
+/* the same table with a status: times of the last call's kernels AND the counts / choices the library reports ("fmm.wg_per_cu",
+ * "spmv.kind", "lsmr.nranks", "fmm.field_pops" ...; docs/OPTIONS.md).  0 and *value, or DAZIM_E_BAD_ARG for an unknown name.      */
+int dazim_get_stat(const dazim_ctx *ctx, const char *name, double *value);
+/* tuning / test knobs, none of which changes a result unless its entry says so: the catalogue is docs/OPTIONS.md (heap forms and
+ * time slicing of the eikonal kernel "fmm.*", two-stream dispersion "disp.*", ray cell lists "rays.*", product kernels "spmv.*",
+ * "lsmr.*", CSR reservations "csr.*").  The environment variable DAZIM_OPTS=name=value,... sets options when a context is made. */
 int dazim_set_option(dazim_ctx *ctx, const char *name, int value);
 
 /* ---- geometry (host only; replaces the constant block inv/CalSurfG.f90:1005-1038) ---------- */

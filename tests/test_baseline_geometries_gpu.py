@@ -38,7 +38,7 @@ def workload_guard():
 def sample_case(name, nfield_s, extra_long):
     bench.set_workload(name)
     vel = bench.s256_model()
-    nsrc, nrcv = 1000, 32
+    nsrc, nrcv = (200, 16) if name == "s128" else (1000, 32)     # the source / receiver counts of the bench workloads
     scx, scz, per, field_of_ray, rcx, rcz = bench.workload(nsrc, nrcv, 0)
     nfield = len(scx)
     # fields spread over all periods and sources (a stride co-prime with the source count)
@@ -102,7 +102,8 @@ def csr(m, n, ir, ic, rw):
     return sp.csr_matrix((rw.astype(np.float64), (ir.astype(np.int64) - 1, ic.astype(np.int64) - 1)), shape=(m, n))
 
 
-@pytest.mark.parametrize("name,nfield_s,n_expected,ax_kind,weight", [("s256", 64, 29744, 1, 2.0), ("s512", 96, 116699, 2, 2000.0)])
+@pytest.mark.parametrize("name,nfield_s,n_expected,ax_kind,weight", [("s128", 160, 7436, 0, 20.0), ("s256", 64, 29744, 1, 2.0),
+                                                                     ("s512", 96, 116699, 2, 2000.0)])
 def test_rays_G_and_lsmr_at_the_baseline_geometry(ctx, orc, workload_guard, name, nfield_s, n_expected, ax_kind, weight):
     vel, scx, scz, per, ray_f, rx, rz = sample_case(name, nfield_s, extra_long=(name == "s512"))
     NX, NY, nz = bench.NX, bench.NY, len(bench.DEPZ)
