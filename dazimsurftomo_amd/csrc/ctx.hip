@@ -69,7 +69,8 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
     s.second = 0;
     // a little slack so slowly growing batches do not thrash; none on the multi-GB blocks (the per-field state of time-sliced
     // eikonal marches: an eighth of 34 GB would be 4 GB that nothing ever touches)
-    size_t want = bytes >= ((size_t)1 << 30) ? bytes : bytes + bytes / 8;
+    // ... but rounded up to the next 256 MB, so that a batch that grows by one field does not free and allocate gigabytes each time
+    size_t want = bytes >= ((size_t)1 << 30) ? ((bytes + ((size_t)1 << 28) - 1) >> 28) << 28 : bytes + bytes / 8;
     DZ_HIP(dz_malloc_retry(ctx, &s.first, want));
     s.second = want;
   }

@@ -738,7 +738,8 @@ contains
     a_iw = transfer(c_loc(iw), a_iw); a_rw = transfer(c_loc(rw), a_rw)
     fp = 0
     if (.not. dazim_aprod_trust .and. kk >= 1) &
-      fp = ieor(dazim_hash64(c_loc(iw), int(2*kk + 1, c_size_t)*4), 3*dazim_hash64(c_loc(rw), int(kk, c_size_t)*4))
+      fp = ieor(dazim_hash64(c_loc(iw), (int(kk, c_size_t)*2 + 1)*4), ishftc(dazim_hash64(c_loc(rw), int(kk, c_size_t)*4), 21))
+    ! (sizes in c_size_t before the multiplication; the two hashes combined by rotate-and-xor: a signed multiply may overflow)
     if (.not. (c_associated(aprod_A) .and. a_iw == aprod_iw .and. a_rw == aprod_rw .and. kk == aprod_kk .and. m == aprod_m &
                .and. n == aprod_n .and. fp == aprod_fp)) then
       call dazim_aprod_forget()
