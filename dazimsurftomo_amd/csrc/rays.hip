@@ -220,14 +220,33 @@ template <bool EMIT, bool AZIM>
 #ifndef DZ_RAYS_MINW
 #define DZ_RAYS_MINW 4
 #endif
-__global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayArgs A) {
+__global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayArgs A_) {
+  // (arguments through an opaque pointer to the kernarg segment, like fmm_kernel: taken by value, the ~50 scalar registers of
+  // RayArgs stay alive across the stepping loop and the spill code moved 93 of its 1 227 VALU instructions per step through
+  // VGPR lanes -- v_readlane / v_writelane --, 17 more through scratch memory)
+#ifndef DZ_RAYS_ARGS_BYVALUE
+  using ArgP = const __attribute__((address_space(4))) RayArgs *;
+  auto launder = [](ArgP p) {
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return (ArgP)((const __attribute__((address_space(4))) char *)p + __builtin_amdgcn_readfirstlane(z));
+  };
+  ArgP Ap = launder((ArgP)__builtin_amdgcn_kernarg_segment_ptr());
+#define A (*Ap)
+#define RAYS_ARGS_FRESH Ap = launder(Ap)
+#else
+  const RayArgs &A = A_;
+#define RAYS_ARGS_FRESH
+#endif
   constexpr int GP = EMIT ? GP_EMIT : GP_COUNT;   // lanes per ray
   constexpr int RPW = 64 / GP;                    // rays per wavefront
   constexpr int LPR = 16 / GP;                    // cells of the 4x4 B-spline block per lane
   constexpr int LSTEP = 4 / LPR;                  // ... which are LSTEP rows apart
   constexpr unsigned GMASK = (1u << GP) - 1u;
   extern __shared__ __attribute__((aligned(16))) unsigned short s_lists[];  // [RPW][lcap] cell lists
-  const dazim_geom g = A.g;
+  dazim_geom g;
+  g.nvx = A.g.nvx; g.nvz = A.g.nvz; g.nnx = A.g.nnx; g.nnz = A.g.nnz;
+  g.gox = A.g.gox; g.goz = A.g.goz; g.dnx = A.g.dnx; g.dnz = A.g.dnz; g.dvx = A.g.dvx; g.dvz = A.g.dvz;
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   const int lm = gl & 3, l0 = gl >> 2;  // this lane's cells of the 4x4 scatter: (m, l) = (lm, l0 + q*LSTEP), q < LPR
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
@@ -248,6 +267,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
   unsigned *qcnt = A.qcount + (EMIT ? 8 : 0);
   int chunk = (int)(blockIdx.x % nxcd);
   for (;;) {
+    RAYS_ARGS_FRESH;
     long quad = -1;
     if (lane == 0) {
       for (int tried = 0; tried < nxcd; tried++) {
@@ -662,6 +682,8 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     }
   }
 }
+#undef A
+#undef RAYS_ARGS_FRESH
 
 }  // namespace
 
