@@ -199,7 +199,16 @@ int dz_join_aux(dazim_ctx *ctx) {
   if (!ctx->aux_pending) return 0;
   DZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_a1, 0));
   ctx->aux_pending = false;
+  ctx->aux_ranges.clear();
   return 0;
+}
+int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes) {
+  if (!ctx->aux_pending) return 0;
+  const char *a = (const char *)dev;
+  bool hit = ctx->aux_ranges.empty();   // (no ranges recorded: assume the worst)
+  for (const auto &r : ctx->aux_ranges)
+    if (a < r.p + r.bytes && r.p < a + bytes) hit = true;
+  return hit ? dz_join_aux(ctx) : 0;
 }
 
 extern "C" {
@@ -294,15 +303,17 @@ int dazim_free(dazim_ctx *ctx, void *dptr) {
 }
 // (both copies come after whatever the auxiliary stream still has to do -- the depth kernels of a disp.async call: a caller that
 // reads sen_* straight after dazim_dispersion_kernels gets the complete arrays, one that overwrites vel does not race the copies)
+// (a copy into or out of the arrays the perturbed copies of an asynchronous dazim_dispersion_kernels call still work on waits for
+// them; any other copy leaves the auxiliary stream alone, so that staging the next inputs does not cost the overlap)
 int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
-  int rcj = dz_join_aux(ctx);
+  int rcj = dz_join_aux_if_touched(ctx, dst, bytes);
   if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
-  int rcj = dz_join_aux(ctx);
+  int rcj = dz_join_aux_if_touched(ctx, src, bytes);
   if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -311,6 +322,7 @@ int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
 int dazim_sync(dazim_ctx *ctx) {
   if (ctx->stream2) DZ_HIP(hipStreamSynchronize(ctx->stream2));
   ctx->aux_pending = false;
+  ctx->aux_ranges.clear();
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -363,6 +375,10 @@ int dazim_get_stat(const dazim_ctx *ctx, const char *name, double *value) {
     const double v = dazim_last_kernel_seconds(ctx, name);
     if (v < 0) return DAZIM_E_BAD_ARG;
     *value = v;
+    return 0;
+  }
+  if (std::string(name) == "aux.pending") {   // 1 while work handed to the auxiliary stream has not been joined by the main stream
+    *value = ctx->aux_pending ? 1.0 : 0.0;
     return 0;
   }
   auto it = ctx->ksec.find(name);

@@ -36,6 +36,10 @@ struct dazim_ctx {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_a0 = nullptr, ev_a1 = nullptr;
   bool aux_pending = false, aux_timed = false;
+  // device ranges the auxiliary stream's pending work reads or writes (the model and the three kernel tables): a host copy that
+  // touches none of them does not have to wait for it (dazim_memcpy_h2d / _d2h)
+  struct AuxRange { const char *p; size_t bytes; };
+  std::vector<AuxRange> aux_ranges;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
@@ -44,6 +48,7 @@ struct dazim_ctx {
 int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
 int dz_aux_init(dazim_ctx *ctx);                  // creates the auxiliary stream and its events on first use
 int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what the auxiliary stream was given (no host wait)
+int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes);   // ... only if [dev, dev + bytes) overlaps what it works on
 
 #define DZ_HIP(call)                                                                           \
   do {                                                                                         \

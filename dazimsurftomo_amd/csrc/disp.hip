@@ -1186,6 +1186,10 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
       DZ_HIP(hipEventRecord(ctx->ev_a1, ctx->stream2));
       ctx->aux_pending = true;
       ctx->aux_timed = true;
+      ctx->aux_ranges.clear();
+      ctx->aux_ranges.push_back({(const char *)vel.dev, (size_t)nz * ncol * sizeof(float)});
+      for (const double *q : {svs.dev, svp.dev, srho.dev})
+        if (q) ctx->aux_ranges.push_back({(const char *)q, nk * sizeof(double)});
     }
     t.stop();
   }

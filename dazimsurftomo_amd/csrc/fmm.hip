@@ -689,7 +689,12 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   const bool third = both2 || (!two && so1);       // two ? both2 : so1 -- tdiv = 3 (else 1)
   float rd1 = b * b - 4.0f * a * c;
   if (rd1 < 0.0f) rd1 = 0.0f;
-  const float tdsh = div_exact(-b + sqrt_exact(rd1, fast), 2.0f * a, fast);
+  // (one test of `fast` around both: two tests cost the loop two more taken branches and their flag bookkeeping per pop)
+  float tdsh;
+  if (fast)
+    tdsh = div_exact(-b + sqrt_exact(rd1, 1), 2.0f * a, 1);
+  else
+    tdsh = div_exact(-b + sqrt_exact(rd1, 0), 2.0f * a, 0);
   const float tsum = tref + tdsh;
   const float t3 = div3_exact(tsum);
   const float t = third ? t3 : tsum;
@@ -1658,7 +1663,9 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // predecessor is still running waits; with equal stages that wait is 0.15 % of the workgroups' time at 2 stages, 2 % at 8:
   // tools/exp_ts_wait.sh)
   ctx->ksec["fmm.ts_stages"] = ts ? (double)nseg : 0.0;
-  const size_t nown = (ts ? (size_t)nfield : (size_t)nslot) + 8;   // owners of node words / HBM heap levels: fields or resident slots
+  // owners of node words / HBM heap levels: fields or resident slots.  + 8: the idle lane groups of the last wavefront of a batch
+  // (owner index up to nfield + fields per wavefront - 1, at most 8 fields per wavefront) address their own, unused, state
+  const size_t nown = (ts ? (size_t)nfield : (size_t)nslot) + 8;
   if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
   A.rec_c = (unsigned *)p;
   A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr;

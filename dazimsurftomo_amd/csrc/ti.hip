@@ -213,6 +213,7 @@ __device__ cx h2func(cx na, cx nb, double dm) {
 
 struct TiArgs {
   int ncol, nz, kmax, mmax;
+  int prio;                // 1: ti_kernel raises its wavefronts' issue priority (the dispersion copies of an asynchronous call are pending)
   const float *vel;        // [nz][ncol]
   const double *pv;        // [kmax][ncol]
   const float *twopi_t;    // [kmax] fp32 periods (t_in)
@@ -273,7 +274,7 @@ __global__ void ti_model_kernel(TiArgs A) {
 __global__ __launch_bounds__(TT) void ti_kernel(TiArgs A) {
   // a small launch the eikonal solve waits for, usually beside the dispersion kernel's perturbed copies (auxiliary stream): issue
   // priority over their wavefronts (test4_Yunnan: 13.5 ms per call beside the copies, 1.6 ms alone)
-  __builtin_amdgcn_s_setprio(3);
+  if (A.prio) __builtin_amdgcn_s_setprio(3);   // (only while such copies are pending: alone on the chip there is nobody to overtake)
   const long lane = (long)blockIdx.x * TT + threadIdx.x;
   const long nlane = (long)A.ncol * A.kmax;
   if (lane >= nlane) return;
@@ -576,6 +577,7 @@ extern "C" int dazim_ti_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const fl
   DZ_HIP(hipStreamSynchronize(ctx->stream));   // host tables go out of scope after the launches are queued; keep it simple
   {
     DzTimer t(ctx, "ti");
+    A.prio = ctx->aux_pending ? 1 : 0;
     hipLaunchKernelGGL(ti_model_kernel, dim3((ncol + 127) / 128), dim3(128), 0, ctx->stream, A);
     hipLaunchKernelGGL(ti_kernel, dim3((unsigned)((nlane + TT - 1) / TT)), dim3(TT), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());

@@ -395,3 +395,48 @@ def test_column_curves_in_teams_are_bit_identical():
         assert out[0][2] == out[1][2] and np.array_equal(out[0][0], out[1][0]), (vel.shape, np.abs(out[0][0] - out[1][0]).max())
         for a, b in zip(out[0][1], out[1][1]):
             assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_host_copies_join_the_perturbed_copies_only_when_they_touch_their_arrays():
+    """dazim_memcpy_h2d / _d2h after an asynchronous dazim_dispersion_kernels call: a copy into an unrelated device array leaves
+    the auxiliary stream alone (the overlap with the eikonal solve survives staging the next inputs); a copy out of a kernel table
+    or into the model waits for the copies first and delivers the finished table."""
+    import ctypes
+    import torch
+    import dazimsurftomo_amd as dz
+    import bench
+    dev = torch.device("cuda:0")
+    nx = ny = 28
+    old = (bench.NX, bench.NY)
+    bench.NX = bench.NY = nx
+    try:
+        vel = bench.s256_model()
+    finally:
+        bench.NX, bench.NY = old
+    depz, periods, minthk = bench.DEPZ, np.asarray(bench.PERIODS, np.float64)[:8], bench.MINTHK
+    d_vel = torch.from_numpy(np.ascontiguousarray(vel)).to(dev)
+    ref = dz.Context(0)
+    _, sen_ref, _ = ref.depthkernel(d_vel, depz, periods, minthk)
+    ref.sync()
+    want = sen_ref[0].cpu().numpy()
+    ref.close()
+    c = dz.Context(0)
+    c.set_option("disp.async", 2)
+    pv, sen, nf = c.depthkernel(d_vel, depz, periods, minthk)
+    assert c.kernel_seconds("disp.async") == 1 and c.stat("aux.pending") == 1
+    lib = c.lib
+    lib.dazim_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    lib.dazim_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    other = torch.zeros(1024, dtype=torch.float32, device=dev)
+    src = np.arange(1024, dtype=np.float32)
+    assert lib.dazim_memcpy_h2d(c._h, other.data_ptr(), src.ctypes.data, src.nbytes) == 0
+    assert c.stat("aux.pending") == 1                       # unrelated array: not joined
+    assert np.array_equal(other.cpu().numpy(), src)
+    got = np.empty_like(want)
+    assert lib.dazim_memcpy_d2h(c._h, got.ctypes.data, sen[0].data_ptr(), got.nbytes) == 0
+    assert c.stat("aux.pending") == 0                       # a kernel table: joined, and complete
+    assert np.array_equal(got, want)
+    c.sync()
+    c.close()
+
