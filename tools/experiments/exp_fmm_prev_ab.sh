@@ -8,7 +8,7 @@ for f in "$@"; do
   DAZIM_LIB=/tmp/libdazim_ab$i.so DAZIM_HIPCC_EXTRA="$f" python -c "import dazimsurftomo_amd as dz; dz.build(force=True)" > /dev/null 2>&1 || echo "build failed: $f"
   i=$((i+1))
 done
-for rep in 1 2 3; do
+for rep in $(seq ${REPS:-3}); do
   echo -n "[prev] "; DAZIM_LIB=/tmp/libdazim_prev.so python tools/fmm_only.py ${SRC:-1000} 1 2>&1 | grep kernel | awk '{print $7, $8, $9}'
   echo -n "[new]  "; python tools/fmm_only.py ${SRC:-1000} 1 2>&1 | grep kernel | awk '{print $7, $8, $9}'
   i=0
