@@ -245,8 +245,11 @@ struct Heap {
   NT *nodes;    // this group's [CAP] node ids
   HEnt *ovf;   // HBM spill for slots >= CAP
   unsigned *rec;   // node words of the grid being marched (4 x 4 tiles, see w_alive)
+  __device__ __forceinline__ void set_rec(unsigned *r) { rec = r; }
+  __device__ __forceinline__ unsigned ldw(unsigned node) const { return rec[node]; }
+  __device__ __forceinline__ void stw(unsigned node, unsigned w) { rec[node] = w; }
   // back-pointer store: a band node's word is its slot
-  __device__ __forceinline__ void set_slot(unsigned node, int slot) { rec[node] = w_band(slot); }
+  __device__ __forceinline__ void set_slot(unsigned node, int slot) { stw(node, w_band(slot)); }
   int tsh;     // log2 of the record stride between columns of tiles of that grid
   int ntr;
   bool g0;     // lane 0 of the group
@@ -321,7 +324,7 @@ struct Heap {
     const int rs = (valid && !ahi) ? a : 0;
     float ak = keys[rs];
     NT an = nodes[rs];
-    if (HYB && NH > 1 && wballot(ahi) != 0) {
+    if (HYB && NH > 1 && __builtin_expect(wballot(ahi) != 0, 0)) {
       if (ahi) {
         const HEnt e = ovf[a - CAP];
         ak = e.key;
@@ -346,7 +349,7 @@ struct Heap {
       nodes[fin] = (NT)node;
     }
     if (last) set_slot((unsigned)node, fin);
-    if (HYB && wballot(dhi || fhi) != 0) {
+    if (HYB && __builtin_expect(wballot(dhi || fhi) != 0, 0)) {
       if (dhi) ovf[dst - CAP] = HEnt{ak, (int)an};
       if (fhi) ovf[fin - CAP] = HEnt{key, node};
     }
@@ -472,7 +475,7 @@ struct Heap {
     float mvk = keys[mls];
     NT mvc = nodes[mls];
     keys[mls] = INFINITY;                                 // the slot leaves the heap: +inf beyond the end (see pad())
-    if (HYB && wballot(mhi) != 0) {
+    if (HYB && __builtin_expect(wballot(mhi) != 0, 0)) {
       if (mhi) {
         const HEnt e = ovf[ntr - CAP];
         mvk = e.key;
@@ -555,7 +558,7 @@ struct Heap {
       // entries in the HBM levels are exact -- march() cannot search there.
 #pragma unroll
       for (int h = 0; h < NH; h++) {
-        if (deepm == 0) break;
+        if (__builtin_expect(deepm == 0, 1)) break;   // (the usual pop of a 256 x 256 field ends in the LDS part)
         int again = 0;
         if (lanes(deepm)) {
           const HEnt *ch = ovf + (2 * p - CAP);
@@ -584,7 +587,7 @@ struct Heap {
     const int lp = phi ? 0 : p;
     keys[lp] = mvk;
     nodes[lp] = mvc;
-    if (HYB && wballot(phi) != 0) {
+    if (HYB && __builtin_expect(wballot(phi) != 0, 0)) {
       if (phi && g0) ovf[p - CAP] = HEnt{mvk, (int)mvc};
     }
     fin_node = (int)mvc;
@@ -689,12 +692,13 @@ __device__ __forceinline__ float quadrant_time(float slown, float risti, float d
   const bool third = both2 || (!two && so1);       // two ? both2 : so1 -- tdiv = 3 (else 1)
   float rd1 = b * b - 4.0f * a * c;
   if (rd1 < 0.0f) rd1 = 0.0f;
-  // (one test of `fast` around both: two tests cost the loop two more taken branches and their flag bookkeeping per pop)
-  float tdsh;
-  if (fast)
-    tdsh = div_exact(-b + sqrt_exact(rd1, 1), 2.0f * a, 1);
-  else
-    tdsh = div_exact(-b + sqrt_exact(rd1, 0), 2.0f * a, 0);
+  // (the short forms first, the compiler's sequences as a rare override behind ONE not-taken branch: written as the two arms of an
+  // if / else -- or as a test inside sqrt_exact and another inside div_exact -- the loop got both arms inline behind a flag, two
+  // taken branches per pop; `fast` is a per-lane copy of the launch's flag so that the test does not fetch a spilled scalar)
+  float tdsh = div_exact(-b + sqrt_exact(rd1, 1), 2.0f * a, 1);
+  int fast_here = fast;
+  asm volatile("" : "+v"(fast_here));   // (compared here: hoisted out of the loop, the lane mask of the comparison is a spilled scalar pair again)
+  if (__builtin_expect(wballot(fast_here == 0) != 0, 0)) tdsh = div_exact(-b + sqrt_exact(rd1, 0), 2.0f * a, 0);
   const float tsum = tref + tdsh;
   const float t3 = div3_exact(tsum);
   const float t = third ? t3 : tsum;
@@ -744,7 +748,6 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
   const int dix = nb == 0 ? -1 : (nb == 1 ? 1 : 0);
   const int diz = nb == 2 ? -1 : (nb == 3 ? 1 : 0);
   const int jd = GPL == 16 ? ((q & 2) ? 1 : -1) : (q ? 1 : -1), kd = GPL == 16 ? ((q & 1) ? 1 : -1) : -1;
-  unsigned *recw = H.rec;
   const int tsh = H.tsh;
   bool overflow = false;
   // lazy back-pointers (see below) wherever the sift-down is the parallel one: the all-in-LDS heap and, since the late round 3,
@@ -808,7 +811,10 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       const lmask inm = wballot(((uroot & XMASK) - xlo) <= xspan) & wballot(((uroot & ZMASK) - zlo) <= zspan);
       interior = inm == wballot(true);
     }
-    if (TAB && interior) {
+    // (the table path is written as straight-line code in front of an `if` without `else`: as the two arms of an if / else the
+    // compiler placed BOTH out of line behind a flag, two taken branches and three scalar instructions per pop; an edge root
+    // reads the table for nothing)
+    if constexpr (TAB) {
       const short *xa = xt + ((uroot >> 2) & 3u), *za = zt + (uroot & 3u);
       const int dnx_ = xa[0], dj_ = xa[24], dj2_ = xa[48];
       const int dnz_ = za[0], dk_ = za[24], dk2_ = za[48];
@@ -818,7 +824,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       ak_i = uself + (unsigned)dk_;
       ak2_i = uself + (unsigned)dk2_;
       nvalidm = vjm = vj2m = vkm = vk2m = ~0ull;
-    } else {
+    }
+    if (!TAB || __builtin_expect(!interior, 0)) {
       const int ix = rid_x0(iroot, tsh) + 1, iz = rid_z0(iroot, tsh) + 1;
       if (REFINED) {
         bool swrg = false;
@@ -827,9 +834,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
         if (iz == 1 && (ex & 4)) swrg = true;
         if (iz == nnz && (ex & 8)) swrg = true;
         if (swrg) {  // nsts(iz,ix)=0 ; EXIT  -- the band keeps its slots in nstsr (:378-381)
-          if (H.g0) recw[iroot] = w_alive(root.key);            // (it stays at slot 1 of the heap; its time is its key)
+          if (H.g0) H.stw(uroot, w_alive(root.key));            // (it stays at slot 1 of the heap; its time is its key)
           if (LAZY)   // lazy back-pointers (below): the words of entries that only moved up are behind; nstsr wants them exact
-            for (int i = 2 + gl; i <= H.ntr; i += GP) recw[(unsigned)H.get(i).node] = w_band(i);
+            for (int i = 2 + gl; i <= H.ntr; i += GP) H.stw((unsigned)H.get(i).node, w_band(i));
           break;
         }
       }
@@ -864,18 +871,18 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       }
     }
     const bool nvalid = lanes(nvalidm), vj = lanes(vjm), vj2 = lanes(vj2m), vk = lanes(vkm), vk2 = lanes(vk2m);
-    if (H.g0) recw[iroot] = w_alive(root.key);              // accepted: the word becomes the time (= the heap key, the trial time)
+    if (H.g0) H.stw(uroot, w_alive(root.key));              // accepted: the word becomes the time (= the heap key, the trial time)
     cbar();
     // (the node words as they are: an alive node's word is its time, sign bit clear; see w_alive)
-    unsigned wself = recw[uself];
-    unsigned wj = recw[aj_i];
-    unsigned wj2 = recw[aj2_i];
-    unsigned wk = recw[ak_i];
-    unsigned wk2 = recw[ak2_i];
+    unsigned wself = H.ldw(uself);
+    unsigned wj = H.ldw(aj_i);
+    unsigned wj2 = H.ldw(aj2_i);
+    unsigned wk = H.ldw(ak_i);
+    unsigned wk2 = H.ldw(ak2_i);
     unsigned wkp = 0, wk2p = 0;
     if constexpr (GPL == 8) {
-      wkp = recw[akp_i];
-      wk2p = recw[ak2p_i];
+      wkp = H.ldw(akp_i);
+      wk2p = H.ldw(ak2p_i);
     }
     const float2 slri = slow[uself];                        // slowness of the neighbour (1/velocity, precomputed, same tiling) and its risti
     const float vel = slri.x, risti = slri.y;
@@ -980,7 +987,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       if (q == 0 && band) atomicAdd(&g_lazy_stat[found == 64 && !isdrop ? 1 : 0], 1ull);
       if (q == 0 && band && isdrop) atomicAdd(&g_lazy_stat[2], 1ull);
 #endif
-      if ((bandm & wballot(found == 64) & ~dropm) != 0) {   // (wave-uniform, rare) the higher ancestors
+      if (__builtin_expect((bandm & wballot(found == 64) & ~dropm) != 0, 0)) {   // (wave-uniform, rare) the higher ancestors
 #pragma unroll
         for (int t = 1; t < LT; t++) {
 #pragma unroll
@@ -1030,7 +1037,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       const int gp = pc >> 1;
       const float gk = H.keys[(act && room && gp >= 1) ? gp : 0];
       NT pn = H.nodes[(act && room && !pchi) ? pc : 0];
-      if (HYB && NH > 1 && wballot(pchi) != 0) {
+      if (HYB && NH > 1 && __builtin_expect(wballot(pchi) != 0, 0)) {
         if (pchi) {
           const HEnt e = H.ovf[pc - CAP];
           pk = e.key;
@@ -1081,7 +1088,7 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
         if (lanes(f2rise)) {
           H.keys[pc] = trav;
           H.nodes[pc] = (NT)uself;
-          recw[uself] = w_band(pc);
+          H.stw(uself, w_band(pc));
           H.keys[c] = pk;
           H.nodes[c] = pn;
           H.set_slot((unsigned)pn, c);
@@ -1094,8 +1101,8 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
         const int dst = lanes(wrm & ~whim) ? c : 0;        // slot 0 is never a heap entry
         H.keys[dst] = trav;
         H.nodes[dst] = (NT)uself;
-        if (wr) recw[uself] = w_band(c);
-        if (HYB && whim != 0) {
+        if (wr) H.stw(uself, w_band(c));
+        if (HYB && __builtin_expect(whim != 0, 0)) {
           if (lanes(whim)) H.ovf[c - CAP] = HEnt{trav, (int)uself};
         }
         H.ntr += __popc(newb & ((1u << (NBL * n0)) - 1u));
@@ -1272,7 +1279,8 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
   // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
   // (an integer in a scalar register: a wavefront-uniform bool is still a lane mask to the compiler, and a branch on it costs VALU work)
-  const int fastm = __builtin_amdgcn_readfirstlane(*A.vflag) == 0 ? A.fastm : 0;
+  int fastm = __builtin_amdgcn_readfirstlane(*A.vflag) == 0 ? A.fastm : 0;
+  asm volatile("" : "+v"(fastm));   // (kept in a vector register: as a scalar it is spilled and comes back through v_readlane in every pop)
   if (A.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over another kernel's wavefronts on the same SIMD (see run_fmm)
   const int nstage = SPILL ? 1 : A.ts_nstage;
   const bool ts = nstage > 1;
@@ -1340,7 +1348,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         }
         H.ntr = n0;
         if (!SPILL) H.pad(gl, nl + 1);
-        H.rec = rec_c;
+        H.set_rec(rec_c);
         H.tsh = tsh_c;
         cbar();
         const bool ovf = march<CAP, SPILL, NT, HYB, false, GPL>(H, A.slown + (size_t)per * nrec_c, nnx, nnz, g.dnx, g.dnz, 0, lane, fastm,
@@ -1437,7 +1445,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         // ---- travel(urg=1) source initialisation, inv/CalSurfG.f90:324-345 ----
         H.ntr = 0;
         if (!SPILL) H.pad(gl, 1);
-        H.rec = rec_r;
+        H.set_rec(rec_r);
         H.tsh = TSH_R;
         int rsx = (int)((scx - bx.goxr) / bx.dnxr) + 1;
         int rsz = (int)((scz - bx.gozr) / bx.dnzr) + 1;
@@ -1541,7 +1549,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         // ---- travel(urg=2): rebuild the band in column-major node order (inv/CalSurfG.f90:311-317) ----
         H.ntr = 0;
         if (!SPILL) H.pad(gl, 1);
-        H.rec = rec_c;
+        H.set_rec(rec_c);
         H.tsh = tsh_c;
         for (int base = 0; base < nbox; base += GP) {
           const int i = base + gl;
