@@ -871,7 +871,9 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
       }
     }
     const bool nvalid = lanes(nvalidm), vj = lanes(vjm), vj2 = lanes(vj2m), vk = lanes(vkm), vk2 = lanes(vk2m);
-    if (H.g0) H.stw(uroot, w_alive(root.key));              // accepted: the word becomes the time (= the heap key, the trial time)
+    // accepted: the word becomes the time (= the heap key, the trial time).  Stored by all sixteen lanes of the group (same address,
+    // same value: one request) -- a store by lane 0 alone costs the pop an exec save / test / restore
+    H.stw(uroot, w_alive(root.key));
     cbar();
     // (the node words as they are: an alive node's word is its time, sign bit clear; see w_alive)
     unsigned wself = H.ldw(uself);
