@@ -1115,26 +1115,29 @@ __device__ __forceinline__ bool march(Heap<CAP, SPILL, NT, HYB, GPL> &H, const f
     if (wballot(!fast)) pa_[3] += 1000000;   // "fix" slot doubles as a counter of slow-path iterations (x1e6)
     pa_[7] += 1000000;                        // iterations (x1e6) on top of the loop-top ticks
 #endif
-#ifdef DZ_FMM_PROF2   // experiment: how many slow-path pops consist of single one-level rises with untouched siblings?
+#ifdef DZ_FMM_PROF2   // experiment: how many slow-path pops have, in every group that needs the rounds, exactly ONE rising entry (any
+    // number of levels) whose path no other neighbour of the pop touches?  (counted x1e6 on the "setup+loads" slot; slow pops on "fix")
     if (!SPILL && wballot(!fast)) {
       const bool owner = q == 0;
       const bool act = stfix != 0, isnew = stfix < 0;
       const unsigned newb = (unsigned)(wballot(owner && isnew) >> gbase) & 0x1111u;
       const int ntr0 = H.ntr - __popc(newb & ((1u << (4 * n0)) - 1u));            // (H.ntr was advanced for the neighbours < n0)
       const int c = isnew ? ntr0 + 1 + __popc(newb & ((1u << gl) - 1u)) : stfix;
-      const int pc = c >> 1, gp = pc >> 1;
-      const float pk = H.keys[act ? pc : 0], gk = H.keys[(act && gp >= 1) ? gp : 0];
+      const int pc = c >> 1;
+      const float pk = H.keys[(act && pc < CAP) ? pc : 0];
       const bool rise = owner && act && c > 1 && trav < pk;
       const unsigned rb = (unsigned)(wballot(rise) >> gbase) & 0xffffu;
       const int rl = rb ? __builtin_ctz(rb) : 0;
-      const int cr = __shfl(c, gbase + rl), pr = __shfl(pc, gbase + rl);
+      const int cr = __shfl(c, gbase + rl);
       const bool one = __popc(rb) == 1;
-      const bool stops = !(gp >= 1 && trav < gk);                         // the riser stops after one level
-      const bool clash = owner && act && gl != rl && (c == pr || pc == cr || pc == pr);
+      auto anc = [&](int x) { if (x < 1 || x > cr) return false; const int d = __clz(x) - __clz(cr); return (cr >> d) == x; };
+      const bool clash = owner && act && gl != rl && (anc(c) || anc(pc));
       const unsigned cl = (unsigned)(wballot(clash) >> gbase) & 0xffffu;
-      const bool stopr = __shfl((int)stops, gbase + rl) != 0;
-      const bool ok = rb == 0 || (one && stopr && cl == 0 && !fast);
-      if (wballot(!ok) == 0) pa_[0] += 1000000;   // covered slow pops (x1e6 on the "setup+loads" slot)
+      const bool room = ntr0 + __popc(newb) < Heap<CAP, SPILL, NT, HYB, GPL>::TOT;
+      const bool ok = fast || (room && one && cl == 0 && (!HYB || cr < CAP));
+      if (wballot(!ok) == 0) pa_[0] += 1000000;
+      if (wballot(!fast && !room) != 0) pa_[1] += 1000000;       // pops with a group out of room ("popdown" slot)
+      if (wballot(!fast && room && !one) != 0) pa_[2] += 1000000; // ... with several risers in a group ("loadwait" slot)
     }
 #endif
     if (!fast) {
