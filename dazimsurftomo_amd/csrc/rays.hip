@@ -41,6 +41,7 @@ struct RayArgs {
   const dazim_refbox *boxes;
   const float *vels;       // [nz][ny][nx]
   const double *svs, *svp, *srho;  // [nz][kmax][nx*ny]
+  const double *skern;     // [nz][kmax][nx*ny] svp*coe_a + srho*coe_rho + svs per model cell and period (k_row_kernels), or nullptr
   const float *lsen;       // joint mode: Lsen_Gsc [nz-1][kmax][nx*ny] (fp32, inv/CalSurfGAniso_Joint.f90:337)
   // double-precision reciprocals RN(1/d) of the loop-invariant fp32 divisors (grid spacings and 2*EARTH*spacing): see divr()
   double r_dnx, r_dnz, r_dnxr, r_dnzr, r_dvx, r_dvz, r_e2dnx, r_e2dnxr;
@@ -184,6 +185,22 @@ __device__ __forceinline__ float bilin_cell(const dazim_geom &g, const float *ve
       biv = biv + veln[(size_t)(cx - 2 + i) * g.nnz + (cz - 2 + j)] * produ;
     }
   return biv;
+}
+
+// The factor of a dVs row entry that does not depend on the ray (inv/CalSurfG.f90:1339-1364): the Brocher derivatives of the cell's
+// velocity and the three depth kernels, (svp*coe_a + srho*coe_rho + svs) in the reference's order and precision -- once per model
+// cell, layer and period instead of once per ray that crosses the cell (both passes of rays_kernel; the emit pass is little else).
+__global__ void k_row_kernels(long n, int kmax, long ncol, const float *__restrict__ vels, const double *__restrict__ svs,
+                              const double *__restrict__ svp, const double *__restrict__ srho, double *__restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;     // (layer, period, column)
+  if (i >= n) return;
+  const long k = i / (kmax * ncol), c = i % ncol;
+  const float v = vels[k * ncol + c];
+  const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
+  const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
+  const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
+                                 0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
+  out[i] = svp[i] * (double)coe_a + srho[i] * (double)coe_rho + svs[i];
 }
 
 // sort key of a ray for the order in which rays are dealt to the wavefronts: field in the high bits, quantised source-receiver
@@ -639,12 +656,17 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
             const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
             if (blk == 0) {
               const float fd = gfdm[kk * ldf + jj];
-              const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
-              const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
-              const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
-              const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
-                                             0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
-              const double r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
+              double r;
+              if (A.skern) {
+                r = A.skern[si] * (double)fd;           // (the cell's factor from k_row_kernels: same operations, same order)
+              } else {
+                const float v = A.vels[((size_t)(k - 1) * A.ny + jj) * A.nx + kk];
+                const float coe_a = (2.0947f - 0.8206f * 2 * v + 0.2683f * 3 * (v * v) - 0.0251f * 4 * (v * v * v));
+                const float vpft = 0.9409f + 2.0947f * v - 0.8206f * (v * v) + 0.2683f * (v * v * v) - 0.0251f * (v * v * v * v);
+                const float coe_rho = coe_a * (1.6612f - 0.4721f * 2 * vpft + 0.0671f * 3 * (vpft * vpft) -
+                                               0.0043f * 4 * (vpft * vpft * vpft) + 0.000106f * 5 * (vpft * vpft * vpft * vpft));
+                r = (A.svp[si] * (double)coe_a + A.srho[si] * (double)coe_rho + A.svs[si]) * (double)fd;
+              }
               rowv = (float)r;
               if (A.dense) {   // the same expression with the derivatives left over from the last cell of the first loop
                 const float vL = A.vels[((size_t)(k - 1) * A.ny + jjL) * A.nx + kkL];
@@ -752,6 +774,15 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.period = period.dev; A.kidx = kidx.dev; A.veln = veln.dev; A.ttn = ttn.dev; A.ttnr = ttnr.dev;
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
   A.lsen = joint ? lsen.dev : nullptr;
+  A.skern = nullptr;
+  if (!(ctx->opts.count("rays.skern") && !ctx->opts["rays.skern"])) {   // (option rays.skern = 0: every entry from the three kernels)
+    void *pk;
+    if ((rc = dz_scratch(ctx, "rays.skern", nk * sizeof(double), &pk))) return rc;
+    hipLaunchKernelGGL(k_row_kernels, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, ctx->stream, (long)nk, kmax, (long)ncol,
+                       vels.dev, svs.dev, svp.dev, srho.dev, (double *)pk);
+    DZ_HIP(hipGetLastError());
+    A.skern = (const double *)pk;
+  }
   {  // dpl, inv/CalSurfG.f90:1829-1833 (host libm sin, geometry only)
     float dpl = g.dnx * EARTH;
     float rd1 = g.dnz * EARTH * sinf(g.gox);
