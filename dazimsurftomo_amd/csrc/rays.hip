@@ -41,6 +41,7 @@ struct RayArgs {
   const dazim_refbox *boxes;
   const float *vels;       // [nz][ny][nx]
   const double *svs, *svp, *srho;  // [nz][kmax][nx*ny]
+  unsigned nvx_magic;      // ceil(2^32 / nvx): cell id / nvx = __umulhi(id, nvx_magic) for every id < 65 536 (checked on the host)
   const double *skern;     // [nz][kmax][nx*ny] svp*coe_a + srho*coe_rho + svs per model cell and period (k_row_kernels), or nullptr
   const float *lsen;       // joint mode: Lsen_Gsc [nz-1][kmax][nx*ny] (fp32, inv/CalSurfGAniso_Joint.f90:337)
   // double-precision reciprocals RN(1/d) of the loop-invariant fp32 divisors (grid spacings and 2*EARTH*spacing): see divr()
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
   const int lm = gl & 3, l0 = gl >> 2;  // this lane's cells of the 4x4 scatter: (m, l) = (lm, l0 + q*LSTEP), q < LPR
   const int nnx = g.nnx, nnz = g.nnz, nvx = g.nvx, nvz = g.nvz, ldf = nvz + 2, nf = ldf * (nvx + 2);
   constexpr int NG = AZIM ? 3 : 1;
+  const unsigned nvx_magic = A.nvx_magic;   // (cell ids are decoded in the innermost loops of the row assembly: two instructions instead of the ~20 of an integer division)
   const int LC = A.lcap;   // list capacity (<= 1024 so that 12 wavefronts fit a CU); longer lists fall back to a full-grid sweep
   unsigned short *s_list = s_lists + (size_t)grp * LC;
   float *gfdm = A.fdm_scratch + ((size_t)blockIdx.x * RPW + grp) * nf * NG;
@@ -575,7 +577,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       const size_t o = (size_t)ray * A.LK, ov = o * NG;
       for (int i = gl; i < nlist; i += GP) {
         const int c = A.lcell[o + i];
-        const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+        const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
         s_list[i] = (unsigned short)c;
         gfdm[kk * ldf + jj] = A.lval[ov + i];
         if (AZIM) {
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         const int c = base + gl;
         bool keep = false;
         if (c < nvz * nvx) {
-          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
           keep = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
         }
         const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & GMASK);
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       if (nlist <= A.LK)
         for (int i = gl; i < nlist; i += GP) {
           const int c = s_list[i];
-          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
           A.lcell[o + i] = (unsigned short)c;
           A.lval[ov + i] = gfdm[kk * ldf + jj];
           if (AZIM) {
@@ -631,14 +633,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           const int c = base + gl;
           bool k2 = false;
           if (c < nvz * nvx) {
-            const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+            const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
             k2 = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
           }
           const unsigned m2 = (unsigned)((__ballot(k2) >> gmask_shift) & GMASK);
           if (m2) clast = base + (31 - __clz(m2));
         }
       }
-      if (clast >= 0) { jjL = clast / nvx + 1; kkL = clast - (jjL - 1) * nvx + 1; }
+      if (clast >= 0) { jjL = (int)__umulhi((unsigned)clast, nvx_magic) + 1; kkL = clast - (jjL - 1) * nvx + 1; }
     }
     for (int blk = 0; blk < NG; blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
       for (int k = 1; k <= A.nz - 1; k++) {
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           bool cell = li < ntot;
           int c = 0;
           if (cell) c = lovf ? li : s_list[li];
-          const int jj = c / nvx + 1, kk = c - (jj - 1) * nvx + 1;
+          const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
           if (cell && lovf) cell = fabsf(gfdm[kk * ldf + jj]) >= FTOL;
           if (cell) {
             const size_t si = ((size_t)(k - 1) * A.kmax + kslot) * ncol + (size_t)jj * (nvx + 2) + kk;
@@ -775,6 +777,12 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
   A.lsen = joint ? lsen.dev : nullptr;
   A.skern = nullptr;
+  {
+    const unsigned d = (unsigned)g.nvx;
+    A.nvx_magic = (unsigned)((0x100000000ull + d - 1) / d);
+    for (unsigned c = 0; c < 65536u; c++)   // (cell ids are 16-bit: the identity is checked for all of them, once per call)
+      if ((unsigned)(((unsigned long long)c * A.nvx_magic) >> 32) != c / d) return dz_fail(ctx, DAZIM_E_BAD_ARG, "internal: reciprocal of nvx");
+  }
   if (!(ctx->opts.count("rays.skern") && !ctx->opts["rays.skern"])) {   // (option rays.skern = 0: every entry from the three kernels)
     void *pk;
     if ((rc = dz_scratch(ctx, "rays.skern", nk * sizeof(double), &pk))) return rc;
