@@ -412,6 +412,15 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         }
       };
       load_corner_times();
+      // What a step needs at its starting point -- velocity and B-spline weights at (x0, z0) -- is what the step before computed at
+      // its end point, bit for bit, whenever that end point was the step's (x1, z1) itself in the same cells: the last sub-segment
+      // ends at x0 + 1.0f * (x1 - x0), which is x1 exactly unless the two differ by more than a factor of two (Sterbenz), and the
+      // cell indices agree unless the point was clipped to the grid.  Checked per ray after every step; the values are carried
+      // over only while every ray of the wavefront may (a sixth of the step's instructions otherwise repeated).
+      bool carry = false;
+      float vel_c = 0.0f, vi_c = 0.0f, wi_c[LPR];
+#pragma unroll
+      for (int q = 0; q < LPR; q++) wi_c[q] = 0.0f;
       const long maxrp = (long)nnx * nnz;
       for (long j = 1; j <= maxrp; j++) {
         if (sw == 1) break;
@@ -495,15 +504,26 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         nhp++;  // the closing sub-segment with vrat = 1, chp = 0
         if (nhp == 1) vr0 = 1.0f;
         if (nhp == 2) vr1 = 1.0f;
-        float drx = (x0 - gox) - (float)(ipxo - 1) * dnx;
-        float drz = (z0 - goz) - (float)(ipzo - 1) * dnz;
-        float vel = vel_at(g, veln, ipxo, ipzo, drx, drz, rdnx, rdnz);
-        drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
-        drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
-        float vi = basis1(divr(drx, rdvx), lm), wi[LPR];  // this lane's vi(m), wi(l)
+        float drx, drz;
+        float vel = vel_c, vi = vi_c, wi[LPR];            // this lane's vi(m), wi(l)
 #pragma unroll
-        for (int q = 0; q < LPR; q++) wi[q] = basis1(divr(drz, rdvz), l0 + q * LSTEP);
+        for (int q = 0; q < LPR; q++) wi[q] = wi_c[q];
+#ifdef DZ_RAYS_NOCARRY   // experiment: every step computes its starting point
+        if (true) {
+#else
+        if (__builtin_expect(__ballot(!carry) != 0, 0)) {  // (first step, clipped points: rare -- and wave-uniform, so out of line)
+#endif
+          drx = (x0 - gox) - (float)(ipxo - 1) * dnx;
+          drz = (z0 - goz) - (float)(ipzo - 1) * dnz;
+          vel = vel_at(g, veln, ipxo, ipzo, drx, drz, rdnx, rdnz);
+          drx = (x0 - gox) - (float)(ivxo - 1) * dvx;
+          drz = (z0 - goz) - (float)(ivzo - 1) * dvz;
+          vi = basis1(divr(drx, rdvx), lm);
+#pragma unroll
+          for (int q = 0; q < LPR; q++) wi[q] = basis1(divr(drz, rdvz), l0 + q * LSTEP);
+        }
         int ivxt = ivxo, ivzt = ivzo;
+        bool endsame = false;
         for (int k = 1; k <= nhp; k++) {
           const float velo = vel, vio = vi;
           float wio[LPR];
@@ -519,6 +539,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           const float rigz = z0 + vrk * (z1 - z0);
           const float rigx = x0 + vrk * (x1 - x0);
           const int ipxt = (int)divr(rigx - gox, rdnx) + 1, ipzt = (int)divr(rigz - goz, rdnz) + 1;
+          endsame = rigx == x1 && rigz == z1 && ipxt == ipx && ipzt == ipz && ivxt == ivx && ivzt == ivz;   // (of the last sub-segment)
           drx = (rigx - gox) - (float)(ipxt - 1) * dnx;
           drz = (rigz - goz) - (float)(ipzt - 1) * dnz;
           vel = vel_at(g, veln, ipxt, ipzt, drx, drz, rdnx, rdnz);
@@ -556,6 +577,11 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
             }
           }
         }
+        carry = endsame;
+        vel_c = vel;
+        vi_c = vi;
+#pragma unroll
+        for (int q = 0; q < LPR; q++) wi_c[q] = wi[q];
         x0 = x1;
         z0 = z1;
         sinx0 = sinx1;
