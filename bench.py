@@ -422,6 +422,12 @@ def main():
     # all-reduce) even with a single rank, so that it can be exercised on a 1-GPU box
     force_dist = os.environ.get("DAZIM_BENCH_FORCE_DIST") == "1"
     use_dist = world > 1 or force_dist
+    # DAZIM_BENCH_REHEARSAL=1: the N-rank run on ONE GPU (development boxes have one): every rank on device 0, the process group over
+    # gloo, the library's collectives through its file transport (dazim_comm_init_files) -- everything of the N-rank path except
+    # RCCL itself: sharding, sharded dispersion tables, row-sharded solve with one collective per iteration, timing, the JSON line.
+    rehearsal = use_dist and os.environ.get("DAZIM_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -429,7 +435,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -452,7 +461,11 @@ def main():
         ok, uid = 1, None
         if rank == 0:
             try:
-                uid = dz.comm_unique_id()
+                if rehearsal:
+                    import tempfile
+                    uid = tempfile.mkdtemp(prefix="dazim_comm_")
+                else:
+                    uid = dz.comm_unique_id()
             except Exception as e:
                 lsmr_note = f"ncclGetUniqueId failed: {e}"
         box = [uid]
@@ -461,7 +474,10 @@ def main():
             ok = 0
         else:
             try:
-                ctx.comm_init(world, rank, box[0])
+                if rehearsal:
+                    ctx.comm_init_files(world, rank, box[0])
+                else:
+                    ctx.comm_init(world, rank, box[0])
             except Exception as e:
                 ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
         vote = torch.tensor([ok], dtype=torch.int32, device=dev)
@@ -679,8 +695,8 @@ def main():
                              "stored_bytes_per_entry": 4 + ib_aty, "stored_achieved": s_aty / stats["spmvt_s"] / 1e9,
                              "stored_frac": s_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS},
                      "m": m, "n": n, "nnz": nnz},
-            "lsmr": {"driver": ("in-library RCCL (dazim_comm_init)" if native else "torch.distributed (backend nccl = RCCL)") if use_dist
-                               else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
+            "lsmr": {"driver": (("in-library, file transport on one shared GPU (DAZIM_BENCH_REHEARSAL)" if rehearsal else "in-library RCCL (dazim_comm_init)")
+                                if native else "torch.distributed (backend nccl = RCCL)") if use_dist else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
                      # row-sharded solve: one grouped ncclAllReduce per iteration (the n floats of A_p^T u_p and the double ||u_p||^2)
                      "collectives_per_iteration": (int(stats.get("collectives_per_iteration", 1)) if use_dist else 0),
                      "host_syncs_per_iteration": (stats["host_syncs"] / max(stats["lsmr_itn"], 1)) if stats.get("host_syncs", -1) >= 0 else None,

@@ -75,8 +75,14 @@ def depthkernel_sharded(depthkernel, vel, depz, periods, minthk, world, rank, gr
         if kernels:
             for q in range(3):
                 send[1 + q, :, :, :n] = torch.as_tensor(sen_b[q], device=dev)
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    if send.is_cuda and dist.get_backend(group) == "gloo":   # (gloo gathers host tensors only: the one-GPU rehearsal of bench.py)
+        send_h = send.cpu()
+        recv_h = [torch.empty_like(send_h) for _ in range(world)]
+        dist.all_gather(recv_h, send_h, group=group)
+        recv = [r.to(dev) for r in recv_h]
+    else:
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send, group=group)
     nfail = torch.tensor([nf], dtype=torch.int64, device=dev)
     dist.all_reduce(nfail, group=group)
     cols = [(b - a) * nx for a, b in bounds]

@@ -77,6 +77,35 @@ def test_bench_two_gpus_strong_scaling_uses_the_in_library_rccl_solve():
     assert d["lsmr_iterations"] == 20
 
 
+def test_bench_two_and_three_ranks_rehearsed_on_one_gpu():
+    """The N-rank bench path on the one GPU a development box has (DAZIM_BENCH_REHEARSAL=1: every rank on device 0, process group
+    over gloo, the library's collectives through its file transport): the driver's own launch form -- torch.distributed.run with
+    one rank per "GPU" --, weak and strong scaling.  Everything of `bench.py --gpus N` runs except RCCL: the sources are sharded,
+    the dispersion tables computed in blocks of rows and joined by one all-gather, G row-sharded, the solve inside the library
+    with ONE collective per iteration over N ranks, the time is the maximum over the ranks, rank 0 prints one JSON line."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DAZIM_BENCH_REHEARSAL="1")
+    single = None
+    for n, extra in ((2, ["--scaling", "weak"]), (3, ["--scaling", "strong", "--sources", "120"])):
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+                              "127.0.0.1", "--master-port", str(29571 + n), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "s128",
+                              "--steps", "1", "--warmup", "1", "--no-cpu"] + extra, capture_output=True, text=True, timeout=1200, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1                               # rank 0 alone prints
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["value"] > 0 and d["lsmr_iterations"] == 20
+        assert d["lsmr"]["driver"].startswith("in-library") and d["lsmr"]["rccl_nranks"] == n
+        assert d["lsmr"]["collectives_per_iteration"] == 1
+        assert d["dispersion"].startswith("model rows sharded")
+        assert d["dispersion_root_failures"] == 0
+        if n == 2:      # weak: every rank its own 200 sources x 8 periods
+            assert d["scaling"] == "weak" and d["config"]["fields_per_gpu"] == 1600
+            assert abs(d["value"] * d["ms_per_step"] / 1e3 - 2 * 1600) < 1e-3   # whole-job fields per step
+        else:           # strong: 120 sources x 8 periods cut into three shards
+            assert d["scaling"] == "strong"
+            assert abs(d["value"] * d["ms_per_step"] / 1e3 - 120 * 8) < 1e-3
+
+
 def test_bench_sweep_over_all_gpus():
     """`bench.py --sweep 1,2[,4,8]`: one JSON line per count, values that grow with the count (weak scaling, reduced batch)"""
     import torch
