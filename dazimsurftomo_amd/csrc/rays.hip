@@ -668,6 +668,56 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       }
       if (clast >= 0) { jjL = (int)__umulhi((unsigned)clast, nvx_magic) + 1; kkL = clast - (jjL - 1) * nvx + 1; }
     }
+    // The usual ray (its cell list fits RC cells per lane, the combined kernels are there, no dense twin): every cell's indices and
+    // Frechet values are decoded and loaded ONCE into registers and the layers loop over them, where the general loop below decodes
+    // the cell id and reloads its Frechet value for each of the nz - 1 layers.  Same entries in the same order.
+    constexpr int RC = 8;   // (128 cells in the emit pass, where a ray of the S-256 batch has ~100; 64 in the count pass: sixteen per lane there cost the tracing loop registers, 38.1 -> 40.1 ms)
+#ifdef DZ_RAYS_NOROWCACHE
+    const bool rowcache = false;
+#else
+    const bool rowcache = !lovf && ntot <= RC * GP && A.skern != nullptr && !A.dense;
+#endif
+    if (rowcache) {
+      int sidx[RC], cbase[RC], fidx[RC];
+#pragma unroll
+      for (int i = 0; i < RC; i++) {
+        const int li = i * GP + gl;
+        const int c = li < ntot ? (int)s_list[li] : 0;
+        const int jj = (int)__umulhi((unsigned)c, nvx_magic) + 1, kk = c - (jj - 1) * nvx + 1;
+        sidx[i] = jj * (nvx + 2) + kk;
+        cbase[i] = (jj - 1) * nvx + kk;
+        fidx[i] = kk * ldf + jj;
+      }
+      for (int blk = 0; blk < NG; blk++) {
+        float fdv[RC];
+        const float *fsrc = blk == 0 ? gfdm : (blk == 1 ? gfdmc : gfdms);
+#pragma unroll
+        for (int i = 0; i < RC; i++) fdv[i] = (i * GP + gl < ntot) ? fsrc[fidx[i]] : 0.0f;
+        for (int k = 1; k <= A.nz - 1; k++) {
+          const size_t sk = ((size_t)(k - 1) * A.kmax + kslot) * ncol;
+          const int nk = blk * nparpi + (k - 1) * nvz * nvx;
+#pragma unroll
+          for (int i = 0; i < RC; i++) {
+            if (i * GP >= ntot) break;                    // (per ray: the lanes of a group leave together)
+            const bool cell = i * GP + gl < ntot;
+            float rowv = 0.0f;
+            bool keep = false;
+            if (cell) {
+              if (blk == 0) rowv = (float)(A.skern[sk + sidx[i]] * (double)fdv[i]);
+              else rowv = A.lsen[sk + sidx[i]] * fdv[i];
+              keep = A.keep_small ? (rowv != 0.0f) : (fabsf(rowv) > FTOL);
+            }
+            const unsigned m = (unsigned)((__ballot(keep) >> gmask_shift) & GMASK);
+            if (EMIT && keep) {
+              const long pos = rstart + cnt + __popc(m & ((1u << gl) - 1u));
+              A.val[pos] = rowv;
+              A.col[pos] = nk + cbase[i] - 1;
+            }
+            cnt += __popc(m);
+          }
+        }
+      }
+    } else
     for (int blk = 0; blk < NG; blk++)   // dVs | Gc | Gs column blocks (inv/CalSurfGAniso_Joint.f90:728-738)
       for (int k = 1; k <= A.nz - 1; k++) {
         for (int base = 0; base < ntot; base += GP) {
