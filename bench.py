@@ -13,8 +13,8 @@ metric; the second half (LSMR SpMV HBM GB/s) is reported in `spmv`.  With --gpus
 torch.distributed.run, one rank per GPU) every rank processes its own S sources (weak scaling, no
 data-path collective in the forward pass).
 
-The JSON line also carries `roofline` for the dominant kernel (the eikonal kernel, latency-bound:
-its HBM fraction is reported for transparency, not as a target), `spmv` (the HBM-bound kernel the
+The JSON line also carries `roofline` for the dominant kernel (the eikonal kernel, bound by instruction
+issue: useful and issued VALU rates against the measured issue peak; its HBM fraction under `roofline.hbm`), `spmv` (the HBM-bound kernel the
 40 % target applies to) and `cpu_baseline` (the oracle = plain-C port of the reference, 1 thread, on
 a bounded sample of the same workload on this box's host cores).
 
@@ -26,12 +26,13 @@ TOTAL number of sources: one fixed (period x source) field list, cut into N cont
 (dazimsurftomo_amd.distributed.shard_fields); BASELINE's 8-GPU configuration is literally
 `--gpus 8 --workload s512 --sources 8000 --scaling strong` (511 x 511 nodes, 32 periods, 8000 sources).  `--dry-launch` spawns the
 ranks, shards the work and prints the JSON skeleton without touching a GPU (gloo): the launch path's CPU test.  The row-sharded LSMR runs inside the library over its own RCCL communicator
-(dazim_comm_init; one n-float all-reduce + one scalar per iteration); if that communicator cannot be set up on every rank the
+(dazim_comm_init; ONE grouped all-reduce per iteration: the n floats of A_p^T u_p with the shard's ||u_p||^2); if that communicator cannot be set up on every rank the
 run falls back to the torch.distributed driver (dazimsurftomo_amd/distributed.py) and says so in the JSON line (`lsmr.driver`).
 
 Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_LSMR_NATIVE=0 forces the
 torch.distributed driver at N > 1, =1 the in-library RCCL path (no fallback); DAZIM_BENCH_FORCE_DIST=1 takes the multi-rank code
-path with a single rank.
+path with a single rank; DAZIM_BENCH_REHEARSAL=1 runs N ranks on ONE GPU (gloo process group, the library's file transport):
+the whole N-rank path except RCCL, for boxes with one GPU (tests/test_multigpu_gpu.py).
 """
 import argparse
 import hashlib
