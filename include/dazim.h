@@ -61,6 +61,9 @@ void dazim_destroy(dazim_ctx *ctx);
 const char *dazim_last_error(const dazim_ctx *ctx);
 int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes);
 int dazim_free(dazim_ctx *ctx, void *dptr);
+/* blocking copies on the context's stream.  After an asynchronous dazim_dispersion_kernels call (option disp.async) a copy that
+ * touches the model or one of the three kernel tables waits for the perturbed copies on the auxiliary stream first; any other
+ * copy leaves them running (dazim_get_stat "aux.pending") */
 int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes);
 int dazim_sync(dazim_ctx *ctx);
