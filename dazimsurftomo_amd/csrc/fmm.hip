@@ -1657,8 +1657,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   // stage-major the fields march in step again and the mixture of phases on a CU is lost): S-256's 16 000
   // fields on the 512-slot hybrid heap take 0.240 / 0.253 / 0.248 / 0.249 / 0.252 s with 2 / 3 / 4 / 8 / 12 coarse stages
   // (0.288 s unsliced on the 768-slot heap, same box), the 768-slot heap 0.292 / 0.264 / 0.262 s with 2 / 4 / 8-12; S-512's
-  // 32 000 fields (1024-slot hybrid heap) 4.29 s unsliced, 4.03 / 3.96 / 3.97 s with 2 / 4 / 8.  Defaults: 2 on the 512-slot hybrid
-  // heap with 16-bit ids, 8 on the one with two HBM levels (S-512: 2.68 / 2.63 / 2.61 s with 2 / 4 / 8), 4 elsewhere.
+  // 32 000 fields (1024-slot hybrid heap) 4.29 s unsliced, 4.03 / 3.96 / 3.97 s with 2 / 4 / 8.  Defaults: 2 on the 512-slot heaps
+  // with 16-bit ids (round 5, the all-LDS one on a 166 x 166 grid, 16 000 fields: 156 k fields/s with 2 stages, 122 k with 4), 8 on the one with two HBM levels (S-512: 2.68 / 2.63 / 2.61 s with 2 / 4 / 8), 4 elsewhere.
   bool ts = nfield > nslot;
   if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 1) ts = true;
   if (ctx->opts.count("fmm.ts") && ctx->opts["fmm.ts"] == 2) ts = false;
@@ -1667,7 +1667,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     size_t mfree = 0, mtot = 0;
     if (hipMemGetInfo(&mfree, &mtot) != hipSuccess || (size_t)nfield * rec_field_bytes > mfree / 4) ts = false;
   }
-  int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (HYB && CAP <= 512 ? (sizeof(NT) == 2 ? 2 : 8) : 4);
+  int nseg = ctx->opts.count("fmm.ts_stages") && ctx->opts["fmm.ts_stages"] > 0 ? ctx->opts["fmm.ts_stages"] : (CAP <= 512 ? (sizeof(NT) == 2 ? 2 : (HYB ? 8 : 4)) : 4);
   A.ts_nstage = ts ? 1 + nseg : 1;
   // (stage lengths that shrink towards the end -- a shorter tail -- were measured and lose: 0.251-0.265 s against 0.247 s)
   A.ts_pops = (int)((nn + nseg - 1) / nseg);
