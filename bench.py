@@ -25,14 +25,16 @@ torch.distributed.run directly it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 TOTAL number of sources: one fixed (period x source) field list, cut into N contiguous shards balanced by rays
 (dazimsurftomo_amd.distributed.shard_fields); BASELINE's 8-GPU configuration is literally
 `--gpus 8 --workload s512 --sources 8000 --scaling strong` (511 x 511 nodes, 32 periods, 8000 sources).  `--dry-launch` spawns the
-ranks, shards the work and prints the JSON skeleton without touching a GPU (gloo): the launch path's CPU test.  The row-sharded LSMR runs inside the library over its own RCCL communicator
-(dazim_comm_init; ONE grouped all-reduce per iteration: the n floats of A_p^T u_p with the shard's ||u_p||^2); if that communicator cannot be set up on every rank the
-run falls back to the torch.distributed driver (dazimsurftomo_amd/distributed.py) and says so in the JSON line (`lsmr.driver`).
+ranks, shards the work and prints the JSON skeleton without touching a GPU (gloo): the launch path's CPU test.  With N > 1
+everything the ranks exchange goes through the library's own communicator (dazim_comm_init: RCCL over xGMI) -- the dispersion
+tables of the model, sharded by rows inside dazim_dispersion_kernels_sharded, and the row-sharded LSMR with ONE collective per
+iteration (an all-gather of the n floats of A_p^T u_p with the shard's ||u_p||^2, summed in rank order) -- the code path of the
+Fortran program host/dazim_main.f90; a rank that cannot join is an error, there is no second driver.
 
-Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_LSMR_NATIVE=0 forces the
-torch.distributed driver at N > 1, =1 the in-library RCCL path (no fallback); DAZIM_BENCH_FORCE_DIST=1 takes the multi-rank code
-path with a single rank; DAZIM_BENCH_REHEARSAL=1 runs N ranks on ONE GPU (gloo process group, the library's file transport):
-the whole N-rank path except RCCL, for boxes with one GPU (tests/test_multigpu_gpu.py).
+Environment: DAZIM_OPTS=name=value,... sets library tuning options (tools/opt_sweep.sh); DAZIM_BENCH_FORCE_DIST=1 takes the
+multi-rank code path with a single rank; DAZIM_BENCH_REHEARSAL=1 runs N ranks on ONE GPU (gloo process group, the library's file
+transport): the whole N-rank path except RCCL, for boxes with one GPU (tests/test_multigpu_gpu.py, tests/test_rehearsal_gpu.py).
+`--dump PATH`: every rank writes PATH.<rank>.npz (x, predicted times, dispersion tables) after the timed steps.
 """
 import argparse
 import hashlib
@@ -178,17 +180,22 @@ def workload(nsrc, nrcv, rank):
     return scx, scz, per, field_of_ray, sx[ridx].copy(), sz[ridx].copy()
 
 
+RAY_SPAN = [0, 0]   # strong scaling: (this rank's first ray in the one ray list, rays in that list)
+
+
 def rank_workload(a, rank, world):
     """this rank's fields and rays.  weak: its own a.sources stations (seeded by rank); strong: shard `rank` of the one field list
     of a.sources stations x periods (period-major, as the reference orders its data), balanced by rays per field"""
     if a.scaling == "weak" or world == 1:
         scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, rank if a.scaling == "weak" else 0)
+        RAY_SPAN[:] = [0, len(rcx)]
         return scx, scz, per, field_of_ray, rcx, rcz, len(scx) * (world if a.scaling == "weak" else 1)
     from dazimsurftomo_amd.distributed import shard_fields
     scx, scz, per, field_of_ray, rcx, rcz = workload(a.sources, a.receivers, 0)
     nfield = len(scx)
     f0, f1 = shard_fields(nfield, world, rank, np.bincount(field_of_ray, minlength=nfield))
     r0, r1 = np.searchsorted(field_of_ray, [f0, f1])
+    RAY_SPAN[:] = [int(r0), len(rcx)]      # this rank's first ray in the one list, rays in the list
     return (scx[f0:f1].copy(), scz[f0:f1].copy(), per[f0:f1].copy(), (field_of_ray[r0:r1] - f0).astype(np.int32),
             rcx[r0:r1].copy(), rcz[r0:r1].copy(), nfield)
 
@@ -372,6 +379,8 @@ def main():
                     help="weak: --sources per GPU; strong: --sources in total, one field list sharded over the ranks")
     ap.add_argument("--sweep", default=None, help="comma-separated GPU counts, e.g. 1,2,4,8: one run and one JSON line per count "
                                                   "(each launched as `bench.py --gpus N` with the other flags unchanged)")
+    ap.add_argument("--dump", default=None, help="after the timed steps every rank writes <path>.<rank>.npz: x of the last solve, its "
+                                                 "predicted times and their place in the ray list (tests: N ranks against one)")
     ap.add_argument("--dry-launch", action="store_true", help="spawn the ranks and shard the work, no GPU (CPU test of the launch path)")
     a = ap.parse_args()
     if a.sources is None:
@@ -452,11 +461,11 @@ def main():
     for kv in os.environ.get("DAZIM_OPTS", "").split(","):   # tuning experiments: DAZIM_OPTS=rays.wg_per_cu=4,fmm.wg_per_cu=6
         if "=" in kv:
             ctx.set_option(*kv.split("="))
-    # N > 1: the row-sharded LSMR.  Default: inside the C library with its own RCCL communicator (dazim_comm_init), set up
-    # here and confirmed by every rank; if any rank cannot join, all ranks fall back together to the Python driver over
-    # torch.distributed (backend nccl = RCCL).  DAZIM_LSMR_NATIVE=0 / 1 forces one or the other.
-    want = os.environ.get("DAZIM_LSMR_NATIVE", "auto")
-    native = use_dist and want != "0"
+    # N > 1: ONE multi-rank path, the library's (the same the Fortran program takes): its own communicator (dazim_comm_init: RCCL;
+    # rehearsal: files), the model's dispersion tables sharded inside dazim_dispersion_kernels_sharded, the row-sharded LSMR with one
+    # collective per iteration.  torch.distributed only carries the 128-byte id, the barriers and the timing reductions.  A rank
+    # that cannot join is an error on every rank (vote first, raise afterwards: nobody is left waiting in a collective).
+    native = use_dist
     lsmr_note = ""
     if native:
         ok, uid = 1, None
@@ -480,16 +489,13 @@ def main():
                 else:
                     ctx.comm_init(world, rank, box[0])
             except Exception as e:
-                ok, lsmr_note = 0, f"in-library RCCL set-up failed on rank {rank}: {e}"
+                ok, lsmr_note = 0, f"in-library communicator set-up failed on rank {rank}: {e}"
         vote = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN)     # (vote first, raise afterwards: no rank is left waiting in the collective)
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
         if int(vote.item()) == 0:
             if ok:
                 ctx.comm_free()
-            native = False
-            lsmr_note = lsmr_note or "in-library RCCL set-up failed on another rank"
-            if want == "1":
-                raise RuntimeError(lsmr_note)
+            raise RuntimeError(lsmr_note or "in-library communicator set-up failed on another rank")
 
     kmax = len(PERIODS)
     vel = s256_model()
@@ -515,12 +521,16 @@ def main():
     c3_all, t_ir, t_ic, t_rw = tikhonov_rows(NX, NY, nz, nray, 2.0)
     c3 = c3_all
     if use_dist:   # every rank keeps its own ray rows + an even slice of the Tikhonov rows
-        from dazimsurftomo_amd.distributed import GpuLocalOps, lsmr_distributed, shard_rows
+        from dazimsurftomo_amd.distributed import shard_rows
         r0, r1 = shard_rows(c3_all, world, rank)
         keep = (t_ir > nray + r0) & (t_ir <= nray + r1)
         t_ir, t_ic, t_rw, c3 = (t_ir[keep] - r0).astype(np.int32), t_ic[keep], t_rw[keep], r1 - r0
-    rng = np.random.default_rng(3 + rank)
-    d_b = T(np.concatenate([(rng.standard_normal(nray) * 0.5).astype(np.float32), np.zeros(c3, np.float32)]))
+    if a.scaling == "strong":   # one right-hand side for the one ray list, whatever the number of ranks (tests compare N ranks with one)
+        b_all = (np.random.default_rng(3).standard_normal(RAY_SPAN[1]) * 0.5).astype(np.float32)
+        b_rays = b_all[RAY_SPAN[0]:RAY_SPAN[0] + nray]
+    else:
+        b_rays = (np.random.default_rng(3 + rank).standard_normal(nray) * 0.5).astype(np.float32)
+    d_b = T(np.concatenate([b_rays, np.zeros(c3, np.float32)]))
     d_x = torch.zeros(n_model, dtype=torch.float32, device=dev)
 
     stats = {}
@@ -533,26 +543,21 @@ def main():
         wall[name] = wall.get(name, 0.0) + now - tw[0]
         tw[0] = now
 
-    # N > 1: the dispersion tables belong to the model every rank shares -- each rank computes a block of its rows and one
-    # all-gather (RCCL) joins them (dazimsurftomo_amd.distributed.depthkernel_sharded; DAZIM_SHARD_DISP=0: every rank all of it)
+    # N > 1: the dispersion tables belong to the model every rank shares -- each rank computes a block of its rows and all-gathers
+    # inside the library join them (dazim_dispersion_kernels_sharded, the entry host/dazim_mod.f90's dazim_assemble_G calls too;
+    # DAZIM_SHARD_DISP=0: every rank all of it)
     shard_disp = use_dist and os.environ.get("DAZIM_SHARD_DISP", "1") != "0"
     # The perturbed copies of the dispersion kernel (72/73 of its work, wanted by the G rows only) on the library's auxiliary
     # stream: the eikonal kernel shares the chip with their last, partly filled round.  DAZIM_DISP_ASYNC=0: one stream.
-    disp_async = not shard_disp and os.environ.get("DAZIM_DISP_ASYNC", "1") != "0"
+    disp_async = os.environ.get("DAZIM_DISP_ASYNC", "1") != "0"
     if disp_async:
         ctx.set_option("disp.async", 1)
+    last = {}
 
     def step():
         tw[0] = time.perf_counter()
-        if shard_disp:
-            from dazimsurftomo_amd.distributed import depthkernel_sharded
-            t_d = time.perf_counter()
-            pv, sen, nfail = depthkernel_sharded(ctx.depthkernel, d_vel, DEPZ, PERIODS, MINTHK, world, rank)
-            torch.cuda.synchronize()                        # (the library launches on its own stream)
-            stats["disp_s"] = time.perf_counter() - t_d     # local curves + all-gather
-        else:
-            pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
-            stats["disp_s"] = ctx.kernel_seconds("disp")            # (disp.async: the column curves; the copies overlap what follows)
+        pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen, sharded=shard_disp)
+        stats["disp_s"] = ctx.kernel_seconds("disp")            # (disp.async: the column curves; the copies overlap what follows)
         lap("depthkernel")
         fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
@@ -571,20 +576,14 @@ def main():
         G.append_coo(c3, t_ir, t_ic, t_rw)
         lap("append")
         stats["nnz"], stats["m"], stats["n"] = G.nnz, G.m, G.n
-        if not use_dist or native:
-            x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
-            stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
-            stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
-            stats["nranks"] = ctx.kernel_seconds("lsmr.nranks")
-            stats["collectives_per_iteration"] = ctx.kernel_seconds("lsmr.collectives_per_iteration")
-            stats["host_syncs"] = ctx.kernel_seconds("lsmr.host_syncs")      # counted by the library around the iteration loop
-        else:           # row-partitioned G, one RCCL all-reduce of G^T u (n floats) + one scalar per iteration
-            t_l = time.perf_counter()
-            x, info = lsmr_distributed(GpuLocalOps(ctx, G), d_b, n_model, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10)
-            torch.cuda.synchronize()
-            stats["lsmr_s"] = time.perf_counter() - t_l
-            stats["host_syncs"] = info.get("host_syncs", -1)
-            stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        x, info = ctx.lsmr(G, d_b, 0.01, 1e-9, 1e-9, 1e9, a.lsmr_iters, 10, x=d_x)   # fixed iteration count
+        stats["lsmr_s"] = ctx.kernel_seconds("lsmr")
+        stats["spmv_s"], stats["spmvt_s"] = ctx.kernel_seconds("spmv"), ctx.kernel_seconds("spmvt")
+        stats["nranks"] = ctx.kernel_seconds("lsmr.nranks")
+        stats["collectives_per_iteration"] = ctx.kernel_seconds("lsmr.collectives_per_iteration")   # counted by the library
+        stats["collective_kind"] = ctx.kernel_seconds("lsmr.collective_kind")
+        stats["host_syncs"] = ctx.kernel_seconds("lsmr.host_syncs")      # counted by the library around the iteration loop
+        last["x"], last["tpred"] = x, tpred
         stats["spmv_kind"], stats["spmvt_kind"] = ctx.kernel_seconds("spmv.kind"), ctx.kernel_seconds("spmvt.kind")
         stats["ax_idx_bytes"], stats["aty_idx_bytes"] = ctx.kernel_seconds("spmv.idx_bytes"), ctx.kernel_seconds("spmvt.idx_bytes")
         stats["lsmr_itn"] = info["itn"]
@@ -696,13 +695,15 @@ def main():
                              "stored_bytes_per_entry": 4 + ib_aty, "stored_achieved": s_aty / stats["spmvt_s"] / 1e9,
                              "stored_frac": s_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS},
                      "m": m, "n": n, "nnz": nnz},
-            "lsmr": {"driver": (("in-library, file transport on one shared GPU (DAZIM_BENCH_REHEARSAL)" if rehearsal else "in-library RCCL (dazim_comm_init)")
-                                if native else "torch.distributed (backend nccl = RCCL)") if use_dist else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
-                     # row-sharded solve: one grouped ncclAllReduce per iteration (the n floats of A_p^T u_p and the double ||u_p||^2)
-                     "collectives_per_iteration": (int(stats.get("collectives_per_iteration", 1)) if use_dist else 0),
+            "lsmr": {"driver": ("in-library, file transport on one shared GPU (DAZIM_BENCH_REHEARSAL)" if rehearsal else "in-library RCCL (dazim_comm_init)")
+                               if use_dist else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
+                     # row-sharded solve: ONE collective per iteration, counted by the library (collectives issued / iterations enqueued):
+                     # an all-gather of the n floats of A_p^T u_p with the double ||u_p||^2, summed in rank order on the device
+                     "collectives_per_iteration": (stats.get("collectives_per_iteration", 0) if use_dist else 0),
+                     "collective": {0: None, 1: "all-gather + rank-ordered sums (deterministic)", 2: "ncclAllReduce (option comm.allreduce)"}[int(stats.get("collective_kind", 0))],
                      "host_syncs_per_iteration": (stats["host_syncs"] / max(stats["lsmr_itn"], 1)) if stats.get("host_syncs", -1) >= 0 else None,
                      "host_syncs_note": "host waits on the device counted by the solver during its iteration loop / iterations"},
-            "dispersion": ("model rows sharded over the ranks, tables joined by one all-gather (RCCL)" if shard_disp
+            "dispersion": ("model rows sharded over the ranks inside the library (dazim_dispersion_kernels_sharded), tables joined by all-gathers" if shard_disp
                            else ("every rank computes the whole model's tables" if use_dist else "single GPU")),
             "phases_s": {k: stats[k] for k in ("disp_s", "fmm_s", "rays_s", "lsmr_s")},
             "dispersion_streams": ({"async": True, "column_curves_s": stats["disp_s"], "perturbed_copies_s": stats.get("disp_copies_s"),
@@ -725,9 +726,12 @@ def main():
         result_line = json.dumps(out)
     else:
         result_line = None
+    if a.dump:
+        torch.cuda.synchronize()
+        np.savez(f"{a.dump}.{rank}.npz", x=last["x"].cpu().numpy(), tpred=last["tpred"].cpu().numpy(), ray0=RAY_SPAN[0], nray_all=RAY_SPAN[1],
+                 pv=d_pv.cpu().numpy(), sen_vs=d_sen[0].cpu().numpy())
     if use_dist:
-        if native:
-            ctx.comm_free()
+        ctx.comm_free()
         dist.barrier()
         dist.destroy_process_group()
     import ctypes

@@ -132,13 +132,31 @@ class Context:
         self._check(self.lib.dazim_comm_allreduce(self._h, C.c_void_p(arr.ctypes.data), C.c_int64(arr.size), dt, 0 if op == "sum" else 1))
         return arr
 
+    def comm_allgather(self, send, recv=None):
+        """all-gather over the ranks: numpy `send` (float32, float64 or int64) -> recv[nranks, send.size]; one rank: a copy"""
+        dt = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int64): 2}[send.dtype]
+        nr = int(self.stat_or("comm.nranks", 1))
+        if recv is None:
+            recv = np.zeros((nr, send.size), send.dtype)
+        assert send.flags.c_contiguous and recv.flags.c_contiguous and recv.size == nr * send.size
+        self._check(self.lib.dazim_comm_allgather(self._h, C.c_void_p(send.ctypes.data), C.c_void_p(recv.ctypes.data), C.c_int64(send.size), dt))
+        return recv
+
+    def stat_or(self, name, default):
+        try:
+            return self.stat(name)
+        except KeyError:
+            return default
+
     def comm_free(self):
         self._check(self.lib.dazim_comm_free(self._h))
 
     # ---- K1 ---------------------------------------------------------------------------------
-    def depthkernel(self, vel, depz, tRc, minthk, kernels=True, pv=None, sen=None):
+    def depthkernel(self, vel, depz, tRc, minthk, kernels=True, pv=None, sen=None, sharded=False):
         """depthkernel (inv/CalSurfG.f90:1): vel[nz][ny][nx] -> pvRc[kmax][nx*ny] and, if `kernels`,
-        (sen_vs, sen_vp, sen_rho)[nz][kmax][nx*ny].  Returns (pv, sen, n_failed)."""
+        (sen_vs, sen_vp, sen_rho)[nz][kmax][nx*ny].  Returns (pv, sen, n_failed).
+        sharded: dazim_dispersion_kernels_sharded -- with a communicator attached this rank computes its block of the model's
+        rows and all-gathers join the tables (every rank must call)."""
         nz, ny, nx = vel.shape
         depz = np.ascontiguousarray(depz, np.float32)
         tRc = np.ascontiguousarray(tRc, np.float64)
@@ -157,8 +175,9 @@ class Context:
                 sen = [np.zeros((nz, kmax, nx * ny), np.float64) for _ in range(3)]
         nf = C.c_int(0)
         sp = [_ptr(a) for a in sen] if kernels else [None] * 3
-        rc = self.lib.dazim_dispersion_kernels(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk),
-                                               kmax, _ptr(tRc), _ptr(pv), sp[0], sp[1], sp[2], C.byref(nf))
+        fn = self.lib.dazim_dispersion_kernels_sharded if sharded else self.lib.dazim_dispersion_kernels
+        rc = fn(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk),
+                kmax, _ptr(tRc), _ptr(pv), sp[0], sp[1], sp[2], C.byref(nf))
         self._check(rc)
         return pv, (sen if kernels else None), nf.value
 
@@ -182,9 +201,9 @@ class Context:
         return (cg[0] if single else cg), nf.value
 
     # ---- N1 --------------------------------------------------------------------------------
-    def ti_kernels(self, vel, depz, tRc, minthk, pv, lsen=None):
+    def ti_kernels(self, vel, depz, tRc, minthk, pv, lsen=None, sharded=False):
         """depthkernelTI/tregn96 (inv/depthkernelTI.f90:2): vel[nz][ny][nx] and pvRc[kmax][nx*ny] (output of
-        depthkernel) -> Lsen_Gsc[nz-1][kmax][nx*ny] fp32."""
+        depthkernel) -> Lsen_Gsc[nz-1][kmax][nx*ny] fp32.  sharded: dazim_ti_kernels_sharded (see depthkernel)."""
         nz, ny, nx = vel.shape
         depz = np.ascontiguousarray(depz, np.float32)
         tRc = np.ascontiguousarray(tRc, np.float64)
@@ -198,8 +217,8 @@ class Context:
             pv = np.ascontiguousarray(pv, np.float64)
             if lsen is None:
                 lsen = np.zeros((nz - 1, kmax, nx * ny), np.float32)
-        rc = self.lib.dazim_ti_kernels(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk), kmax,
-                                       _ptr(tRc), _ptr(pv), _ptr(lsen))
+        fn = self.lib.dazim_ti_kernels_sharded if sharded else self.lib.dazim_ti_kernels
+        rc = fn(self._h, nx, ny, nz, _ptr(vel, np.float32), _ptr(depz), C.c_float(minthk), kmax, _ptr(tRc), _ptr(pv), _ptr(lsen))
         self._check(rc)
         return lsen
 

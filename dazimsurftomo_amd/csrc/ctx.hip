@@ -200,6 +200,11 @@ int dz_join_aux(dazim_ctx *ctx) {
   DZ_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_a1, 0));
   ctx->aux_pending = false;
   ctx->aux_ranges.clear();
+  if (ctx->aux_epilogue) {   // (sharded dispersion tables: the all-gather that follows the perturbed copies, on the main stream)
+    auto f = ctx->aux_epilogue;
+    ctx->aux_epilogue = nullptr;
+    return f(ctx);
+  }
   return 0;
 }
 int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes) {
@@ -266,6 +271,7 @@ int dazim_create(dazim_ctx **out, int device) {
 void dazim_destroy(dazim_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  ctx->aux_epilogue = nullptr;   // (no collective on the way out)
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && ctx->comm_release) ctx->comm_release(ctx);
@@ -296,6 +302,7 @@ int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes) {
   return 0;
 }
 int dazim_free(dazim_ctx *ctx, void *dptr) {
+  if (ctx->aux_epilogue) { int rcj = dz_join_aux(ctx); if (rcj) return rcj; }
   if (ctx->stream2) DZ_HIP(hipStreamSynchronize(ctx->stream2));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
   DZ_HIP(hipFree(dptr));
@@ -320,6 +327,7 @@ int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
   return 0;
 }
 int dazim_sync(dazim_ctx *ctx) {
+  if (ctx->aux_epilogue) { int rcj = dz_join_aux(ctx); if (rcj) return rcj; }
   if (ctx->stream2) DZ_HIP(hipStreamSynchronize(ctx->stream2));
   ctx->aux_pending = false;
   ctx->aux_ranges.clear();
@@ -379,6 +387,10 @@ int dazim_get_stat(const dazim_ctx *ctx, const char *name, double *value) {
   }
   if (std::string(name) == "aux.pending") {   // 1 while work handed to the auxiliary stream has not been joined by the main stream
     *value = ctx->aux_pending ? 1.0 : 0.0;
+    return 0;
+  }
+  if (std::string(name) == "comm.nranks" || std::string(name) == "comm.rank") {   // the attached communicator (1, 0 without one)
+    *value = name[5] == 'n' ? ctx->nranks : ctx->rank;
     return 0;
   }
   auto it = ctx->ksec.find(name);

@@ -1,6 +1,7 @@
 // dazim_internal.h -- shared plumbing of libdazim_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -40,12 +41,49 @@ struct dazim_ctx {
   // touches none of them does not have to wait for it (dazim_memcpy_h2d / _d2h)
   struct AuxRange { const char *p; size_t bytes; };
   std::vector<AuxRange> aux_ranges;
+  // what the join of the auxiliary stream still has to do on the MAIN stream (dazim_dispersion_kernels_sharded: the all-gather
+  // of the ranks' blocks of the depth-kernel tables); run once by dz_join_aux / dazim_sync, dropped by dazim_destroy
+  int (*aux_epilogue)(dazim_ctx *) = nullptr;
+  struct ShardPending {
+    int nx = 0, ny = 0, nz = 0, kmax = 0;
+    const double *send = nullptr;                     // this rank's blocks of sen_vs | sen_vp | sen_rho
+    double *svs = nullptr, *svp = nullptr, *srho = nullptr;   // the complete tables (device)
+  } shard;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
 };
 
 int dz_fail(dazim_ctx *c, int code, const char *fmt, ...);
+
+// ---- the communicator of a multi-rank run (comm.hip) ---------------------------------------------------------------------------
+struct DzComm {
+  ncclComm_t nccl = nullptr;
+  std::string dir;        // non-empty: the file transport (tests: several ranks on ONE GPU)
+  std::string tag;        // ... the nonce every file of this communicator carries in its name
+  unsigned seq = 0;
+  int nranks = 1, rank = 0;
+};
+enum { DZ_F32 = 0, DZ_F64 = 1, DZ_I64 = 2, DZ_SUM = 0, DZ_MAX = 1 };
+// recv[r*bytes .. (r+1)*bytes) = rank r's `bytes` bytes at send, every rank the same; DEVICE buffers, on the context's stream
+int dz_allgather(dazim_ctx *ctx, DzComm *c, const void *send_dev, void *recv_dev, size_t bytes);
+// in-place sum / max over the ranks of a DEVICE buffer on the context's stream: all-gather + one kernel that combines the ranks'
+// values in RANK ORDER (the same bits on every rank, with every transport and every rank count's grouping)
+int dz_allreduce(dazim_ctx *ctx, DzComm *c, void *dbuf, size_t count, int dtype, int op);
+// a rank that fails on its own after the others may already wait in a collective: abort the communicator, detach it
+void dz_comm_abort(dazim_ctx *ctx);
+// even contiguous split of n items over the ranks (dazim_shard_rows of host/dazim_mod.f90, shard_rows of distributed.py)
+static inline void dz_shard_even(int64_t n, int world, int rank, int64_t *lo, int64_t *hi) {
+  const int64_t base = n / world, rem = n % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+
+#define DZ_NCCL(call)                                                                                        \
+  do {                                                                                                        \
+    ncclResult_t r_ = (call);                                                                                 \
+    if (r_ != ncclSuccess) return dz_fail(ctx, -2000 - (int)r_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
+  } while (0)
 int dz_aux_init(dazim_ctx *ctx);                  // creates the auxiliary stream and its events on first use
 int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what the auxiliary stream was given (no host wait)
 int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes);   // ... only if [dev, dev + bytes) overlaps what it works on

@@ -379,7 +379,8 @@ __global__ void k_beta_scal_u(int64_t m, float *u, const double *part, int np, c
 // Row-sharded solve, ONE collective per iteration (round 5).  The two all-reduces of an iteration used to depend on each other:
 // ||u||^2 had to be summed over the ranks before u could be scaled, and only the scaled u went into A_p^T u_p.  A^T is linear, so
 // each rank now scales its shard by its OWN norm (u_p / beta_p: entries <= 1, which the fixed-point scatter relies on), forms
-// w_p = beta_p A_p^T (u_p / beta_p) = A_p^T u_p, and one grouped all-reduce carries the n floats of w and the double beta_p^2;
+// w_p = beta_p A_p^T (u_p / beta_p) = A_p^T u_p, and ONE collective carries the n floats of w and the double beta_p^2 (round 6: an
+// all-gather of the ranks' buffers, summed in rank order by k_beta_axpby; a grouped ncclAllReduce with option comm.allreduce);
 // afterwards beta = sqrt(sum beta_p^2), v = w / beta - beta v and u_p <- (u_p / beta_p) (beta_p / beta).
 // k_local_norm_scal: beta_p^2 -> sum[0], beta_p -> bp[0], u_p /= beta_p.
 __global__ void k_local_norm_scal(int64_t m, float *u, const double *part, int np, double *sum, float *bp, const LsmrState *S) {
@@ -399,12 +400,17 @@ __global__ void k_scale_by(int64_t n, float *w, const float *f, const int *guard
   const float a = f[0];
   for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) w[i] = a * w[i];
 }
-// after the all-reduce: beta (:487), localVEnqueue(v) (:490-492), u_p = u / beta, v = A^T u - beta v (:496-497) from w = sum_p A_p^T u_p,
-// partials of ||v||^2.  beta == 0 skips the second half-step (stop2), as in k_beta_scal_u.
-__global__ void k_beta_axpby(int64_t m, float *u, int64_t n, float *v, const float *w, const double *sum, const float *bp,
-                             float *lv_slot, double *part, LsmrState *S) {
+// after the collective: beta (:487), localVEnqueue(v) (:490-492), u_p = u / beta, v = A^T u - beta v (:496-497) from w = sum_p A_p^T u_p,
+// partials of ||v||^2.  beta == 0 skips the second half-step (stop2), as in k_beta_scal_u.  The collective is an all-gather: rank r's
+// n floats of w_r and its double beta_r^2 (at byte offset sum_off) sit at gathered + r*stride, and the sums over the ranks are formed
+// HERE, in rank order -- the same bits on every rank and with every transport (SURVEY 8e "fix reduction order").  nr = 1: `gathered`
+// holds sums already (option comm.allreduce).
+__global__ void k_beta_axpby(int64_t m, float *u, int64_t n, float *v, const char *__restrict__ gathered, int nr, size_t stride,
+                             size_t sum_off, const float *bp, float *lv_slot, double *part, LsmrState *S) {
   if (S->stop) return;
-  const float beta = (float)sqrt(sum[0]);
+  double t = *reinterpret_cast<const double *>(gathered + sum_off);
+  for (int r = 1; r < nr; r++) t += *reinterpret_cast<const double *>(gathered + (size_t)r * stride + sum_off);
+  const float beta = (float)sqrt(t);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     S->beta = beta;
     S->stop2 = !(beta > 0.0f);
@@ -416,7 +422,9 @@ __global__ void k_beta_axpby(int64_t m, float *u, int64_t n, float *v, const flo
     for (int64_t i = (int64_t)blockIdx.x * VB + threadIdx.x; i < n; i += (int64_t)gridDim.x * VB) {
       const float vi = v[i];
       if (lv_slot) lv_slot[i] = vi;
-      const float o = -beta * vi + rb * w[i];
+      float w = reinterpret_cast<const float *>(gathered)[i];
+      for (int r = 1; r < nr; r++) w += reinterpret_cast<const float *>(gathered + (size_t)r * stride)[i];
+      const float o = -beta * vi + rb * w;
       v[i] = o;
       sq += (double)o * o;
     }
@@ -1747,162 +1755,6 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x_u, float 
   return 0;
 }
 
-#define DZ_NCCL(call)                                                                                        \
-  do {                                                                                                        \
-    ncclResult_t r_ = (call);                                                                                 \
-    if (r_ != ncclSuccess) return dz_fail(ctx, -2000 - (int)r_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
-  } while (0)
-
-// ---- the communicator of a row-sharded run -------------------------------------------------------------------------------------
-// Two transports behind one interface (round 5).  RCCL (dazim_comm_init): ncclAllReduce on the context's stream, over xGMI -- the
-// product.  Files (dazim_comm_init_files): every collective is staged through the host and a directory all ranks can see -- each
-// rank publishes its buffer as <dir>/ar<seq>.<rank> (written under a temporary name, then renamed), waits for the others' and
-// adds them up in rank order, so that every rank gets the same bits.  Slow (a stream synchronisation and a few file operations
-// per collective) and only there so that the WHOLE multi-rank path -- the library's sharded LSMR, the sharded host program --
-// runs with two or three processes on a box with ONE GPU, where RCCL refuses a device used twice (tests/test_multirank_files_gpu.py).
-struct DzComm {
-  ncclComm_t nccl = nullptr;
-  std::string dir;        // non-empty: the file transport
-  unsigned seq = 0;
-  int nranks = 1, rank = 0;
-};
-enum { DZ_F32 = 0, DZ_F64 = 1, DZ_I64 = 2, DZ_SUM = 0, DZ_MAX = 1 };
-static int dz_files_allreduce(dazim_ctx *ctx, DzComm *c, void *host, size_t count, int dtype, int op) {
-  const size_t esz = dtype == DZ_F32 ? 4 : 8, bytes = count * esz;
-  const unsigned seq = ++c->seq;
-  auto path = [&](unsigned s_, int r) { return c->dir + "/ar" + std::to_string(s_) + "." + std::to_string(r); };
-  {
-    const std::string tmp = path(seq, c->rank) + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
-    if (!f || fwrite(host, 1, bytes, f) != bytes) { if (f) fclose(f); return dz_fail(ctx, -2100, "file transport: cannot write %s", tmp.c_str()); }
-    fclose(f);
-    if (rename(tmp.c_str(), path(seq, c->rank).c_str()) != 0) return dz_fail(ctx, -2100, "file transport: cannot publish %s", tmp.c_str());
-  }
-  std::vector<char> acc(bytes), in(bytes);
-  for (int r = 0; r < c->nranks; r++) {   // rank order: the same sum on every rank
-    const std::string pr = path(seq, r);
-    FILE *f = nullptr;
-    for (int spin = 0; spin < 600000 && !(f = fopen(pr.c_str(), "rb")); spin++) usleep(200);   // <= 120 s
-    if (!f) return dz_fail(ctx, -2101, "file transport: rank %d never published collective %u (%s)", r, seq, pr.c_str());
-    const size_t got = fread(in.data(), 1, bytes, f);
-    fclose(f);
-    if (got != bytes) return dz_fail(ctx, -2102, "file transport: %s holds %zu bytes, %zu expected (the ranks disagree on a size)", pr.c_str(), got, bytes);
-    if (r == 0) { memcpy(acc.data(), in.data(), bytes); continue; }
-    for (size_t i = 0; i < count; i++) {
-      if (dtype == DZ_F32) { float *a = (float *)acc.data(); const float b = ((const float *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
-      else if (dtype == DZ_F64) { double *a = (double *)acc.data(); const double b = ((const double *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
-      else { long long *a = (long long *)acc.data(); const long long b = ((const long long *)in.data())[i]; a[i] = op == DZ_SUM ? a[i] + b : (a[i] > b ? a[i] : b); }
-    }
-  }
-  memcpy(host, acc.data(), bytes);
-  // every rank has published collective `seq`, hence finished reading collective seq - 1: this rank's file of it can go
-  if (seq > 1) (void)remove(path(seq - 1, c->rank).c_str());
-  return 0;
-}
-// in-place all-reduce of a DEVICE buffer on the context's stream (RCCL), or staged through the host (files)
-static int dz_allreduce(dazim_ctx *ctx, DzComm *c, void *dbuf, size_t count, int dtype, int op) {
-  if (c->dir.empty()) {
-    const ncclDataType_t t = dtype == DZ_F32 ? ncclFloat : (dtype == DZ_F64 ? ncclDouble : ncclInt64);
-    const ncclResult_t r = ncclAllReduce(dbuf, dbuf, count, t, op == DZ_SUM ? ncclSum : ncclMax, c->nccl, ctx->stream);
-    if (r != ncclSuccess) return dz_fail(ctx, -2000 - (int)r, "ncclAllReduce -> %s", ncclGetErrorString(r));
-    return 0;
-  }
-  const size_t bytes = count * (dtype == DZ_F32 ? 4 : 8);
-  std::vector<char> h(bytes);
-  DZ_HIP(hipMemcpyAsync(h.data(), dbuf, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  DZ_HIP(hipStreamSynchronize(ctx->stream));
-  const int rc = dz_files_allreduce(ctx, c, h.data(), count, dtype, op);
-  if (rc) return rc;
-  DZ_HIP(hipMemcpyAsync(dbuf, h.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-  DZ_HIP(hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-static void dz_comm_group(DzComm *c, bool begin) {
-  if (c->dir.empty()) { if (begin) (void)ncclGroupStart(); else (void)ncclGroupEnd(); }
-}
-
-static int dz_files_or_stage_allreduce(dazim_ctx *ctx, double *host, int count);
-int dazim_comm_unique_id(void *id128) {
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
-  if (!id128) return DAZIM_E_BAD_ARG;
-  ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) return -2000;
-  memcpy(id128, &id, sizeof id);
-  return 0;
-}
-int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128) {
-  if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_init");
-  if (ctx->comm) return dz_fail(ctx, DAZIM_E_BAD_ARG, "a communicator is already attached");
-  DZ_HIP(hipSetDevice(ctx->device));
-  ncclUniqueId id;
-  memcpy(&id, id128, sizeof id);
-  ncclComm_t comm;
-  DZ_NCCL(ncclCommInitRank(&comm, nranks, id, rank));
-  DzComm *c = new DzComm;
-  c->nccl = comm;
-  c->nranks = nranks;
-  c->rank = rank;
-  ctx->comm = (void *)c;
-  ctx->comm_release = [](dazim_ctx *cx) { (void)dazim_comm_free(cx); };
-  ctx->nranks = nranks;
-  ctx->rank = rank;
-  return 0;
-}
-int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir) {
-  if (!ctx || !dir || !dir[0] || nranks < 1 || rank < 0 || rank >= nranks) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_init_files");
-  if (ctx->comm) return dz_fail(ctx, DAZIM_E_BAD_ARG, "a communicator is already attached");
-  DzComm *c = new DzComm;
-  c->dir = dir;
-  c->nranks = nranks;
-  c->rank = rank;
-  ctx->comm = (void *)c;
-  ctx->comm_release = [](dazim_ctx *cx) { (void)dazim_comm_free(cx); };
-  ctx->nranks = nranks;
-  ctx->rank = rank;
-  return 0;
-}
-int dazim_comm_free(dazim_ctx *ctx) {
-  if (!ctx) return DAZIM_E_BAD_ARG;
-  if (ctx->comm) {
-    DzComm *c = (DzComm *)ctx->comm;
-    DZ_HIP(hipStreamSynchronize(ctx->stream));
-    if (c->nccl) DZ_NCCL(ncclCommDestroy(c->nccl));
-    delete c;
-  }
-  ctx->comm = nullptr;
-  ctx->nranks = 1;
-  ctx->rank = 0;
-  return 0;
-}
-// sum / max over the ranks of `count` values, in place; buf is a host or a device pointer.  dtype: 0 fp32, 1 fp64, 2 int64; op: 0 sum,
-// 1 max.  Without a communicator (one rank) nothing happens.  What the sharded host program reduces with: residual statistics,
-// column sums, the predicted times it writes out.
-int dazim_comm_allreduce(dazim_ctx *ctx, void *buf, int64_t count, int dtype, int op) {
-  if (!ctx || !buf || count < 0 || dtype < 0 || dtype > 2 || op < 0 || op > 1) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_comm_allreduce");
-  if (!ctx->comm || count == 0) return 0;
-  DzComm *c = (DzComm *)ctx->comm;
-  DZ_HIP(hipSetDevice(ctx->device));
-  hipPointerAttribute_t at;
-  const bool dev = hipPointerGetAttributes(&at, buf) == hipSuccess && at.type == hipMemoryTypeDevice;
-  if (!dev) (void)hipGetLastError();
-  const size_t bytes = (size_t)count * (dtype == DZ_F32 ? 4 : 8);
-  if (dev) {
-    const int rc = dz_allreduce(ctx, c, buf, (size_t)count, dtype, op);
-    if (rc) return rc;
-    DZ_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
-  }
-  if (!c->dir.empty()) return dz_files_allreduce(ctx, c, buf, (size_t)count, dtype, op);
-  void *p;
-  int rc;
-  if ((rc = dz_scratch(ctx, "comm.stage", bytes, &p))) return rc;
-  DZ_HIP(hipMemcpyAsync(p, buf, bytes, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = dz_allreduce(ctx, c, p, (size_t)count, dtype, op))) return rc;
-  DZ_HIP(hipMemcpyAsync(buf, p, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  DZ_HIP(hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-
 static int dz_files_or_stage_allreduce(dazim_ctx *ctx, double *host, int count) {   // sum of a few host doubles over the ranks
   return dazim_comm_allreduce(ctx, host, count, DZ_F64, DZ_SUM);
 }
@@ -1925,6 +1777,8 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   double *d_sum = nullptr;
   long long *d_cons = nullptr;
   float *wbuf = nullptr;
+  char *gbuf = nullptr;
+  const size_t w_sum_off = (((size_t)n * 4 + 7) / 8) * 8, w_bytes = w_sum_off + 8;
   int64_t m_glob = m;
   int localVecs = 0;
   float *u = nullptr, *v = nullptr, *h = nullptr, *hbar = nullptr, *localV = nullptr, *d_scal = nullptr;
@@ -1943,8 +1797,10 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
       d_cons = (long long *)p;
       if ((r = dz_scratch(ctx, "lsmr.sum", 64, &p))) return r;
       d_sum = (double *)p;
-      if ((r = dz_scratch(ctx, "lsmr.w", n * 4, &p))) return r;
+      if ((r = dz_scratch(ctx, "lsmr.w", w_bytes, &p))) return r;            // this rank's n floats of A_p^T u_p | its double beta_p^2
       wbuf = (float *)p;
+      if ((r = dz_scratch(ctx, "lsmr.gather", w_bytes * (size_t)comm->nranks, &p))) return r;   // ... of every rank
+      gbuf = (char *)p;
     }
     if ((r = dz_scratch(ctx, "lsmr.u", m * 4, &p))) return r;
     u = (float *)p;
@@ -1983,11 +1839,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   // (every pending and future collective on it returns an error on every rank) and detach it
   auto leave = [&](int code) -> int {
     if (comm) {
-      if (comm->nccl) (void)ncclCommAbort(comm->nccl);
-      delete comm;
-      ctx->comm = nullptr;
-      ctx->nranks = 1;
-      ctx->rank = 0;
+      dz_comm_abort(ctx);
       comm = nullptr;
     }
     return code;
@@ -2075,6 +1927,9 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   int ntrace = 0;
   double t_spmv = 0, t_spmvt = 0;
   int n_spmv = 0, n_spmvt = 0;
+  long n_enq = 0;       // iterations enqueued
+  long n_coll = 0;      // collectives issued inside the iteration loop (row-sharded solve)
+  bool rccl_allreduce = false;
   int host_syncs = 0;   // host waits on the device inside the iteration loop (one per examined batch of CHECK iterations)
   // u = b ; beta = ||u|| ; u /= beta ; v = A^T u ; alpha = ||v|| ; v /= alpha   (:355-372)
   hipLaunchKernelGGL(k_copy, dim3(bm), dim3(VB), 0, ctx->stream, m, b.dev, u);
@@ -2111,7 +1966,8 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     const int *g1 = &S->stop, *g2 = &S->stop2;
     // one iteration, enqueued without any host synchronisation; k = its number (the reorthogonalisation window is a function
     // of k alone: localVEnqueue advances once per iteration, :723-731)
-    unsigned reorth_barriers = 0;   // arrivals booked at the grid barrier of k_reorth_coop so far (its counter is zeroed here, once)
+    unsigned reorth_barriers = 0;
+    rccl_allreduce = comm && comm->nccl && ctx->opts.count("comm.allreduce") && ctx->opts["comm.allreduce"] == 1;   // arrivals booked at the grid barrier of k_reorth_coop so far (its counter is zeroed here, once)
     DZ_HIP(hipMemsetAsync(part2 + 2 * NPART, 0, 64, ctx->stream));
     auto enqueue_iteration = [&](int k, hipEvent_t *tev) -> int {
       int r;
@@ -2125,20 +1981,33 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
         slot = localV + (size_t)(ptr - 1) * n;
         lim = k >= localVecs ? localVecs : k + 1;     // localVQueueFull ? localVecs : localPointer (:738-742)
       }
-      if (comm) {   // one grouped all-reduce per iteration (see k_local_norm_scal)
+      if (comm) {   // ONE collective per iteration (see k_local_norm_scal / k_beta_axpby)
         float *d_bp = reinterpret_cast<float *>(d_sum + 4);
+        double *w_sum = reinterpret_cast<double *>(reinterpret_cast<char *>(wbuf) + w_sum_off);
         const int bmn = bm > bn ? bm : bn;
-        hipLaunchKernelGGL(k_local_norm_scal, dim3(bm), dim3(VB), 0, ctx->stream, m, u, part, gm_t, d_sum, d_bp, S);
+        hipLaunchKernelGGL(k_local_norm_scal, dim3(bm), dim3(VB), 0, ctx->stream, m, u, part, gm_t, w_sum, d_bp, S);
         if (tev) DZ_HIP(hipEventRecord(tev[2], ctx->stream));
         DZ_HIP(hipMemsetAsync(wbuf, 0, n * 4, ctx->stream));
         if ((r = launch_spmvT(ctx, A, u, 1.0f, wbuf, nullptr, 1.0f, nullptr, nullptr, g1))) return r;
         hipLaunchKernelGGL(k_scale_by, dim3(bn), dim3(VB), 0, ctx->stream, n, wbuf, d_bp, g1);
         if (tev) DZ_HIP(hipEventRecord(tev[3], ctx->stream));
-        dz_comm_group(comm, true);
-        const int ra = dz_allreduce(ctx, comm, wbuf, (size_t)n, DZ_F32, DZ_SUM), rb = dz_allreduce(ctx, comm, d_sum, 1, DZ_F64, DZ_SUM);
-        dz_comm_group(comm, false);
-        if (ra || rb) return ra ? ra : rb;
-        hipLaunchKernelGGL(k_beta_axpby, dim3(bmn), dim3(VB), 0, ctx->stream, m, u, n, v, wbuf, d_sum, d_bp, slot, part, S);
+        if (rccl_allreduce) {   // option comm.allreduce: RCCL's own sums (its order), the two buffers in one group
+          DZ_NCCL(ncclGroupStart());
+          const ncclResult_t ra = ncclAllReduce(wbuf, wbuf, (size_t)n, ncclFloat, ncclSum, comm->nccl, ctx->stream);
+          const ncclResult_t rb = ncclAllReduce(w_sum, w_sum, 1, ncclDouble, ncclSum, comm->nccl, ctx->stream);
+          const ncclResult_t rg = ncclGroupEnd();   // (inside a group the calls above only enqueue: launch errors surface here)
+          if (ra != ncclSuccess || rb != ncclSuccess || rg != ncclSuccess) {
+            const ncclResult_t bad = ra != ncclSuccess ? ra : (rb != ncclSuccess ? rb : rg);
+            return dz_fail(ctx, -2000 - (int)bad, "row-sharded LSMR: grouped ncclAllReduce -> %s", ncclGetErrorString(bad));
+          }
+          hipLaunchKernelGGL(k_beta_axpby, dim3(bmn), dim3(VB), 0, ctx->stream, m, u, n, v, (const char *)wbuf, 1, w_bytes, w_sum_off, d_bp,
+                             slot, part, S);
+        } else {
+          if ((r = dz_allgather(ctx, comm, wbuf, gbuf, w_bytes))) return r;
+          hipLaunchKernelGGL(k_beta_axpby, dim3(bmn), dim3(VB), 0, ctx->stream, m, u, n, v, (const char *)gbuf, comm->nranks, w_bytes,
+                             w_sum_off, d_bp, slot, part, S);
+        }
+        n_coll++;
         gn_t = bmn;
       } else {
         hipLaunchKernelGGL(k_beta_scal_u, dim3(bm > bn ? bm : bn), dim3(VB), 0, ctx->stream, m, u, part, gm_t,
@@ -2192,6 +2061,7 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
         const int sl = nbatch % NSLOT;
         for (int i = 0; i < CHECK && launched < limit; i++) {
           launched++;
+          n_enq++;
           if ((rc = enqueue_iteration(launched, i == 0 ? guard.ta[sl] : nullptr))) return rc;
         }
         DZ_HIP(hipMemcpyAsync(&h_state[sl], S, sizeof(LsmrState), hipMemcpyDeviceToHost, ctx->stream));
@@ -2233,7 +2103,9 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
   ctx->ksec["spmvt"] = n_spmvt ? t_spmvt / n_spmvt : -1.0;
   ctx->ksec["lsmr.normb"] = normb;
   ctx->ksec["lsmr.host_syncs"] = host_syncs;
-  ctx->ksec["lsmr.collectives_per_iteration"] = comm ? 1.0 : 0.0;   // (a grouped all-reduce: the n floats of A^T u and the double ||u_p||^2)
+  // counted, not assumed: collectives issued by the loop / iterations enqueued (the n floats of A_p^T u_p with the double ||u_p||^2)
+  ctx->ksec["lsmr.collectives_per_iteration"] = comm && n_enq > 0 ? (double)n_coll / (double)n_enq : 0.0;
+  ctx->ksec["lsmr.collective_kind"] = comm ? (rccl_allreduce ? 2.0 : 1.0) : 0.0;   // 1 all-gather + rank-ordered sums, 2 ncclAllReduce
   {
     int nr = 1;
     if (comm && comm->nccl) (void)ncclCommCount(comm->nccl, &nr);

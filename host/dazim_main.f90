@@ -248,7 +248,11 @@ program DAzimSurfTomo_amd
       fidx = fidx + 1
     end do
   end do
-  if (dloc < 1) stop 'this rank has no data: more ranks than (period, source) fields'
+  ! (a decision every rank takes together: one that stopped on its own would leave the others waiting in their next collective)
+  if (dazim_allmax_int(merge(1, 0, dloc < 1)) > 0) then
+    call dazim_finalize()
+    stop 'a rank has no data: more ranks than (period, source) fields'
+  end if
   allocate (dsyn_l(dloc))
   if (dazim_nranks > 1) write (*, '(a,i3,a,i3,a,i8,a,i8,a,i8)') '  rank ', dazim_rank, ' of ', dazim_nranks, ': fields ', f0 + 1, ' ..', f1, &
     ', data rows ', dloc
@@ -338,7 +342,12 @@ program DAzimSurfTomo_amd
       end if
     end if
     nar = nar1 + nreg
-    if (int(nar, 8) > maxnar) stop 'increase sparsity fraction(spfra)'                   ! inv/Main_Jt.f90:523
+    ! inv/Main_Jt.f90:523 tests the whole system's entries: the ranks' ray rows summed + the regularisation block, the same number
+    ! and hence the same decision on every rank
+    if (dazim_allsum_int8(int(nar1, 8)) + nreg > maxnar) then
+      call dazim_finalize()
+      stop 'increase sparsity fraction(spfra)'
+    end if
     nregblk = merge(1, 3, iso_mod)
     call dazim_shard_rows(nregblk*maxvp, dazim_nranks, dazim_rank, treg0, treg1)   ! (all of them with one rank)
     if (iso_mod) then
@@ -510,7 +519,11 @@ program DAzimSurfTomo_amd
   write (66, *) '  Output inverted shear velocity model: Vs_model_Syn.rela  Vs_model_Syn.abs'
   call tick(9)
   call get_environment_variable('DAZIM_TIMING', timing_env)
-  if (len_trim(timing_env) > 0) write (0, '(a,9f8.3)') ' phase seconds: read init assemble weights tikhonov lsmr update diag output ', tph
+  if (len_trim(timing_env) > 0) then
+    write (0, '(a,9f8.3)') ' phase seconds: read init assemble weights tikhonov lsmr update diag output ', tph
+    ! (with several ranks the first three are this rank's block of the model, the last two its share of the fields)
+    write (0, '(a,i3,a,5f8.3)') ' rank ', dazim_rank, ' device seconds: curves copies ti eikonal rays ', dazim_dev_seconds
+  end if
   call system_clock(c1)
   write (*, '(a, f13.1, a)') '   All time cost= ', real(c1 - c0)/real(crate), "s"
   write (66, '(a, f13.1, a)') '   All time cost= ', real(c1 - c0)/real(crate), "s"

@@ -27,10 +27,14 @@ module dazim_mod
             dazim_csr_free, dazim_aprod, dazim_lsmr, dazim_csr_to_coo, dazim_lsmr_log, dazim_lsmr_traced, dazim_lsmr_rec, &
             dazim_csr_append_tikhonov, dazim_weight_data, dazim_model_update, dazim_csr_threshold, dazim_csr_dims, dazim_csr_take_twin, dazim_ray_paths_dims, dazim_ray_paths_copy
   ! several GPUs: one process per GPU (DAZIM_NGPU / DAZIM_RANK), rows of [G; L] sharded over them, see dazim_ranks_init
-  public :: dazim_comm_unique_id, dazim_comm_init, dazim_comm_init_files, dazim_comm_free, dazim_comm_allreduce, &
+  public :: dazim_comm_unique_id, dazim_comm_init, dazim_comm_init_files, dazim_comm_free, dazim_comm_allreduce, dazim_comm_allgather, &
+            dazim_dispersion_kernels_sharded, dazim_ti_kernels_sharded, dazim_allmax_int, dazim_allsum_int8, &
             dazim_csr_append_tikhonov_rows, dazim_weight_data_sharded, dazim_ranks_init, dazim_nranks, dazim_rank, &
             dazim_shard_fields, dazim_shard_rows, dazim_allsum
   integer, save :: dazim_nranks = 1, dazim_rank = 0
+  ! device seconds of dazim_assemble_G's calls, summed over its calls (HIP events of the library): the column curves of this rank's
+  ! block of the model, its perturbed copies (auxiliary stream), the TI kernels, the eikonal launch, the ray kernels
+  real(8), save, public :: dazim_dev_seconds(5) = 0
 
   type(c_ptr), save :: dazim_handle = c_null_ptr
   ! the matrix of the last aprod call (see aprod) and how often it had to be (re)built
@@ -79,6 +83,36 @@ module dazim_mod
       real(c_float) :: vel(*), depz(*)
       real(c_double) :: periods(*), pv(*)
       integer(c_int) :: nfail
+    end function
+    ! the same two calls with the model's rows sharded over the ranks of the attached communicator (include/dazim.h); without one
+    ! they ARE the plain calls
+    integer(c_int) function dazim_dispersion_kernels_sharded(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, &
+        pv, svs, svp, srho, nfail) bind(C, name="dazim_dispersion_kernels_sharded")
+      import
+      type(c_ptr), value :: ctx, svs, svp, srho
+      integer(c_int), value :: nx, ny, nz, kmax
+      real(c_float), value :: sublayers
+      real(c_float) :: vel(*), depz(*)
+      real(c_double) :: periods(*), pv(*)
+      integer(c_int) :: nfail
+    end function
+    integer(c_int) function dazim_ti_kernels_sharded(ctx, nx, ny, nz, vel, depz, sublayers, kmax, periods, pv, lsen) &
+        bind(C, name="dazim_ti_kernels_sharded")
+      import
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nx, ny, nz, kmax
+      real(c_float), value :: sublayers
+      real(c_float) :: vel(*), depz(*), lsen(*)
+      real(c_double) :: periods(*), pv(*)
+    end function
+    integer(c_int) function dazim_comm_allgather(ctx, send, recv, count, dtype) bind(C, name="dazim_comm_allgather")
+      import
+      type(c_ptr), value :: ctx, send, recv
+      integer(c_int64_t), value :: count
+      integer(c_int), value :: dtype
+    end function
+    real(c_double) function dazim_last_kernel_seconds(ctx, name) bind(C, name="dazim_last_kernel_seconds")
+      import; type(c_ptr), value :: ctx; character(kind=c_char) :: name(*)
     end function
     integer(c_int) function dazim_surfdisp96(ctx, nmodel, nlayer_max, nlayer, thk, vp, vs, rho, iflsph, iwave, mode, igr, &
         kmax, periods, cg, nfail) bind(C, name="dazim_surfdisp96")
@@ -362,6 +396,12 @@ contains
       close (u)
     end if
     call check(dazim_comm_init(dazim_handle, int(dazim_nranks, c_int), int(dazim_rank, c_int), id), 'communicator (RCCL)')
+    if (dazim_rank == 0) then     ! every rank has joined (the call above is collective): a later run in this directory must not find this id
+      open (newunit=u, file=trim(dir)//'/rccl_id.ready', status='old', iostat=ios)
+      if (ios == 0) close (u, status='delete')
+      open (newunit=u, file=trim(dir)//'/rccl_id', status='old', iostat=ios)
+      if (ios == 0) close (u, status='delete')
+    end if
   end subroutine
 
   subroutine sleep_ms(ms)
@@ -420,6 +460,25 @@ contains
     if (dazim_nranks <= 1 .or. n < 1) return
     call check(dazim_comm_allreduce(dazim_handle, c_loc(x), int(n, c_int64_t), 0_c_int, 0_c_int), 'all-reduce')
   end subroutine
+
+  ! max over the ranks of an integer (a flag every rank must agree on before any of them stops: a rank that STOPs on its own
+  ! leaves the others waiting in the next collective for ever)
+  integer function dazim_allmax_int(v)
+    integer, intent(in) :: v
+    integer(c_int64_t), target :: w(1)
+    w(1) = v
+    if (dazim_nranks > 1) call check(dazim_comm_allreduce(dazim_handle, c_loc(w), 1_c_int64_t, 2_c_int, 1_c_int), 'all-reduce (max)')
+    dazim_allmax_int = int(w(1))
+  end function
+
+  ! sum over the ranks of an integer count (64 bits: the stored entries of a sharded matrix)
+  integer(8) function dazim_allsum_int8(v)
+    integer(8), intent(in) :: v
+    integer(c_int64_t), target :: w(1)
+    w(1) = v
+    if (dazim_nranks > 1) call check(dazim_comm_allreduce(dazim_handle, c_loc(w), 1_c_int64_t, 2_c_int, 0_c_int), 'all-reduce (sum)')
+    dazim_allsum_int8 = w(1)
+  end function
 
   subroutine dazim_finalize()
     integer :: q
@@ -502,9 +561,11 @@ contains
     integer(c_int) :: nfail
     call dazim_init(0)
     allocate (pv(nx*ny, kmaxRc))
-    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
-                                        c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
-    call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, Lsen_Gsc), 'depthkernelTI/tregn96')
+    ! (with several ranks each computes its block of the model's rows -- the reference's OMP loop over the columns,
+    ! inv/depthkernelTI.f90:44 -- and all-gathers join the tables; one rank: the plain calls)
+    call check(dazim_dispersion_kernels_sharded(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, c_null_ptr, c_null_ptr, &
+                                                c_null_ptr, nfail), 'depthkernelTI/surfdisp96')
+    call check(dazim_ti_kernels_sharded(dazim_handle, nx, ny, nz, vel, depz, minthk, kmaxRc, tRc, pv, Lsen_Gsc), 'depthkernelTI/tregn96')
     if (present(pvRc)) pvRc = pv
   end subroutine
 
@@ -645,6 +706,7 @@ contains
     integer(c_int) :: nfail, nb
     integer(c_int64_t) :: nnz64
     integer(c_size_t) :: nn
+    real(8) :: t_curves, t_ti
     call dazim_init(0)
     nkb = int(nx, c_size_t)*ny*kmaxRc*nz*8
     call field_buffer(6, int(nx, c_size_t)*ny*nz*4, p_vel)
@@ -657,13 +719,18 @@ contains
     call c_f_pointer(p_srho, dsrho, [nx*ny*kmaxRc*nz])
     call check(dazim_memcpy_h2d(dazim_handle, p_vel, c_loc(vels), int(nx, c_size_t)*ny*nz*4), 'CalSurfG/model')
     call check(dazim_set_option(dazim_handle, 'disp.async'//c_null_char, 1_c_int), 'option')
-    call check(dazim_dispersion_kernels(dazim_handle, nx, ny, nz, dvel, depz, minthk, kmaxRc, tRc, pv, p_svs, p_svp, &
-                                        p_srho, nfail), 'CalSurfG/depthkernel')
+    ! several ranks: this rank's block of the model's rows (the reference's OMP loop over jj, inv/CalSurfG.f90:39-43), tables
+    ! joined by all-gathers inside the library -- pvRc before the call returns, the depth kernels behind the perturbed copies
+    call check(dazim_dispersion_kernels_sharded(dazim_handle, nx, ny, nz, dvel, depz, minthk, kmaxRc, tRc, pv, p_svs, p_svp, &
+                                                p_srho, nfail), 'CalSurfG/depthkernel')
     call check(dazim_set_option(dazim_handle, 'disp.async'//c_null_char, 0_c_int), 'option')   ! (the handle is shared: only this call)
     if (nfail > 0) write (6, *) 'WARNING:improper initial value in disper - no zero found', nfail   ! inv/surfdisp96.f:311
+    t_curves = max(dazim_last_kernel_seconds(dazim_handle, 'disp'//c_null_char), 0.0_c_double)
+    t_ti = 0
     if (joint .and. present(ti_here)) then
-      if (ti_here) call check(dazim_ti_kernels(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
+      if (ti_here) call check(dazim_ti_kernels_sharded(dazim_handle, nx, ny, nz, vels, depz, minthk, kmaxRc, tRc, pv, lsen), &
                               'depthkernelTI/tregn96')
+      if (ti_here) t_ti = max(dazim_last_kernel_seconds(dazim_handle, 'ti'//c_null_char), 0.0_c_double)
     end if
     ! flatten the (period, source, receiver) loops in the reference's order (:1114-1326)
     nfield = sum(nsrcsurf1(1:kmax)); nray = 0
@@ -703,6 +770,11 @@ contains
     end if
     nar = int(nnz64)
     if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
+    dazim_dev_seconds(1) = dazim_dev_seconds(1) + t_curves
+    dazim_dev_seconds(2) = dazim_dev_seconds(2) + max(dazim_last_kernel_seconds(dazim_handle, 'disp.copies'//c_null_char), 0.0_c_double)
+    dazim_dev_seconds(3) = dazim_dev_seconds(3) + t_ti
+    dazim_dev_seconds(4) = dazim_dev_seconds(4) + max(dazim_last_kernel_seconds(dazim_handle, 'fmm'//c_null_char), 0.0_c_double)
+    dazim_dev_seconds(5) = dazim_dev_seconds(5) + max(dazim_last_kernel_seconds(dazim_handle, 'rays'//c_null_char), 0.0_c_double)
   end subroutine
 
   ! device buffer q of at least `bytes` bytes, reused from the previous call when it is large enough

@@ -255,15 +255,22 @@ int dazim_aprod(dazim_ctx *ctx, int mode, const dazim_csr *A, float *x, float *y
  * dazim_comm_unique_id: rank 0 makes the 128-byte RCCL id and hands it to the other ranks (any transport: MPI,
  * torch.distributed, a file); dazim_comm_init: every rank joins with the same id (ncclCommInitRank on the ctx's device).
  * While a communicator is attached, dazim_lsmr treats A and b as THIS rank's row shard of one global system: per iteration
- * ONE grouped ncclAllReduce(sum) on the ctx stream -- the n fp32 of A_p^T u_p and the double ||u_p||^2 (each rank scales its
- * shard of u by its own norm first; beta follows the collective) --; x, v, h, hbar and the reorthogonalisation window are
- * replicated, so every rank returns the same x.  dazim_comm_free detaches.                                          */
+ * ONE collective on the ctx stream -- an all-gather of the n fp32 of A_p^T u_p with the double ||u_p||^2 (each rank scales its
+ * shard of u by its own norm first; the sums over the ranks are formed in rank order, beta follows) --; x, v, h, hbar and the
+ * reorthogonalisation window are replicated, so every rank returns the same x.  dazim_comm_free detaches.             */
 int dazim_comm_unique_id(void *id128);
 int dazim_comm_init(dazim_ctx *ctx, int nranks, int rank, const void *id128);
 int dazim_comm_free(dazim_ctx *ctx);
 /* The same communicator over FILES in a directory every rank sees (each collective staged through the host): for tests -- the
  * whole multi-rank path with two or three processes on ONE GPU, which RCCL refuses -- not for production.                      */
 int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir);
+/* recv[r*count .. (r+1)*count) = rank r's `count` values at send, on every rank; send, recv: host or device pointers (each on its
+ * own); dtype as for dazim_comm_allreduce.  No communicator attached: recv = send.  Both transports move bytes only (RCCL:
+ * ncclAllGather on the ctx stream); every SUM over the ranks in this library -- dazim_comm_allreduce, the row-sharded LSMR -- is an
+ * all-gather followed by one kernel that adds the ranks' values in RANK ORDER, so that RCCL and the file transport, and every rank,
+ * return the same bits (SURVEY 8e "fix reduction order"; the reference's sums are sequential, inv/aprod.f90:40-55).  Option
+ * "comm.allreduce" = 1: ncclAllReduce instead (RCCL's own order). */
+int dazim_comm_allgather(dazim_ctx *ctx, const void *send, void *recv, int64_t count, int dtype);
 /* sum (op 0) / max (op 1) over the ranks of `count` values in place; buf: host or device pointer; dtype 0 fp32, 1 fp64, 2 int64.
  * No communicator attached: nothing happens.  What a sharded host program reduces its statistics and outputs with
  * (host/dazim_main.f90, DAZIM_NGPU; the reference has no counterpart: inv/Main_Jt.f90 is one process).                         */
@@ -276,6 +283,21 @@ int dazim_csr_append_tikhonov_rows(dazim_ctx *ctx, dazim_csr *A, int nx, int ny,
                                    int64_t row_lo, int64_t row_hi);
 int dazim_weight_data_sharded(dazim_ctx *ctx, dazim_csr *G, int64_t dall, int64_t row0, int64_t dall_glob, const float *obst,
                               const float *dsyn, float *res, float *wgt, float *rhs, float *stats);
+
+/* The model's tables with the model's rows sharded over the ranks: the reference's one parallel loop (OpenMP over the columns jj,
+ * inv/CalSurfG.f90:39-43 called at :1078; depthkernelTI inv/depthkernelTI.f90:2-112).  Same arguments and results as
+ * dazim_dispersion_kernels / dazim_ti_kernels.  With a communicator attached, this rank computes the model rows [lo, hi) of the even
+ * contiguous split of ny (columns are numbered jj*nx+ii: a block of rows is a block of columns) with the same kernels, and
+ * all-gathers join the blocks: every rank returns the complete tables, bit-identical to the single-rank call.  pvRc is joined
+ * before the call returns; with option "disp.async" and device-resident sen_* the perturbed copies of this rank's block run on the
+ * auxiliary stream as in the single-rank call and the gather of the three depth-kernel tables follows them when that stream is
+ * joined (dazim_rays_build_G*, dazim_sync, a copy that touches the tables).  Every rank must make the same calls in the same order.
+ * Without a communicator: the plain calls.                                                                                     */
+int dazim_dispersion_kernels_sharded(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel, const float *depz, float sublayers,
+                                     int kmax, const double *periods, double *pvRc, double *sen_vs, double *sen_vp,
+                                     double *sen_rho, int *n_failed);
+int dazim_ti_kernels_sharded(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel, const float *depz, float sublayers,
+                             int kmax, const double *periods, const double *pvRc, float *Lsen_Gsc);
 
 /* = LSMR (inv/lsmrModule.f90:36), fp32 like the reference; b[m] in, x[n] out.                     */
 int dazim_lsmr(dazim_ctx *ctx, const dazim_csr *A, const float *b, float damp, float atol,

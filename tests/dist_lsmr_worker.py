@@ -57,7 +57,6 @@ def main(out_path):
     x_nat = torch.zeros(n, dtype=torch.float32, device=dev)
     x_nat, info_nat = ctx.lsmr(G, b_loc, *CFG, x=x_nat)
     nranks = int(ctx.kernel_seconds("lsmr.nranks"))
-    ctx.comm_free()
     torch.cuda.synchronize()
     # every rank must hold the same x, bit for bit (the state is replicated, the all-reduce gives every rank the same sums)
     same = []
@@ -76,6 +75,18 @@ def main(out_path):
     pv, sen, nf = depthkernel_sharded(ctx.depthkernel, d_vel, depz, periods, 2.0, world, rank, always_gather=True)
     torch.cuda.synchronize()
     disp_same = bool(torch.equal(pv, pv1)) and all(bool(torch.equal(a, b_)) for a, b_ in zip(sen, sen1)) and nf == nf1
+    # ... and the product's form of it: the same sharding inside the library over ITS communicator (dazim_dispersion_kernels_sharded,
+    # dazim_ti_kernels_sharded: ncclAllGather), two streams, the depth kernels gathered at the join
+    ctx.set_option("disp.async", 1)
+    pv_l, sen_l, nf_l = ctx.depthkernel(d_vel, depz, periods, 2.0, sharded=True)
+    ctx.sync()
+    ctx.set_option("disp.async", 0)
+    ls1 = ctx.ti_kernels(d_vel, depz, periods, 2.0, pv1)
+    ls_l = ctx.ti_kernels(d_vel, depz, periods, 2.0, pv1, sharded=True)
+    torch.cuda.synchronize()
+    disp_same = disp_same and bool(torch.equal(pv_l, pv1)) and all(bool(torch.equal(a, b_)) for a, b_ in zip(sen_l, sen1)) and nf_l == nf1 \
+        and bool(torch.equal(ls_l, ls1))
+    ctx.comm_free()
     flags = [None] * world
     dist.all_gather_object(flags, disp_same)
     infos = [None] * world

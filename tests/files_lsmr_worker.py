@@ -32,7 +32,7 @@ def main(rank, world, comm_dir, out_path):
     ctx.comm_allreduce(hmax, "max")
     x, info = ctx.lsmr(G, b_loc, *CFG, x=torch.zeros(n, dtype=torch.float32, device="cuda:0"))
     out = {"x": x.cpu().numpy().tolist(), "info": info, "nranks": int(ctx.kernel_seconds("lsmr.nranks")),
-           "transport": int(ctx.kernel_seconds("lsmr.transport")), "collectives_per_iteration": int(ctx.kernel_seconds("lsmr.collectives_per_iteration")),
+           "transport": int(ctx.kernel_seconds("lsmr.transport")), "collectives_per_iteration": ctx.kernel_seconds("lsmr.collectives_per_iteration"),
            "sum": h.tolist(), "max": hmax.tolist()}
     ctx.comm_free()
     G.free()

@@ -336,7 +336,7 @@ def strip_rank_lines(text):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/flang") and not os.path.exists(INV_EXE), reason="no flang and no prebuilt host")
-@pytest.mark.parametrize("tag,world", [("iso", 2), ("joint", 2), ("joint", 3)])
+@pytest.mark.parametrize("tag,world", [("iso", 2), ("joint", 2), ("joint", 3), ("joint", 4)])
 def test_inversion_program_sharded_over_ranks_on_one_gpu(tmp_path, tag, world):
     """The Fortran host with its (period, source) fields sharded over `world` processes (DAZIM_NGPU; host/dazim_main.f90,
     dazim_ranks_init): rows of [G; L] row-sharded, the library's LSMR with one collective per iteration, statistics and per-datum
