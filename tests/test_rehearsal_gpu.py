@@ -74,7 +74,7 @@ def test_bench_strong_scaling_n_ranks_against_one_rank(tmp_path, workload, world
     d1, r1 = run_bench(tmp_path, "one", 1, args, 0)
     dn, rn = run_bench(tmp_path, "many", world, args, 29640 + world)
     assert dn["n_gpus"] == world and dn["lsmr"]["rccl_nranks"] == world and dn["lsmr"]["collectives_per_iteration"] == 1
-    assert dn["lsmr"]["collective"].startswith("all-gather") and dn["dispersion"].startswith("model rows sharded inside the library")
+    assert dn["lsmr"]["collective"].startswith("all-gather") and dn["dispersion"].startswith("model rows sharded over the ranks inside the library")
     assert dn["lsmr_iterations"] == d1["lsmr_iterations"] == 20
     one = r1[0]
     nray = int(one["nray_all"])
