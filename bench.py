@@ -511,7 +511,7 @@ def main():
     d_pv = torch.empty((kmax, ncol), dtype=torch.float64, device=dev)
     d_sen = [torch.empty((nz, kmax, ncol), dtype=torch.float64, device=dev) for _ in range(3)]
     d_veln = torch.empty((kmax, g.nnx, g.nnz), dtype=torch.float32, device=dev)
-    d_ttn = torch.empty((nfield, g.nnx, g.nnz), dtype=torch.float32, device=dev)
+    d_ttn = torch.empty((nfield, g.nnx, g.nnz), dtype=torch.float32, device=dev) if os.environ.get("DAZIM_BENCH_TTN") == "1" else None
     d_ttnr = torch.empty((nfield, 129, 129), dtype=torch.float32, device=dev)
     d_nstsr = torch.empty((nfield, 129, 129), dtype=torch.int32, device=dev)
     d_box = torch.empty((nfield, 12), dtype=torch.int32, device=dev)
@@ -559,8 +559,10 @@ def main():
         pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen, sharded=shard_disp)
         stats["disp_s"] = ctx.kernel_seconds("disp")            # (disp.async: the column curves; the copies overlap what follows)
         lap("depthkernel")
+        # (the coarse fields stay inside the library, in the eikonal kernel's tiles, for the ray kernel: CalSurfG returns none,
+        # inv/CalSurfG.f90:909-912; DAZIM_BENCH_TTN=1: the column-major ttn array of the ABI, as in rounds 1-5)
         fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
-                               ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st)
+                               ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st, keep_fields=d_ttn is None)
         lap("fmm_batch")
         stats["fmm_s"] = ctx.kernel_seconds("fmm")
         stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")

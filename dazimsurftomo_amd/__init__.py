@@ -225,10 +225,12 @@ class Context:
     # ---- K2+K3 -----------------------------------------------------------------------------
     def fmm_batch(self, nx, ny, goxd, gozd, dvxd, dvzd, pv, scx, scz, period_idx,
                   veln=None, ttn=None, ttnr=None, nstsr=None, boxes=None, status=None,
-                  want_refined=True):
+                  want_refined=True, keep_fields=False):
         """gridder + bsplrefine + travel x2 for a batch of (source, period) fields
         (body of the source loop inv/CalSurfG.f90:1146-1314).  Returns a dict of outputs; numpy
-        in -> numpy out, torch-cuda in -> the given output tensors are filled in place."""
+        in -> numpy out, torch-cuda in -> the given output tensors are filled in place.
+        keep_fields: ttn = NULL -- the coarse fields stay inside the library (in the eikonal kernel's tiles) for the
+        rays_build_G call that follows, as in the reference's CalSurfG, which never returns them (out["ttn"] is None)."""
         g = geometry(nx, ny, goxd, gozd, dvxd, dvzd)
         kmax = pv.shape[0]
         nfield = int(scx.shape[0])
@@ -237,7 +239,7 @@ class Context:
             scx = np.ascontiguousarray(scx, np.float32)
             scz = np.ascontiguousarray(scz, np.float32)
             period_idx = np.ascontiguousarray(period_idx, np.int32)
-            if ttn is None:
+            if ttn is None and not keep_fields:
                 ttn = np.zeros((nfield, g.nnx, g.nnz), np.float32)
             if veln is None:
                 veln = np.zeros((kmax, g.nnx, g.nnz), np.float32)
@@ -248,6 +250,8 @@ class Context:
                 boxes = (RefBox * max(nfield, 1))()
             if status is None:
                 status = np.zeros(nfield, np.int32)
+        if keep_fields:
+            ttn = None
         bptr = None
         if boxes is not None:
             bptr = C.c_void_p(boxes.data_ptr()) if _is_torch(boxes) else C.cast(boxes, C.c_void_p)

@@ -36,7 +36,8 @@ size_t dz_trim_caches(dazim_ctx *ctx) {
   // ... and the multi-GB per-field state of a time-sliced eikonal batch (S-512: 34 GB), which is kept between calls because
   // giving it back and asking for it again costs 0.7 s per step -- unless an eikonal call is the one that ran out of memory
   if (!ctx->fmm_busy)
-    for (const char *nm : {"fmm.rec_c", "fmm.ts_keys", "fmm.ts_nodes", "fmm.ovf"}) {
+    for (const char *nm : {"fmm.rec_c", "fmm.ts_keys", "fmm.ts_nodes", "fmm.ovf", "fmm.ttn_tiled"}) {
+      if (ctx->fields.tiled && (std::string(nm) == "fmm.rec_c" || std::string(nm) == "fmm.ttn_tiled")) continue;   // (fields waiting for the ray kernel)
       auto it = ctx->scratch.find(nm);
       if (it != ctx->scratch.end() && it->second.first && it->second.second >= ((size_t)1 << 30)) {
         freed += it->second.second;
@@ -72,6 +73,25 @@ int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
     // ... but rounded up to the next 256 MB, so that a batch that grows by one field does not free and allocate gigabytes each time
     size_t want = bytes >= ((size_t)1 << 30) ? ((bytes + ((size_t)1 << 28) - 1) >> 28) << 28 : bytes + bytes / 8;
     DZ_HIP(dz_malloc_retry(ctx, &s.first, want));
+    s.second = want;
+  }
+  *out = s.first;
+  return 0;
+}
+
+int dz_pinned(dazim_ctx *ctx, const char *name, size_t bytes, void **out) {
+  auto &s = ctx->pinned[name];
+  if (s.second < bytes) {
+    const bool pin = !(ctx->opts.count("ctx.pinned") && !ctx->opts["ctx.pinned"]);
+    if (s.first) {
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      if (hipHostFree(s.first) != hipSuccess) { (void)hipGetLastError(); free(s.first); }
+    }
+    s.first = nullptr;
+    s.second = 0;
+    const size_t want = bytes + bytes / 4 + 64;
+    if (pin) DZ_HIP(hipHostMalloc(&s.first, want));
+    else if (!(s.first = malloc(want))) return dz_fail(ctx, -3, "out of host memory");
     s.second = want;
   }
   *out = s.first;
@@ -282,6 +302,8 @@ void dazim_destroy(dazim_ctx *ctx) {
   ctx->big.clear();
   for (auto &kv : ctx->scratch)
     if (kv.second.first) (void)hipFree(kv.second.first);
+  for (auto &kv : ctx->pinned)
+    if (kv.second.first && hipHostFree(kv.second.first) != hipSuccess) { (void)hipGetLastError(); free(kv.second.first); }
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream2) {

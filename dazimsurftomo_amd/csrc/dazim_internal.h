@@ -22,6 +22,10 @@ struct dazim_ctx {
   std::map<std::string, int> opts;     // dazim_set_option
   // reusable device scratch, grown on demand (never shrunk) so that repeated calls do not hipMalloc
   std::map<std::string, std::pair<void *, size_t>> scratch;
+  // pinned host buffers by name (dz_pinned): where the step's small device-to-host reads land -- a copy into pageable memory is
+  // staged by a blit KERNEL, which waits for a free wavefront slot behind persistent workgroups (the dispersion copies held the
+  // chip for 20 ms while a 4-byte read waited, profiles/r5); into pinned memory it is a DMA transfer
+  std::map<std::string, std::pair<void *, size_t>> pinned;
   bool fmm_busy = false;   // an eikonal call is using its scratch blocks (dz_trim_caches must not free them)
   // RCCL communicator of a row-sharded solve (dazim_comm_init); nullptr = single GPU, RCCL never touched
   // staging blocks for host-pointer arguments (DzBuf): released blocks are kept and handed out again, because a
@@ -49,6 +53,14 @@ struct dazim_ctx {
     const double *send = nullptr;                     // this rank's blocks of sen_vs | sen_vp | sen_rho
     double *svs = nullptr, *svp = nullptr, *srho = nullptr;   // the complete tables (device)
   } shard;
+  // eikonal fields a dazim_fmm_batch call with ttn == NULL left inside the library for dazim_rays_build_G* with ttn == NULL: the
+  // finished node words of every field in the eikonal kernel's own 4 x 4 tiles (scratch "fmm.rec_c" / "fmm.ttn_tiled", which
+  // dz_trim_caches leaves alone while `tiled` is set); field f at tiled + (tslot ? tslot[f] : f) * stride
+  struct TiledFields {
+    const unsigned *tiled = nullptr;
+    const int *tslot = nullptr;
+    int nfield = 0, nnx = 0, nnz = 0, stride = 0, tsh = 0;
+  } fields;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
@@ -96,8 +108,16 @@ int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes);   // 
                      hipGetErrorString(e_));                                                   \
   } while (0)
 
+// The eikonal kernel's 4 x 4-tile layout of a grid (fmm.hip: tile_shift / tile_x / tile_z, which these restate for the ray kernel):
+// node (x0, z0), 0-based, is word dz_tile_x(x0, tsh) + dz_tile_z(z0), tsh = dz_tile_shift(nnz)
+__host__ __device__ constexpr int dz_tile_shift(int nz) { int l = 0; while ((1 << l) < ((nz + 3) >> 2)) l++; return l + 4; }
+__host__ __device__ __forceinline__ constexpr int dz_tile_x(int x0, int tsh) { return ((x0 >> 2) << tsh) + ((x0 & 3) << 2); }
+__host__ __device__ __forceinline__ constexpr int dz_tile_z(int z0) { return ((z0 & ~3) << 2) | (z0 & 3); }
+
 // named scratch buffer of at least `bytes` bytes
 int dz_scratch(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
+// named PINNED host buffer of at least `bytes` bytes (option ctx.pinned = 0: plain malloc'ed memory, the behaviour before round 6)
+int dz_pinned(dazim_ctx *ctx, const char *name, size_t bytes, void **out);
 
 size_t dz_trim_caches(dazim_ctx *ctx);                                // free all idle cached blocks; bytes released
 hipError_t dz_malloc_retry(dazim_ctx *ctx, void **p, size_t bytes);   // hipMalloc; on out-of-memory trim the caches and retry once

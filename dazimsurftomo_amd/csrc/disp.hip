@@ -1193,8 +1193,11 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
     }
     t.stop();
   }
-  int nfail = 0;
-  unsigned hst[4] = {0, 0, 0, 0};
+  if ((rc = dz_pinned(ctx, "disp.host", 64, &p))) return rc;
+  int &nfail = *(int *)p;                 // (pinned: a DMA transfer, not a blit kernel that queues behind the perturbed copies)
+  unsigned *hst = (unsigned *)p + 4;
+  nfail = 0;
+  hst[0] = hst[1] = hst[2] = hst[3] = 0;
   DZ_HIP(hipMemcpyAsync(&nfail, d_nfail, 4, hipMemcpyDeviceToHost, ctx->stream));
 #ifdef DZ_DISP_STAT
   {

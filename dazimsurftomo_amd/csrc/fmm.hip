@@ -62,7 +62,9 @@ struct FmmArgs {
   const int *period;
   const float *risti_c;  // [nnx]       EARTH*sin(gox+(ix-1)*dnx)
   const float *risti_r;  // [nnx][RM]   same on the refined lattice for every possible vnl
-  float *ttn, *ttnr;
+  float *ttn, *ttnr;   // ttn nullable: the coarse fields stay in the kernel's own 4 x 4-tile layout (ttn_tiled) for the ray kernel
+  unsigned *ttn_tiled; // [nfield][tiled nnx x nnz] finished fields (time bits of every node), field f at index tslot[f] (or f)
+  const int *tslot;    // nullable.  Time-sliced batches: ttn_tiled IS rec_c and tslot the field's place in the queue -- nothing is copied
   int *nstsr;
   dazim_refbox *boxes;
   int *status;
@@ -114,6 +116,9 @@ __host__ __device__ __forceinline__ constexpr int tile_x(int x0, int tsh) { retu
 __host__ __device__ __forceinline__ constexpr int tile_z(int z0) { return ((z0 & ~3) << 2) | (z0 & 3); }
 __device__ __forceinline__ int rid_x0(int rid, int tsh) { return ((rid >> tsh) << 2) | ((rid >> 2) & 3); }
 __device__ __forceinline__ int rid_z0(int rid, int tsh) { return (((rid & ((1 << tsh) - 1)) >> 4) << 2) | (rid & 3); }
+static_assert(tile_shift(256) == dz_tile_shift(256) && tile_shift(511) == dz_tile_shift(511) && tile_shift(71) == dz_tile_shift(71) &&
+              tile_x(37, 10) == dz_tile_x(37, 10) && tile_x(510, 11) == dz_tile_x(510, 11) && tile_z(37) == dz_tile_z(37) &&
+              tile_z(510) == dz_tile_z(510), "dazim_internal.h restates this layout for the ray kernel");
 constexpr int TSH_R = tile_shift(DAZIM_RMAX);                       // refined grid: 33 tiles per column of tiles, stride 64 tiles
 constexpr int NREC_R = tile_records(DAZIM_RMAX, DAZIM_RMAX);        // 33 792 record slots per refined field
 
@@ -1284,6 +1289,29 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   // waits for a task that is running (flag per batch, release / acquire at agent scope: the two may run on different XCDs).
   // Which workgroup runs which stage has no influence on any result: the state handed over is exact.
   // (an integer in a scalar register: a wavefront-uniform bool is still a lane mask to the compiler, and a branch on it costs VALU work)
+  // a finished field leaves the kernel: un-tiled into the reference's column-major ttn, or -- ttn == NULL, the fields stay inside the
+  // library for the ray kernel (inv/CalSurfG.f90:909-912 never returns them) -- as it stands, in tiles (copied only if its node
+  // words are not already at their final place); `zero`: a field whose source lies outside the grid
+  auto store_field = [&](const unsigned *rec, int f, bool zero) {
+    if (A.ttn) {
+      float *ttn = A.ttn + (size_t)f * nn;
+      if (zero) {
+        for (int i = gl; i < nn; i += GP) ttn[i] = 0.0f;
+        return;
+      }
+      for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
+        const int tx = tile_x(cx, tsh_c);
+        for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec[tx + tile_z(cz)]);   // all alive
+      }
+    } else {
+      unsigned *dst = A.ttn_tiled + (size_t)(A.tslot ? A.tslot[f] : f) * nrec_c;
+      if (zero) {
+        for (int i = gl; i < nrec_c; i += GP) dst[i] = 0u;
+      } else if (dst != rec) {
+        for (int i = gl; i < nrec_c; i += GP) dst[i] = rec[i];
+      }
+    }
+  };
   int fastm = __builtin_amdgcn_readfirstlane(*A.vflag) == 0 ? A.fastm : 0;
   asm volatile("" : "+v"(fastm));   // (kept in a vector register: as a scalar it is spilled and comes back through v_readlane in every pop)
   if (A.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over another kernel's wavefronts on the same SIMD (see run_fmm)
@@ -1363,11 +1391,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         if (ovf) {
           if (gl == 0) { A.status[f] = -2; A.ts_nodes[(size_t)q * CAP] = -1; }
         } else if (H.ntr == 0) {
-          float *ttn = A.ttn + (size_t)f * nn;
-          for (int cx = 0; cx < nnx; cx++) {
-            const int tx = tile_x(cx, tsh_c);
-            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);
-          }
+          store_field(rec_c, f, false);
           if (gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
         } else {
           const int ns = H.ntr < CAP ? H.ntr : CAP - 1;
@@ -1383,14 +1407,13 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
       const int f = A.flist ? A.flist[q] : q;   // the four groups run the same phases on their own field (SIMT across groups)
       const float scx = A.scx[f], scz = A.scz[f];
       const int per = A.period[f] - 1;
-      float *ttn = A.ttn + (size_t)f * nn;
       // ---- refined source box, inv/CalSurfG.f90:1169-1206 ----
       int isx = (int)((scx - g.gox) / g.dnx) + 1;
       int isz = (int)((scz - g.goz) / g.dnz) + 1;
       const bool outside = isx < 1 || isx > nnx || isz < 1 || isz > nnz || per < 0 || per >= A.kmax;
       if (gl == 0) A.status[f] = outside ? DAZIM_E_SOURCE_OUTSIDE : 0;
       if (outside) {
-        for (int i = gl; i < nn; i += GP) ttn[i] = 0.0f;
+        store_field(rec_c, f, true);
         if (ts && gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
       } else {
         const double *pv = A.pv + (size_t)per * (g.nvz + 2) * (g.nvx + 2);
@@ -1590,10 +1613,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
           if (ts && gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
         } else if (!ts || H.ntr == 0) {   // (time-sliced: only if the box left no band at all -- the later stages find nothing to do)
-          for (int cx = 0; cx < nnx; cx++) {   // traveltime-grid write, back in the reference's column-major order
-            const int tx = tile_x(cx, tsh_c);
-            for (int cz = gl; cz < nnz; cz += GP) ttn[(size_t)cx * nnz + cz] = __int_as_float((int)rec_c[tx + tile_z(cz)]);   // all alive
-          }
+          store_field(rec_c, f, false);
         }
       }
     }
@@ -1681,6 +1701,15 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const size_t nown = (ts ? (size_t)nfield : (size_t)nslot) + 8;
   if ((rc = dz_scratch(ctx, "fmm.rec_c", nown * rec_field_bytes, &p))) return rc;
   A.rec_c = (unsigned *)p;
+  const bool keep_tiled = A.ttn == nullptr;   // the fields stay inside the library, in tiles (dazim_fmm_batch with ttn == NULL)
+  A.ttn_tiled = nullptr;
+  A.tslot = nullptr;
+  if (keep_tiled && ts) {
+    A.ttn_tiled = A.rec_c;   // every field's node words end where they were marched: nothing is copied (tslot below)
+  } else if (keep_tiled) {
+    if ((rc = dz_scratch(ctx, "fmm.ttn_tiled", (size_t)nfield * rec_field_bytes, &p))) return rc;
+    A.ttn_tiled = (unsigned *)p;
+  }
   A.ts_flag = nullptr; A.ts_keys = nullptr; A.ts_nodes = nullptr;
   if (ts) {
     if ((rc = dz_scratch(ctx, "fmm.ts_flag", ((size_t)nfield / A.fpw + 2) * 4, &p))) return rc;
@@ -1705,8 +1734,17 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   A.flist = nullptr;
   std::vector<int> order(nfield);
   {   // stable counting sort of the fields by period (the list the XCD ranges are cut from)
-    std::vector<int> hper(nfield);
-    DZ_HIP(hipMemcpyAsync(hper.data(), A.period, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    // (the host's reads of the step land in pinned memory -- dz_pinned: DMA transfers instead of blit kernels that queue behind
+    // whatever holds the chip)
+    if ((rc = dz_pinned(ctx, "fmm.host", (size_t)nfield * 12 + 64, &p))) return rc;
+    int *hper = (int *)p;
+    float *hx = (float *)p + nfield, *hz = (float *)p + 2 * (size_t)nfield;
+    const bool sorted = !(ctx->opts.count("fmm.sort") && !ctx->opts["fmm.sort"]);
+    DZ_HIP(hipMemcpyAsync(hper, A.period, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (sorted) {
+      DZ_HIP(hipMemcpyAsync(hx, A.scx, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipMemcpyAsync(hz, A.scz, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     DZ_HIP(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < nfield; i++)
       if (hper[i] < 1 || hper[i] > A.kmax)
@@ -1721,11 +1759,7 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     // lockstep and the sift-down runs as many 4-level steps as the largest of their bands needs (three from 512 entries on,
     // else two); the band of a field grows with the room the front has, i.e. with how central the source is, so fields with
     // similar bands are put together.  (Speed only: which fields share a wavefront has no influence on any field.)
-    if (!(ctx->opts.count("fmm.sort") && !ctx->opts["fmm.sort"])) {
-      std::vector<float> hx(nfield), hz(nfield);
-      DZ_HIP(hipMemcpyAsync(hx.data(), A.scx, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
-      DZ_HIP(hipMemcpyAsync(hz.data(), A.scz, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
-      DZ_HIP(hipStreamSynchronize(ctx->stream));
+    if (sorted) {
       const float cx = A.g.gox + 0.5f * (float)(A.g.nnx - 1) * A.g.dnx, cz = A.g.goz + 0.5f * (float)(A.g.nnz - 1) * A.g.dnz;
       const float wx = 1.0f / ((float)A.g.nnx * A.g.dnx), wz = 1.0f / ((float)A.g.nnz * A.g.dnz);
       auto dist = [&](int i) {   // Chebyshev distance from the centre in units of the grid size: the nearest edge decides the band
@@ -1739,19 +1773,32 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
           b0 = i;
         }
     }
+    void *po;
+    if ((rc = dz_pinned(ctx, "fmm.host_order", (size_t)nfield * 8 + 16, &po))) return rc;
+    memcpy(po, order.data(), (size_t)nfield * 4);
+    if (keep_tiled && ts) {   // field -> its place in the queue = its block of node words
+      int *inv = (int *)po + nfield;
+      for (int i = 0; i < nfield; i++) inv[order[i]] = i;
+      if ((rc = dz_scratch(ctx, "fmm.tslot", (size_t)nfield * 4 + 16, &p))) return rc;
+      DZ_HIP(hipMemcpyAsync(p, inv, (size_t)nfield * 4, hipMemcpyHostToDevice, ctx->stream));
+      A.tslot = (const int *)p;
+    }
     if ((rc = dz_scratch(ctx, "fmm.order", (size_t)nfield * 4 + 16, &p))) return rc;
-    DZ_HIP(hipMemcpyAsync(p, order.data(), (size_t)nfield * 4, hipMemcpyHostToDevice, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(p, po, (size_t)nfield * 4, hipMemcpyHostToDevice, ctx->stream));
     A.flist = (const int *)p;
   }
   const bool force_spill = ctx->opts.count("fmm.force_spill") && ctx->opts["fmm.force_spill"];
+  if ((rc = dz_pinned(ctx, "fmm.host_status", (size_t)nfield * 4 + 64, &p))) return rc;
+  int *hs_pin = (int *)p;
   DzTimer t(ctx, "fmm");
   std::vector<int> redo;
   DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
   if (!force_spill) {
     hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB, GPL>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
-    DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(hs_pin, d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(hs.data(), hs_pin, (size_t)nfield * 4);
     for (int i = 0; i < nfield; i++)
       if (hs[i] == -2) redo.push_back(i);
   } else {
@@ -1772,15 +1819,22 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     A.ovfcap = ovfcap;
     if ((rc = dz_scratch(ctx, "fmm.ovf_spill", (size_t)nwg2 * 4 * ovfcap * sizeof(HEnt), &p))) return rc;
     A.ovf = (HEnt *)p;
+    if (keep_tiled && ts) {   // (the first launch's node words ARE the results: the rerun marches in blocks of its own and copies)
+      if ((rc = dz_scratch(ctx, "fmm.rec_spill", (size_t)(nwg2 * 4 + 8) * rec_field_bytes, &p))) return rc;
+      A.rec_c = (unsigned *)p;
+    }
     hipLaunchKernelGGL((fmm_kernel<CAP, true, NT, false>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
-    DZ_HIP(hipMemcpyAsync(hs.data(), d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipMemcpyAsync(hs_pin, d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(hs.data(), hs_pin, (size_t)nfield * 4);
   }
   t.stop();
   {
-    unsigned long long hp = 0;
-    DZ_HIP(hipMemcpy(&hp, A.counter + 16, 8, hipMemcpyDeviceToHost));
+    unsigned long long &hp = *(unsigned long long *)(hs_pin + nfield + 2 - (nfield & 1));
+    hp = 0;
+    DZ_HIP(hipMemcpyAsync(&hp, A.counter + 16, 8, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
     ctx->ksec["fmm.field_pops"] = (double)hp;   // nodes accepted by this call (all fields, refined + coarse marches, incl. spill reruns)
   }
 #ifdef DZ_TS_WAITSTAT
@@ -1811,6 +1865,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fmm_prof), z, sizeof z));
   }
 #endif
+  ctx->fields.tiled = keep_tiled ? A.ttn_tiled : nullptr;
+  ctx->fields.tslot = keep_tiled ? A.tslot : nullptr;
+  ctx->fields.nfield = nfield;
+  ctx->fields.nnx = A.g.nnx;
+  ctx->fields.nnz = A.g.nnz;
+  ctx->fields.stride = tile_records(A.g.nnx, A.g.nnz);
+  ctx->fields.tsh = tile_shift(A.g.nnz);
   return 0;
 }
 
@@ -1824,7 +1885,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
   if (!ctx) return DAZIM_E_BAD_ARG;
   dazim_geom g;
   if (dazim_geometry(nx, ny, goxd, gozd, dvxd, dvzd, &g)) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad grid %dx%d", nx, ny);
-  if (kmax < 1 || nfield < 0 || !pv_u || !ttn_u || (nfield > 0 && (!scx_u || !scz_u || !period_u)) || g.nnx > 32767 || g.nnz > 32767)
+  if (kmax < 1 || nfield < 0 || !pv_u || (nfield > 0 && (!scx_u || !scz_u || !period_u)) || g.nnx > 32767 || g.nnz > 32767)
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_fmm_batch");
   DZ_HIP(hipSetDevice(ctx->device));
   struct Busy {   // (the multi-GB scratch of a time-sliced batch may be freed by dz_trim_caches when another call runs out of memory)
@@ -1832,6 +1893,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     explicit Busy(dazim_ctx *c_) : c(c_) { c->fmm_busy = true; }
     ~Busy() { c->fmm_busy = false; }
   } busy(ctx);
+  ctx->fields = dazim_ctx::TiledFields();   // (whatever an earlier call left for the ray kernel is gone: the scratch is reused)
   const size_t nn = (size_t)g.nnx * g.nnz, npv = (size_t)(g.nvz + 2) * (g.nvx + 2), nr = (size_t)RM * RM;
   DzBuf<double> pv;
   DzBuf<float> scx, scz, veln, ttn, ttnr;

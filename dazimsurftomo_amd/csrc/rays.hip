@@ -35,7 +35,12 @@ struct RayArgs {
   const int *period;       // [nfield], 1-based (velocity map of the field)
   const int *kidx;         // [nfield], 1-based period slot of the depth kernels (knumi), may equal period
   const float *veln;       // [kmax][nnx][nnz]
-  const float *ttn;        // [nfield][nnx][nnz]
+  const float *ttn;        // [nfield][nnx][nnz]; TILED kernels: the fields as dazim_fmm_batch(ttn = NULL) left them, node (x0, z0) of field f
+                           // at ttn[(tslot ? tslot[f] : f) * fstride + dz_tile_x(x0, tsh) + dz_tile_z(z0)] (4 x 4 tiles: a ray that
+                           // moves in x stays in one 64-byte tile for four nodes instead of touching a new 128-byte line per node)
+  const int *tslot;
+  int tsh;
+  long fstride;
   const float *ttnr;       // [nfield][RM][RM]
   const int *nstsr;        // [nfield][RM][RM]
   const dazim_refbox *boxes;
@@ -234,7 +239,7 @@ __device__ __forceinline__ void cbar() { asm volatile("" ::: "memory"); }  // co
 // 4x4 block currently being updated is cached in registers, LPR cells per lane, and written back when the ray
 // moves to another B-spline cell (every ~10 steps), so every cell still sees its contributions in the
 // reference's order (fdm = r1 + fdm).
-template <bool EMIT, bool AZIM>
+template <bool EMIT, bool AZIM, bool TILED>
 #ifndef DZ_RAYS_MINW
 #define DZ_RAYS_MINW 4
 #endif
@@ -308,7 +313,12 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     const int f = A.field[ray];
     const float scx = A.scx[f], scz = A.scz[f], rcx = A.rcx[ray], rcz = A.rcz[ray];
     const float *veln = A.veln + (size_t)(A.period[f] - 1) * nnx * nnz;
-    const float *ttn = A.ttn + (size_t)f * nnx * nnz;
+    const float *ttn = TILED ? A.ttn + (size_t)(A.tslot ? A.tslot[f] : f) * A.fstride : A.ttn + (size_t)f * nnx * nnz;
+    const int tsh = TILED ? A.tsh : 0;
+    // node (x0, z0), 0-based, of this field's coarse times
+    auto tnode = [&](int x0, int z0) -> float {
+      return TILED ? ttn[dz_tile_x(x0, tsh) + dz_tile_z(z0)] : ttn[(size_t)x0 * nnz + z0];
+    };
     const float *ttnr = A.ttnr + (size_t)f * RM * RM;
     const int *nstsr = A.nstsr + (size_t)f * RM * RM;
     const dazim_refbox bx = A.boxes[f];
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
             for (int l = 1; l <= 2; l++) {
               const float produ = (1.0f - fabsf(divr((float)(l - 1) * dnz - drz, rdnz))) *
                                   (1.0f - fabsf(divr((float)(k - 1) * dnx - drx, rdnx)));
-              trr = trr + ttn[(size_t)(irx - 2 + k) * nnz + (irz - 2 + l)] * produ;
+              trr = trr + tnode(irx - 2 + k, irz - 2 + l) * produ;
             }
         }
         if (gl == 0) A.dsurf[ray] = trr;
@@ -404,8 +414,13 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
       // node-state loads of the current step instead of costing a second dependent round trip per step.
       float tc00, tc01, tc10, tc11, tr00 = 0.0f, tr01 = 0.0f, tr10 = 0.0f, tr11 = 0.0f;
       auto load_corner_times = [&]() {
-        const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
-        tc00 = t[0]; tc01 = t[1]; tc10 = t[nnz]; tc11 = t[nnz + 1];
+        if (TILED) {
+          const int x0 = dz_tile_x(ipx - 1, tsh), x1 = dz_tile_x(ipx, tsh), z0 = dz_tile_z(ipz - 1), z1 = dz_tile_z(ipz);
+          tc00 = ttn[x0 + z0]; tc01 = ttn[x0 + z1]; tc10 = ttn[x1 + z0]; tc11 = ttn[x1 + z1];
+        } else {
+          const float *t = ttn + (size_t)(ipx - 1) * nnz + (ipz - 1);
+          tc00 = t[0]; tc01 = t[1]; tc10 = t[nnz]; tc11 = t[nnz + 1];
+        }
         if (ipxr >= 1 && ipxr < nnxr && ipzr >= 1 && ipzr < nnzr) {   // (outside the refined box igref is 0 and these are not used)
           const float *u = ttnr + (size_t)(ipxr - 1) * RM + (ipzr - 1);
           tr00 = u[0]; tr01 = u[1]; tr10 = u[RM]; tr11 = u[RM + 1];
@@ -805,7 +820,11 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if (nray < 0 || nfield < 1 || nz < 2 || kmax < 1 || (size_t)g.nvx * g.nvz > 65535u) return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_rays_build_G");
   // every array the kernels dereference must be there: dazim_fmm_batch can be called without the refined outputs (ttnr, nstsr,
   // boxes nullable there), but the ray tracer reads them next to the source (inv/CalSurfG.f90:1941-1952)
-  if (!vels_u || !scx_u || !scz_u || !period_u || !veln_u || !ttn_u || !ttnr_u || !nstsr_u || !boxes_u || !svs_u || !svp_u ||
+  // ttn == NULL: the coarse fields are the ones the last dazim_fmm_batch call (made with ttn == NULL) kept inside the library
+  const bool tiled = ttn_u == nullptr;
+  if (tiled && (!ctx->fields.tiled || ctx->fields.nfield != nfield || ctx->fields.nnx != g.nnx || ctx->fields.nnz != g.nnz))
+    return dz_fail(ctx, DAZIM_E_BAD_ARG, "dazim_rays_build_G: ttn is NULL and the last dazim_fmm_batch call did not keep %d fields of this grid inside the library (call it with ttn = NULL)", nfield);
+  if (!vels_u || !scx_u || !scz_u || !period_u || !veln_u || !ttnr_u || !nstsr_u || !boxes_u || !svs_u || !svp_u ||
       !srho_u || !dsurf_u || (nray > 0 && (!field_u || !rcx_u || !rcz_u)))
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "dazim_rays_build_G: NULL array (the refined fields ttnr, nstsr and boxes of dazim_fmm_batch are required)");
   DZ_HIP(hipSetDevice(ctx->device));
@@ -825,7 +844,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   if ((rc = period.init(ctx, period_u, nfield, true, false))) return rc;
   if ((rc = kidx.init(ctx, kidx_u ? kidx_u : period_u, nfield, true, false))) return rc;
   if ((rc = veln.init(ctx, veln_u, nn * kmax, true, false))) return rc;
-  if ((rc = ttn.init(ctx, ttn_u, nn * nfield, true, false))) return rc;
+  if (!tiled && (rc = ttn.init(ctx, ttn_u, nn * nfield, true, false))) return rc;
   if ((rc = ttnr.init(ctx, ttnr_u, nr * nfield, true, false))) return rc;
   if ((rc = nstsr.init(ctx, nstsr_u, nr * nfield, true, false))) return rc;
   if ((rc = boxes.init(ctx, boxes_u, nfield, true, false))) return rc;
@@ -850,6 +869,12 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.nray = nray;
   A.field = field.dev; A.rcx = rcx.dev; A.rcz = rcz.dev; A.scx = scx.dev; A.scz = scz.dev;
   A.period = period.dev; A.kidx = kidx.dev; A.veln = veln.dev; A.ttn = ttn.dev; A.ttnr = ttnr.dev;
+  A.tslot = nullptr; A.tsh = 0; A.fstride = (long)nn;
+  if (tiled) {
+    A.ttn = reinterpret_cast<const float *>(ctx->fields.tiled);   // (the node word of a finished node is its time)
+    A.tslot = ctx->fields.tslot; A.tsh = ctx->fields.tsh; A.fstride = ctx->fields.stride;
+  }
+  ctx->ksec["rays.tiled_fields"] = tiled ? 1.0 : 0.0;
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
   A.lsen = joint ? lsen.dev : nullptr;
   A.skern = nullptr;
@@ -947,15 +972,28 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.val = nullptr;
   A.col = nullptr;
   const size_t lds = (size_t)A.lcap * 2 * RPW_MAX + 16;   // one cell list per ray of the wavefront
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  DZ_HIP(hipFuncSetAttribute((const void *)rays_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // the kernel of each pass: count / emit x iso / joint x column-major / tiled fields
+  auto kern = [&](bool emit) -> const void * {
+    if (emit) {
+      if (joint) return tiled ? (const void *)rays_kernel<true, true, true> : (const void *)rays_kernel<true, true, false>;
+      return tiled ? (const void *)rays_kernel<true, false, true> : (const void *)rays_kernel<true, false, false>;
+    }
+    if (joint) return tiled ? (const void *)rays_kernel<false, true, true> : (const void *)rays_kernel<false, true, false>;
+    return tiled ? (const void *)rays_kernel<false, false, true> : (const void *)rays_kernel<false, false, false>;
+  };
+  auto launch = [&](bool emit, const RayArgs &R, long nwg_) -> int {
+    RayArgs args = R;
+    void *params[] = {&args};
+    DZ_HIP(hipLaunchKernel(kern(emit), dim3((unsigned)nwg_), dim3(64), params, lds, ctx->stream));
+    return 0;
+  };
+  DZ_HIP(hipFuncSetAttribute(kern(false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  DZ_HIP(hipFuncSetAttribute(kern(true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)(160 * 1024 / (lds + 256));
   {   // resident workgroups per CU are limited by LDS or by registers (3 wavefronts per SIMD): persistent workgroups beyond
       // that only queue up behind the resident ones and unbalance the XCD-ordered ray ranges
     int occ = 0;
-    const void *kf = joint ? (const void *)rays_kernel<false, true> : (const void *)rays_kernel<false, false>;
+    const void *kf = kern(false);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kf, 64, lds) == hipSuccess && occ > 0 && occ < per_cu) per_cu = occ;
   }
   if (per_cu > 16) per_cu = 16;
@@ -994,13 +1032,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   int64_t nnz = 0;
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
-  if (nray > 0) {
-    if (joint)
-      hipLaunchKernelGGL((rays_kernel<false, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
-    else
-      hipLaunchKernelGGL((rays_kernel<false, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
-    DZ_HIP(hipGetLastError());
-  }
+  if (nray > 0 && (rc = launch(false, A, nwg))) return rc;
   {  // exclusive scan of the row counts -> rowptr
     size_t tb = 0;
     DZ_HIP(rocprim::exclusive_scan(nullptr, tb, A.count, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
@@ -1014,13 +1046,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   { void *pp; if ((rc = dz_big_get(ctx, (size_t)(cap_nnz > 0 ? cap_nnz : 1) * 4, &pp))) return rc; col = (int *)pp; }
   A.val = val;
   A.col = col;
-  if (nray > 0) {
-    if (joint)
-      hipLaunchKernelGGL((rays_kernel<true, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
-    else
-      hipLaunchKernelGGL((rays_kernel<true, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, A);
-    DZ_HIP(hipGetLastError());
-  }
+  if (nray > 0 && (rc = launch(true, A, nwg))) return rc;
   // ---- the dense twin: a second emit pass over the saved cell lists (no ray is traced again unless its list did not fit) ----
   int64_t *rowptr_d = nullptr;
   float *val_d = nullptr;
@@ -1043,13 +1069,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     D.val = val_d;
     D.col = col_d;
     DZ_HIP(hipMemsetAsync(A.qcount + 8, 0, 32, ctx->stream));   // the emit pass's task counters
-    if (nray > 0) {
-      if (joint)
-        hipLaunchKernelGGL((rays_kernel<true, true>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, D);
-      else
-        hipLaunchKernelGGL((rays_kernel<true, false>), dim3((unsigned)nwg), dim3(64), lds, ctx->stream, D);
-      DZ_HIP(hipGetLastError());
-    }
+    if (nray > 0 && (rc = launch(true, D, nwg))) return rc;
   }
   t.stop();
   // statuses: first failing ray is the reference's STOP

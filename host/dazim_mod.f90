@@ -753,7 +753,7 @@ contains
     nn = int(nnx, c_size_t)*nnz
     ! eikonal fields stay on the device between the two calls
     call field_buffer(1, nn*kmaxRc*4, d_veln)
-    call field_buffer(2, nn*nfield*4, d_ttn)
+    d_ttn = c_null_ptr            ! the coarse fields stay inside the library for the ray kernel (CalSurfG returns none, inv/CalSurfG.f90:909-912)
     call field_buffer(3, int(129*129, c_size_t)*nfield*4, d_ttnr)
     call field_buffer(4, int(129*129, c_size_t)*nfield*4, d_nstsr)
     call field_buffer(5, int(48, c_size_t)*nfield, d_box)

@@ -379,3 +379,44 @@ def test_ray_path_points_match_the_oracle(ctx, orc):
             worst = max(worst, float(np.abs(paths[r] - po).max()))
     within("ray path points max |d| rad", worst, 2e-7)
     G0.free(); G.free()
+
+
+@pytest.mark.parametrize("opts,joint", [({}, False), ({}, True), ({"fmm.ts": 1}, False), ({"fmm.ts": 1, "fmm.force_spill": 1}, False),
+                                        ({"fmm.force_spill": 1}, False), ({"fmm.ts": 1, "fmm.cap": 64}, False)])
+def test_rays_on_fields_kept_in_tiles_equal_rays_on_the_column_major_fields(ctx, opts, joint):
+    """Round 6: dazim_fmm_batch(ttn = NULL) leaves the coarse fields inside the library in the eikonal kernel's 4 x 4 tiles and
+    dazim_rays_build_G*(ttn = NULL) traces on them (CalSurfG returns no field, inv/CalSurfG.f90:909-912): predicted times and G must
+    be the bits of the run through the column-major ttn of the ABI -- every heap form's way out of the kernel: one task per field,
+    time-sliced (the node words stay where they were marched), the spill rerun after either (copied to the field's place), a heap
+    too small for most fields (time-sliced first launch + rerun of the overflowed ones)."""
+    nx, ny, kmax = 17, 15, 3
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    t = np.array([8.0, 14.0, 22.0])
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 9, 6, 3)
+    pv, sen, _ = ctx.depthkernel(vel, depz, t, 2.0)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    lsen = ctx.ti_kernels(vel, depz, t, 2.0, pv) if joint else None
+    res = []
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for keep in (False, True):
+            fields = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx, scz, per, keep_fields=keep)
+            assert (fields["ttn"] is None) == keep
+            G, tpred, nb = ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, scx, scz, per, ray_f, rx, rz, sen, lsen=lsen)
+            assert ctx.stat("rays.tiled_fields") == (1.0 if keep else 0.0)
+            res.append((tpred.copy(), G.to_coo(), nb, fields["ttnr"].copy()))
+            G.free()
+    finally:
+        for k in opts:
+            ctx.set_option(k, 0)
+    (tp0, coo0, nb0, r0), (tp1, coo1, nb1, r1) = res
+    assert np.array_equal(tp0, tp1) and nb0 == nb1 and np.array_equal(r0, r1) and tp0.min() > 0
+    for a, b in zip(coo0, coo1):
+        assert np.array_equal(a, b)
+    # ... and a ray call that asks for kept fields after a call that kept none is refused, not served stale memory
+    fields = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, scx, scz, per)
+    fields["ttn"] = None
+    import dazimsurftomo_amd as dz
+    with pytest.raises(dz.DazimError):
+        ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
