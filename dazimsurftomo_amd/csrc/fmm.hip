@@ -1255,14 +1255,28 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
 #define A (*Ap)
 #endif
   constexpr int GP = GPL, FPW = 64 / GPL;   // lanes per field, fields per wavefront (these shadow the 16-lane constants above)
-  __shared__ __attribute__((aligned(16))) float s_keys[FPW][CAP];
-  __shared__ __attribute__((aligned(16))) NT s_nodes[FPW][CAP];
-  // (rows padded so that the four fields sit eight LDS banks apart -- they are walked in step, and CAP is a multiple of the 32
-  // banks -- measured: no difference, 53.4 k fields/s either way)
+  // The four fields of a wavefront walk their heaps in step: the lanes of groups 0 and 1 (one 32-lane half of every LDS access:
+  // MI355X_MICROARCH.md, LDS) read the SAME slot of two rows, and rows CAP entries apart start in the same bank -- a two-way
+  // conflict on every access of the sift-down (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 0.94).  -DDZ_FMM_SKEW lays the rows out
+  // 0, 1, 3, 2 with a skew of half the banks in front of rows 1 and 2 (what is left of the 1 280-byte LDS granule: 12 768 of
+  // 12 800 B at S-256, still twelve workgroups per CU): the ratio drops to 0.48 and NOTHING else moves -- SQ_WAIT_ANY 124.1 ->
+  // 125.1 G of 315 G wave cycles, 80.9 k fields/s without against 80.4 k with in four same-box pairs (profiles/
+  // r6_fmm_lds_conflicts.md).  The two extra LDS cycles of a conflicting access hide behind the ~100-cycle round trip they belong
+  // to; the conflicts are not on the pop's critical chain.  Default: the plain layout.
+#ifndef DZ_FMM_SKEW
+  constexpr int KSKEW = 0, NSKEW = 0;
+#else
+  constexpr int KSKEW = FPW == 4 ? 16 : 0, NSKEW = FPW == 4 ? 16 : 0;   // entries (16-bit node ids: 8 banks)
+#endif
+  __shared__ __attribute__((aligned(16))) float s_keys_all[FPW * CAP + 2 * KSKEW];
+  __shared__ __attribute__((aligned(16))) NT s_nodes_all[FPW * CAP + 2 * NSKEW];
+  auto row_of = [](int g_) { return FPW == 4 ? (g_ == 0 ? 0 : (g_ == 1 ? 1 : (g_ == 3 ? 2 : 3))) : g_; };   // position of group g_'s row
+  auto key_row = [&](int g_) { const int r = row_of(g_); return s_keys_all + r * CAP + (r >= 1 ? KSKEW : 0) + (r >= 3 ? KSKEW : 0); };
+  auto node_row = [&](int g_) { const int r = row_of(g_); return s_nodes_all + r * CAP + (r >= 1 ? NSKEW : 0) + (r >= 3 ? NSKEW : 0); };
   // the queue position is handed to the wavefront through slot 0 of the first field's keys (the dummy slot of the marching
   // loop, idle between fields): the kernel's LDS is exactly the heaps, so five 32 KB workgroups of the hybrid heap fill 160 KB
   __shared__ short s_tab[Heap<CAP, SPILL, NT, HYB, GPL>::TAB ? 144 : 2];
-  unsigned &s_base = *reinterpret_cast<unsigned *>(&s_keys[0][0]);
+  unsigned &s_base = *reinterpret_cast<unsigned *>(key_row(0));
   const int lane = threadIdx.x, grp = lane / GP, gl = lane & (GP - 1);
   dazim_geom g;   // (member by member: the arguments live in the constant address space)
   g.nvx = A.g.nvx; g.nvz = A.g.nvz; g.nnx = A.g.nnx; g.nnz = A.g.nnz;
@@ -1274,8 +1288,8 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   float *velnr = A.velnr + slot * RM * RM;
   float2 *slownr = A.slownr + slot * NREC_R;
   Heap<CAP, SPILL, NT, HYB, GPL> H;
-  H.keys = s_keys[grp];
-  H.nodes = s_nodes[grp];
+  H.keys = key_row(grp);
+  H.nodes = node_row(grp);
   H.g0 = gl == 0;
   H.tab = s_tab;
   H.popcnt = reinterpret_cast<unsigned long long *>(A.counter + 16);
@@ -1317,7 +1331,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
   if (A.prio) __builtin_amdgcn_s_setprio(3);   // issue priority over another kernel's wavefronts on the same SIMD (see run_fmm)
   const int nstage = SPILL ? 1 : A.ts_nstage;
   const bool ts = nstage > 1;
-  unsigned &s_stage = *reinterpret_cast<unsigned *>(&s_keys[1][0]);   // (the dummy slot of the second field, like s_base)
+  unsigned &s_stage = *reinterpret_cast<unsigned *>(key_row(1));   // (the dummy slot of the second field, like s_base)
 
   // Work queue: the field list (sorted by period on the host) is cut into eight contiguous ranges, one per XCD (workgroup b
   // runs on XCD b % 8), so that the fields an XCD marches share one or two velocity grids and these stay in that XCD's L2;
