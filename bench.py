@@ -115,6 +115,7 @@ VALU_PEAK_GINST = 256 * 4 * 2.4 / sum(FMM_VALU_MIX[k] * VALU_CYCLES[k] for k in 
 # quadrant = ~21 multiplies / adds + 1 sqrt + 1 division, of which the 16 lanes of a field evaluate all sixteen in one
 # instruction each), i.e. ~85 instruction slots per wave-pop of four fields if nothing but that arithmetic were issued
 USEFUL_VALU_PER_WAVE_POP = 85
+VALU_PEAK_NOMINAL_GINST = 256 * 4 * 2.4 / 2.0     # = 1228.8 G wave64 VALU instructions/s
 
 
 def profiled_sq(workload, nfield):
@@ -365,6 +366,97 @@ def cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield_total, rays_
     }
 
 
+def timed_small_forward(ctx, nsrc=20, nrcv=16):
+    """A COMPLETE forward pass, timed, not assembled from samples: the S-128 configuration (28 x 28 x 12 model -> 126 x
+    126 nodes, 8 periods) with `nsrc` sources x `nrcv` receivers -- every column's dispersion curves and depth kernels, every field,
+    every ray, every G row -- by the oracle's CalSurfG (= inv/CalSurfG.f90:909, one call, one thread), by the same oracle routines
+    with every host core busy (columns, then fields with their rays, over a thread pool: more threading than the reference has,
+    which only threads depthkernel), and by the device path through the C ABI (host arrays in, G resident, predicted times out;
+    second call timed).  The three produce the same rows (asserted: predicted times to 1e-6 relative, stored entries to 1 %)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle.pyoracle import Oracle
+    global NX, NY, PERIODS
+    saved = (NX, NY, PERIODS)
+    try:
+        NX = NY = WORKLOADS["s128"][0]
+        PERIODS = WORKLOADS["s128"][1]
+        kmax = len(PERIODS)
+        vel = s256_model()
+        scx, scz, per, field_of_ray, rcx, rcz = workload(nsrc, nrcv, 0)
+        nfield, nray = len(scx), len(rcx)
+        rpf = nray // nfield
+        # the reference's argument shapes: [kmax][nsrc], [kmax][nsrc][nrcf]
+        scxf = scx.reshape(kmax, nsrc).copy(); sczf = scz.reshape(kmax, nsrc).copy()
+        rcxf = rcx.reshape(kmax, nsrc, rpf).copy(); rczf = rcz.reshape(kmax, nsrc, rpf).copy()
+        nrc1 = np.full((kmax, nsrc), rpf, np.int32); nsrc1 = np.full(kmax, nsrc, np.int32)
+        periods = np.tile(np.arange(1, kmax + 1, dtype=np.int32)[:, None], (1, nsrc))
+        orc = Oracle()
+        t0 = time.perf_counter()
+        rc, rw, irow, icol, dsurf, nb = orc.calsurfg(vel, DEPZ, GOXD, GOZD, DV, DV, PERIODS, MINTHK, scxf, sczf, rcxf, rczf, nrc1, nsrc1,
+                                                     periods, 16_000_000)
+        t_1 = time.perf_counter() - t0
+        assert rc == 0, rc
+        # all cores: columns of the model, then fields with their rays
+        ncore = os.cpu_count() or 1
+        g = orc.geometry(NX, NY, GOXD, GOZD, DV, DV)
+        t0 = time.perf_counter()
+        cols = [(j, i) for j in range(NY) for i in range(NX)]
+        pv_all = np.zeros((kmax, NX * NY))
+        sen_all = [np.zeros((len(DEPZ), kmax, NX * NY)) for _ in range(3)]
+
+        def one_col(ji):
+            j, i = ji
+            pvc, senc = orc.depthkernel(np.ascontiguousarray(vel[:, j:j + 1, i:i + 1]), DEPZ, PERIODS, MINTHK)
+            pv_all[:, j * NX + i] = pvc[:, 0]
+            for q in range(3):
+                sen_all[q][:, :, j * NX + i] = senc[q][:, :, 0]
+        with ThreadPoolExecutor(ncore) as ex:
+            list(ex.map(one_col, cols))
+        velns = [orc.gridder(g, pv_all[k].reshape(NY, NX)) for k in range(kmax)]
+
+        def one_field(f):
+            k = int(per[f]) - 1
+            veln = orc.gridder(g, pv_all[k].reshape(NY, NX))      # (the reference re-grids per source, inv/CalSurfG.f90:1146)
+            _, ttn, ttnr, nstsr, _, box = orc.fmm_field(g, pv_all[k].reshape(NY, NX), veln, scx[f], scz[f])
+            n = 0
+            for r in np.nonzero(field_of_ray == f)[0]:
+                orc.srtimes(g, veln, ttn, scx[f], scz[f], rcx[r], rcz[r])
+                fdm = orc.rpaths(g, box, veln, ttn, ttnr, nstsr, scx[f], scz[f], rcx[r], rcz[r])[1]
+                n += len(orc.emit_row(vel, fdm, sen_all, k, int(r) + 1)[0])
+            return n
+        with ThreadPoolExecutor(ncore) as ex:
+            nnz_mc = sum(ex.map(one_field, range(nfield)))
+        t_mc = time.perf_counter() - t0
+        del velns
+        if os.environ.get("DAZIM_BENCH_DEBUG"):
+            print("timed_small: 1 core %.2f s, %d cores %.2f s, nnz %d / %d" % (t_1, ncore, t_mc, len(rw), nnz_mc), file=sys.stderr)
+        # the device path, host arrays in and out (second call timed: the first one allocates)
+        t_gpu = None
+        for _ in range(2):
+            ctx.sync()
+            t0 = time.perf_counter()
+            pv, sen, nfail = ctx.depthkernel(vel, DEPZ, PERIODS, MINTHK)
+            fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, scx, scz, per, keep_fields=True)
+            G, tpred, nbg = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, vel, fields, scx, scz, per, field_of_ray, rcx, rcz, sen)
+            ctx.sync()
+            t_gpu = time.perf_counter() - t0
+            nnz_gpu = G.nnz
+            G.free()
+        assert np.abs(tpred - dsurf).max() <= 1e-6 * np.abs(dsurf).max(), "device and oracle predicted times differ"
+        assert abs(nnz_gpu - len(rw)) <= 0.01 * len(rw) and abs(nnz_mc - len(rw)) <= 0.01 * len(rw), (nnz_gpu, nnz_mc, len(rw))
+        return {"extrapolated": False,
+                "workload": f"S-128 complete forward: {NX}x{NY}x{len(DEPZ)} model ({NX * NY} columns x 73 curves x {kmax} periods), "
+                            f"{nfield} fields {g.nnx}x{g.nnz}, {nray} rays, {len(rw)} G entries",
+                "cpu_1core_s": t_1, "cpu_1core_fields_per_s": nfield / t_1, "kind": "port (oracle CalSurfG, one call)",
+                "cpu_allcores_s": t_mc, "cpu_allcores_fields_per_s": nfield / t_mc, "cores": ncore,
+                "gpu_host_api_s": t_gpu, "gpu_fields_per_s": nfield / t_gpu,
+                "speedup_vs_1core": t_1 / t_gpu, "speedup_vs_allcores": t_mc / t_gpu,
+                "note": "the device time is one cold-ish call with HOST arrays on a batch that fills 4 % of the chip (160 fields = 40 "
+                        "wavefronts): a lower bound of the ratio, not the throughput figure"}
+    finally:
+        NX, NY, PERIODS = saved
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -607,6 +699,46 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    # ---- the same step through HOST arrays (outside the timed region; `value` above is device-resident): what a caller of the
+    # C ABI pays who keeps his inputs and results in host memory like the Fortran program does -- model, source / receiver lists and
+    # right-hand side go up, phase-velocity maps, predicted times and x come down every step (PCIe-inclusive); the intermediates
+    # (kernel tables, refined fields, G) stay in dazim_malloc'ed / library memory as in host/dazim_mod.f90's dazim_assemble_G.
+    # coo_to_host_s: what handing G itself to the host as the reference's triplets costs on top (the CalSurfG drop-in's surface).
+    host_api = None
+    if world == 1 and not os.environ.get("DAZIM_BENCH_NO_HOST_API"):
+        h_b = d_b.cpu().numpy()
+        keepG = {}
+
+        def step_host(coo=False):
+            nonlocal d_vel, d_scx, d_scz, d_per, d_fray, d_rcx, d_rcz, d_b
+            d_vel, d_scx, d_scz, d_per = T(vel), T(scx), T(scz), T(per)
+            d_fray, d_rcx, d_rcz, d_b = T(field_of_ray), T(rcx), T(rcz), T(h_b)
+            step()
+            res = (d_pv.cpu().numpy(), last["tpred"].cpu().numpy(), last["x"].cpu().numpy())
+            torch.cuda.synchronize()
+            return res
+        step_host()
+        torch.cuda.synchronize()
+        t0h = time.perf_counter()
+        for _ in range(2):
+            step_host()
+        t_host = (time.perf_counter() - t0h) / 2
+        # G to the host as triplets, once
+        pvh, senh, _ = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen)
+        fld = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pvh, d_scx, d_scz, d_per, veln=d_veln, ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box,
+                            status=d_st, keep_fields=True)
+        Gh, _, _ = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fld, d_scx, d_scz, d_per, d_fray, d_rcx, d_rcz, senh, tpred=d_tpred)
+        t0h = time.perf_counter()
+        coo = Gh.to_coo()
+        t_coo = time.perf_counter() - t0h
+        nnz_h = len(coo[2])
+        del coo
+        Gh.free()
+        host_api = {"value": nfield / t_host, "unit": "fields/s", "ms_per_step": t_host * 1e3,
+                    "coo_to_host_s": t_coo, "coo_bytes": nnz_h * 12,
+                    "note": "the step with HOST arrays for model, source / receiver lists, right-hand side (up) and phase-velocity maps, "
+                            "predicted times, x (down), two steps averaged, outside the timed region; coo_to_host_s = dazim_csr_to_coo "
+                            "of the step's G into host triplets (pageable memory), once"}
     total_fields = nfield
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -662,6 +794,9 @@ def main():
             issue = {"achieved": None, "frac": None, "counters_source": sq_src}
         roofline = {"kernel": "fmm_kernel", "bound": "valu", "achieved": useful_ginst, "peak": VALU_PEAK_GINST, "unit": "G VALU inst/s",
                     "frac": useful_ginst / VALU_PEAK_GINST, "traffic": traffic["fmm"],
+                    # the same useful rate against the guide's NOMINAL issue rate, one wave64 VALU instruction per SIMD every 2 cycles
+                    # (MI355X_MICROARCH.md, wave scheduling): a peak that does not depend on this kernel's own instruction mix
+                    "peak_nominal": VALU_PEAK_NOMINAL_GINST, "frac_nominal": useful_ginst / VALU_PEAK_NOMINAL_GINST,
                     "useful_valu_per_wave_pop": USEFUL_VALU_PER_WAVE_POP, "wave_pops_per_launch": wave_pops, "issue": issue,
                     "useful_frac_of_issued": (USEFUL_VALU_PER_WAVE_POP * wave_pops / sq["SQ_INSTS_VALU"]) if sq else None,
                     "node_acceptances_per_s": pops / stats["fmm_s"], "hbm": hbm,
@@ -717,8 +852,14 @@ def main():
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],
         }
+        if world == 1 and not os.environ.get("DAZIM_BENCH_NO_HOST_API"):
+            out["value_host_api"] = host_api
         if not a.no_cpu and world == 1:      # the CPU baseline is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
+            try:
+                out["cpu_baseline"]["timed_small"] = timed_small_forward(ctx)
+            except Exception as e:
+                out["cpu_baseline"]["timed_small"] = {"error": repr(e)}
             # forward wall time of a step = the step minus its LSMR part (dispersion copies on the auxiliary stream included)
             fwd_s = dt / a.steps - stats["lsmr_s"]
             out["forward_wall_s_per_step"] = fwd_s
