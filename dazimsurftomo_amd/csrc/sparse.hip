@@ -467,7 +467,8 @@ __global__ void k_reorth(int64_t n, float *v, const float *lv_prev, const double
 // grouping of the partial sums.  (Taking all dots of the window at once -- classical Gram-Schmidt, two launches -- was tried first:
 // the iterates leave the reference's within eight iterations, 1.2e-2 relative on the test system of tests/test_sparse_gpu.py.)
 // The barrier: one counter per solve, never reset, target = (barriers so far) x blocks; release / acquire at agent scope
-// (MI355X_MICROARCH.md, inter-workgroup visibility).  All blocks are resident by construction (<= 64 blocks on 256 CUs).
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  All blocks must be resident at once: the host launches at most as many as the
+// occupancy query allows on the device and takes the chain below otherwise (or on a CU-masked stream).
 // Option lsmr.reorth_chain = 1: the chain; lsmr.reorth_blocks: at most that many workgroups.
 constexpr int RC_BLOCKS = 64, RC_THREADS = 1024, RC_EMAX = 16;
 template <int E>
@@ -1966,6 +1967,12 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
     const int *g1 = &S->stop, *g2 = &S->stop2;
     // one iteration, enqueued without any host synchronisation; k = its number (the reorthogonalisation window is a function
     // of k alone: localVEnqueue advances once per iteration, :723-731)
+    int coop_max = 0;
+    if (!getenv("DAZIM_CU_MASK")) {
+      int occ = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_reorth_coop<16>, RC_THREADS, 0) == hipSuccess && occ > 0) coop_max = occ * ctx->num_cu;
+      else (void)hipGetLastError();
+    }
     unsigned reorth_barriers = 0;
     rccl_allreduce = comm && comm->nccl && ctx->opts.count("comm.allreduce") && ctx->opts["comm.allreduce"] == 1;   // arrivals booked at the grid barrier of k_reorth_coop so far (its counter is zeroed here, once)
     DZ_HIP(hipMemsetAsync(part2 + 2 * NPART, 0, 64, ctx->stream));
@@ -2029,7 +2036,9 @@ int dazim_lsmr_traced(dazim_ctx *ctx, const dazim_csr *A, const float *b_u, floa
       if (rcb > RC_BLOCKS) rcb = RC_BLOCKS;
       if (ctx->opts.count("lsmr.reorth_blocks") && ctx->opts["lsmr.reorth_blocks"] > 0 && ctx->opts["lsmr.reorth_blocks"] < rcb) rcb = ctx->opts["lsmr.reorth_blocks"];
       const int64_t per_thread = (n + (int64_t)rcb * RC_THREADS - 1) / ((int64_t)rcb * RC_THREADS);
-      if (localVecs > 0 && lim > 0 && per_thread <= RC_EMAX && !chain) {
+      // the grid barrier of k_reorth_coop needs every workgroup resident at once: bounded by what the occupancy query allows on this
+      // device (coop_max, taken once per solve) -- never on a stream restricted to some CUs (DAZIM_CU_MASK), where that bound does not hold
+      if (localVecs > 0 && lim > 0 && per_thread <= RC_EMAX && !chain && rcb <= coop_max) {
         unsigned *bar = reinterpret_cast<unsigned *>(part2 + 2 * NPART);
         const unsigned base = reorth_barriers;
         reorth_barriers += (unsigned)lim * (unsigned)rcb;

@@ -1,23 +1,20 @@
-"""Multi-GPU host logic: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+"""Sharding rules and a TEST MIRROR of the library's multi-rank algebra (torch.distributed; not a product path).
 
-Forward pass: the (source x period) eikonal fields and their rays are independent, so they are
-sharded over ranks with NO collective (`shard_fields`).  The dispersion curves and depth kernels
-belong to the MODEL, which all ranks share: its columns are independent too, so each rank computes
-the curves of a block of rows of the model and one all-gather hands every rank the whole tables
-(`depthkernel_sharded`: the eikonal solve needs every column's phase velocity, the G rows every
-column's kernels -- a real exchange step, 13 MB at 54 x 54 x 12 x 16 periods).  Solve: G is row-partitioned exactly as its rows were produced (each rank keeps the rows of
-its own rays; the Tikhonov rows are split evenly, `shard_rows`), and LSMR (inv/lsmrModule.f90:36)
-needs per iteration ONE all-reduce: each rank scales its shard of u by its own norm beta_p and sends
-w_p = beta_p A_p^T (u_p / beta_p) together with beta_p^2 (n + 1 values; A^T is linear, beta = sqrt(sum beta_p^2) scales
-afterwards).  Everything n-sized (v, h, hbar, x, localV) is replicated and updated redundantly, so no other
-exchange exists.  At n <= 350 k floats the message is <= 1.4 MB: latency-bound, one ring pass.
+Product: everything the ranks exchange goes through the library's own communicator (csrc/comm.hip: dazim_comm_init = RCCL over
+xGMI) -- the model's dispersion / TI tables sharded by rows inside dazim_dispersion_kernels_sharded / dazim_ti_kernels_sharded, the
+row-sharded LSMR inside dazim_lsmr with ONE collective per iteration.  bench.py and host/dazim_main.f90 both take that path and no
+other.  What lives here:
 
-The PRODUCT path is the solve inside the library (`dazim_comm_init` + `dazim_lsmr`, csrc/sparse.hip: device-side recurrences,
-one grouped ncclAllReduce per iteration).  `lsmr_distributed` below is its TEST MIRROR: the same formulation statement by
-statement in torch, so that the world-size-2 / 3 gloo tests (tests/test_distributed_cpu.py) check the algebra of the fused
-collective where no second GPU exists; bench.py falls back to it only when a rank cannot join the RCCL communicator.  The local
-products come from a `LocalOps` object: on GPUs `GpuLocalOps` (the HIP SpMV kernels through the C ABI on torch CUDA tensors),
-in the CPU gloo tests a test double backed by the oracle.  The scalar recurrences are the reference's, in fp32.
+* `shard_fields`, `shard_rows`: the sharding rules (the Fortran host restates them: dazim_shard_fields / dazim_shard_rows).  The
+  (source x period) eikonal fields and their rays are independent and are sharded with NO collective; G is row-partitioned as its
+  rows were produced, the Tikhonov rows split evenly.
+* `depthkernel_sharded`, `lsmr_distributed`: the same formulations statement by statement in torch, so that the world-size-2 / 3
+  gloo tests (tests/test_distributed_cpu.py) check the algebra where no second GPU exists: blocks of model rows joined by an
+  all-gather; per LSMR iteration (inv/lsmrModule.f90:36) each rank scales its shard of u by its own norm beta_p and sends
+  w_p = beta_p A_p^T (u_p / beta_p) with beta_p^2 -- n fp32 + 1 fp64 in one all-gather of bytes, summed in RANK ORDER (fp32 / fp64
+  like the library's k_beta_axpby); beta = sqrt(sum beta_p^2) scales afterwards; everything n-sized (v, h, hbar, x, localV) is
+  replicated.  The local products come from a `LocalOps` object: `GpuLocalOps` (the HIP SpMV kernels through the C ABI) or, in
+  the CPU gloo tests, a test double backed by the oracle.  The scalar recurrences are the reference's, in fp32.
 """
 import numpy as np
 
@@ -201,10 +198,21 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
         u.mul_(torch.where(bp > 0, 1.0 / bp, torch.ones_like(bp)))
         w.zero_()
         ops.aprod2(w, u)                              # A_p^T (u_p / beta_p)
-        pack = torch.cat([(w * bp).double(), bp2])    # [n + 1] doubles: w_p and beta_p^2
-        allsum_(pack)                                 # RCCL all-reduce over xGMI
+        # ... as the library sends them (csrc/comm.hip, k_beta_axpby): the n fp32 of w_p and the double beta_p^2 in ONE all-gather of
+        # bytes, then summed in RANK ORDER -- fp32 for w, fp64 for beta^2 -- so that this mirror rounds where the product rounds
+        pack = torch.cat([(w * bp).contiguous().view(torch.uint8), bp2.contiguous().view(torch.uint8)])
+        if use_dist:
+            parts = [torch.empty_like(pack) for _ in range(dist.get_world_size(group))]
+            dist.all_gather(parts, pack, group=group)
+        else:
+            parts = [pack]
         collectives[0] += 1
-        beta = _f32(np.sqrt(host(pack[n])))
+        wsum = parts[0][:4 * n].view(f32).clone()
+        b2sum = parts[0][4 * n:].view(torch.float64).clone()
+        for q in parts[1:]:
+            wsum = wsum + q[:4 * n].view(f32)
+            b2sum = b2sum + q[4 * n:].view(torch.float64)
+        beta = _f32(np.sqrt(host(b2sum[0])))
         if beta > 0:
             u.mul_(bp * float(_f32(1) / beta))        # u_p = u / beta
             if localVecs > 0:                         # localVEnqueue
@@ -213,7 +221,7 @@ def lsmr_distributed(ops, b_local, n, damp, atol, btol, conlim, itnlim, localSiz
                 else:
                     localPointer, localVQueueFull = 1, True
                 localV[localPointer - 1].copy_(v)
-            v.mul_(float(-beta)).add_(pack[:n].to(f32) * float(_f32(1) / beta))
+            v.mul_(float(-beta)).add_(wsum * float(_f32(1) / beta))
             if localVecs > 0:                         # localVOrtho, modified Gram-Schmidt
                 lim = localVecs if localVQueueFull else localPointer
                 for q in range(lim):
