@@ -559,34 +559,44 @@ def main():
     # that cannot join is an error on every rank (vote first, raise afterwards: nobody is left waiting in a collective).
     native = use_dist
     lsmr_note = ""
+    transport = "files" if rehearsal else "rccl"
     if native:
-        ok, uid = 1, None
-        if rank == 0:
-            try:
-                if rehearsal:
-                    import tempfile
-                    uid = tempfile.mkdtemp(prefix="dazim_comm_")
-                else:
-                    uid = dz.comm_unique_id()
-            except Exception as e:
-                lsmr_note = f"ncclGetUniqueId failed: {e}"
-        box = [uid]
-        dist.broadcast_object_list(box, src=0)          # (every rank reaches this, whatever happened on rank 0)
-        if box[0] is None:
-            ok = 0
-        else:
-            try:
-                if rehearsal:
-                    ctx.comm_init_files(world, rank, box[0])
-                else:
-                    ctx.comm_init(world, rank, box[0])
-            except Exception as e:
-                ok, lsmr_note = 0, f"in-library communicator set-up failed on rank {rank}: {e}"
-        vote = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-        if int(vote.item()) == 0:
-            if ok:
+        import tempfile
+
+        def join(kind):
+            """every rank attaches the library's communicator of this kind; returns (all joined, note) -- vote first, act afterwards"""
+            ok, uid, note = 1, None, ""
+            if rank == 0:
+                try:
+                    uid = tempfile.mkdtemp(prefix="dazim_comm_") if kind == "files" else dz.comm_unique_id()
+                except Exception as e:
+                    note = f"rank 0 could not make the communicator id: {e}"
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)          # (every rank reaches this, whatever happened on rank 0)
+            if box[0] is None:
+                ok = 0
+            else:
+                try:
+                    if kind == "files":
+                        ctx.comm_init_files(world, rank, box[0])
+                    else:
+                        ctx.comm_init(world, rank, box[0])
+                except Exception as e:
+                    ok, note = 0, f"{kind} communicator set-up failed on rank {rank}: {e}"
+            vote = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+            if int(vote.item()) == 0 and ok:
                 ctx.comm_free()
+            return int(vote.item()) == 1, note
+        joined, lsmr_note = join(transport)
+        if not joined and transport == "rccl" and os.environ.get("DAZIM_BENCH_NO_FILE_FALLBACK") != "1":
+            # RCCL would not come up on some rank: the SAME in-library path over the library's file transport (host-staged
+            # collectives: slower, and the JSON line says so) rather than no measurement at all
+            first = lsmr_note or "RCCL communicator set-up failed on another rank"
+            transport = "files"
+            joined, note2 = join("files")
+            lsmr_note = f"RCCL unavailable ({first}); collectives through the library's FILE transport" + (f"; {note2}" if note2 else "")
+        if not joined:
             raise RuntimeError(lsmr_note or "in-library communicator set-up failed on another rank")
 
     kmax = len(PERIODS)
@@ -705,7 +715,7 @@ def main():
     # (kernel tables, refined fields, G) stay in dazim_malloc'ed / library memory as in host/dazim_mod.f90's dazim_assemble_G.
     # coo_to_host_s: what handing G itself to the host as the reference's triplets costs on top (the CalSurfG drop-in's surface).
     host_api = None
-    if world == 1 and not os.environ.get("DAZIM_BENCH_NO_HOST_API"):
+    if world == 1 and not a.no_cpu:      # (--no-cpu: the timed steps only -- profile passes, A/B scripts)
         h_b = d_b.cpu().numpy()
         keepG = {}
 
@@ -832,7 +842,8 @@ def main():
                              "stored_bytes_per_entry": 4 + ib_aty, "stored_achieved": s_aty / stats["spmvt_s"] / 1e9,
                              "stored_frac": s_aty / stats["spmvt_s"] / 1e9 / HBM_PEAK_GBS},
                      "m": m, "n": n, "nnz": nnz},
-            "lsmr": {"driver": ("in-library, file transport on one shared GPU (DAZIM_BENCH_REHEARSAL)" if rehearsal else "in-library RCCL (dazim_comm_init)")
+            "lsmr": {"driver": ("in-library, file transport on one shared GPU (DAZIM_BENCH_REHEARSAL)" if rehearsal else
+                                ("in-library RCCL (dazim_comm_init)" if transport == "rccl" else "in-library, FILE transport (RCCL set-up failed: see note)"))
                                if use_dist else "single GPU", "rccl_nranks": int(stats.get("nranks", 1)), "note": lsmr_note,
                      # row-sharded solve: ONE collective per iteration, counted by the library (collectives issued / iterations enqueued):
                      # an all-gather of the n floats of A_p^T u_p with the double ||u_p||^2, summed in rank order on the device
@@ -852,7 +863,7 @@ def main():
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],
         }
-        if world == 1 and not os.environ.get("DAZIM_BENCH_NO_HOST_API"):
+        if host_api is not None:
             out["value_host_api"] = host_api
         if not a.no_cpu and world == 1:      # the CPU baseline is timed on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(vel, scx, scz, per, field_of_ray, rcx, rcz, nfield, rays_per_field)
