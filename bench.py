@@ -654,6 +654,10 @@ def main():
     disp_async = os.environ.get("DAZIM_DISP_ASYNC", "1") != "0"
     if disp_async:
         ctx.set_option("disp.async", 1)
+    # The eikonal call returns when its launch is enqueued and the ray call's count pass is dispatched beside it, every ray waiting
+    # for its field's completion flag: the ray kernel fills the tail of the eikonal launch.  DAZIM_FMM_ASYNC=0: one after the other.
+    if os.environ.get("DAZIM_FMM_ASYNC", "1") != "0" and os.environ.get("DAZIM_BENCH_TTN") != "1":
+        ctx.set_option("fmm.async", 1)
     last = {}
 
     def step():
@@ -666,11 +670,12 @@ def main():
         fields = ctx.fmm_batch(NX, NY, GOXD, GOZD, DV, DV, pv, d_scx, d_scz, d_per, veln=d_veln, ttn=d_ttn,
                                ttnr=d_ttnr, nstsr=d_nstsr, boxes=d_box, status=d_st, keep_fields=d_ttn is None)
         lap("fmm_batch")
-        stats["fmm_s"] = ctx.kernel_seconds("fmm")
-        stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")
-        stats["fmm_field_pops"] = ctx.kernel_seconds("fmm.field_pops")
         G, tpred, nb = ctx.rays_build_G(NX, NY, GOXD, GOZD, DV, DV, d_vel, fields, d_scx, d_scz, d_per, d_fray,
                                         d_rcx, d_rcz, sen, tpred=d_tpred)
+        stats["fmm_s"] = ctx.kernel_seconds("fmm")      # (after the ray call: an asynchronous eikonal call is completed by it)
+        stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")
+        stats["fmm_field_pops"] = ctx.kernel_seconds("fmm.field_pops")
+        stats["rays_overlap"] = ctx.kernel_seconds("rays.overlap") > 0
         stats["rays_s"] = ctx.kernel_seconds("rays")
         stats["disp_two_streams"] = disp_async and ctx.kernel_seconds("disp.async") > 0   # (the library declines where it does not pay)
         if stats["disp_two_streams"]:
@@ -859,6 +864,7 @@ def main():
                                             "auxiliary stream beside the eikonal kernel (start to end of that stream's work)"}
                                    if stats.get("disp_two_streams") else {"async": False}),
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
+            "rays_beside_eikonal_tail": bool(stats.get("rays_overlap")),   # option fmm.async: rays_s = what follows the eikonal launch's end
             "fmm_schedule": {"workgroups_per_cu": int(stats["fmm_wg_per_cu"]), "time_sliced_coarse_stages": int(stats["fmm_ts_stages"]),
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],

@@ -286,6 +286,10 @@ int dazim_comm_init_files(dazim_ctx *ctx, int nranks, int rank, const char *dir)
 
 int dazim_comm_free(dazim_ctx *ctx) {
   if (!ctx) return DAZIM_E_BAD_ARG;
+  if (ctx->comm && ctx->aux_epilogue) {   // (tables of a sharded dispersion call still wait for their gather: it needs this communicator)
+    const int rcj = dz_join_aux(ctx);
+    if (rcj) return rcj;
+  }
   if (ctx->comm) {
     DzComm *c = (DzComm *)ctx->comm;
     DZ_HIP(hipStreamSynchronize(ctx->stream));

@@ -214,6 +214,23 @@ int dz_aux_init(dazim_ctx *ctx) {
   return 0;
 }
 
+int dz_async_init(dazim_ctx *ctx) {
+  if (ctx->stream3) return 0;
+  DZ_HIP(hipStreamCreateWithFlags(&ctx->stream3, hipStreamNonBlocking));
+  DZ_HIP(hipEventCreate(&ctx->ev_f0));
+  DZ_HIP(hipEventCreate(&ctx->ev_f1));
+  DZ_HIP(hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming));
+  DZ_HIP(hipEventCreate(&ctx->ev_r0));
+  DZ_HIP(hipEventCreate(&ctx->ev_r1));
+  return 0;
+}
+int dz_fmm_finish(dazim_ctx *ctx) {
+  if (!ctx->fmm_finish) return 0;
+  auto f = std::move(ctx->fmm_finish);
+  ctx->fmm_finish = nullptr;
+  return f();
+}
+
 // everything the main stream enqueues from here on comes after what the auxiliary stream was given (device-side wait only)
 int dz_join_aux(dazim_ctx *ctx) {
   if (!ctx->aux_pending) return 0;
@@ -292,6 +309,9 @@ void dazim_destroy(dazim_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   ctx->aux_epilogue = nullptr;   // (no collective on the way out)
+  if (ctx->stream3) (void)hipStreamSynchronize(ctx->stream3);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)dz_fmm_finish(ctx);
   if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && ctx->comm_release) ctx->comm_release(ctx);
@@ -306,6 +326,10 @@ void dazim_destroy(dazim_ctx *ctx) {
     if (kv.second.first && hipHostFree(kv.second.first) != hipSuccess) { (void)hipGetLastError(); free(kv.second.first); }
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream3) {
+    for (hipEvent_t e : {ctx->ev_f0, ctx->ev_f1, ctx->ev_pre, ctx->ev_r0, ctx->ev_r1}) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->stream3);
+  }
   if (ctx->stream2) {
     (void)hipEventDestroy(ctx->ev_fork);
     (void)hipEventDestroy(ctx->ev_a0);
@@ -324,6 +348,7 @@ int dazim_malloc(dazim_ctx *ctx, void **dptr, size_t bytes) {
   return 0;
 }
 int dazim_free(dazim_ctx *ctx, void *dptr) {
+  { int rcf = dz_fmm_finish(ctx); if (rcf) return rcf; }
   if (ctx->aux_epilogue) { int rcj = dz_join_aux(ctx); if (rcj) return rcj; }
   if (ctx->stream2) DZ_HIP(hipStreamSynchronize(ctx->stream2));
   DZ_HIP(hipStreamSynchronize(ctx->stream));
@@ -335,6 +360,7 @@ int dazim_free(dazim_ctx *ctx, void *dptr) {
 // (a copy into or out of the arrays the perturbed copies of an asynchronous dazim_dispersion_kernels call still work on waits for
 // them; any other copy leaves the auxiliary stream alone, so that staging the next inputs does not cost the overlap)
 int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  { int rcf = dz_fmm_finish(ctx); if (rcf) return rcf; }
   int rcj = dz_join_aux_if_touched(ctx, dst, bytes);
   if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -342,6 +368,7 @@ int dazim_memcpy_h2d(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
   return 0;
 }
 int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  { int rcf = dz_fmm_finish(ctx); if (rcf) return rcf; }
   int rcj = dz_join_aux_if_touched(ctx, src, bytes);
   if (rcj) return rcj;
   DZ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -349,6 +376,7 @@ int dazim_memcpy_d2h(dazim_ctx *ctx, void *dst, const void *src, size_t bytes) {
   return 0;
 }
 int dazim_sync(dazim_ctx *ctx) {
+  { int rcf = dz_fmm_finish(ctx); if (rcf) return rcf; }
   if (ctx->aux_epilogue) { int rcj = dz_join_aux(ctx); if (rcj) return rcj; }
   if (ctx->stream2) DZ_HIP(hipStreamSynchronize(ctx->stream2));
   ctx->aux_pending = false;

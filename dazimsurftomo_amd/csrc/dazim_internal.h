@@ -6,7 +6,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -60,7 +62,16 @@ struct dazim_ctx {
     const unsigned *tiled = nullptr;
     const int *tslot = nullptr;
     int nfield = 0, nnx = 0, nnz = 0, stride = 0, tsh = 0;
+    const int *fdone = nullptr;   // asynchronous eikonal call: per field 0 = still marching, 1 = finished, 2 = band overflow (rerun pending)
   } fields;
+  // Option fmm.async (with ttn == NULL and device-resident arguments): dazim_fmm_batch returns when its launch is enqueued, and the
+  // dazim_rays_build_G* call that follows starts its count pass on a third stream -- its workgroups are dispatched as the eikonal
+  // launch's persistent workgroups leave, and each ray waits for its field's completion flag: the ray kernel fills the TAIL of the
+  // eikonal launch (profiles/r6_tail_fill.md).  fmm_finish = what the eikonal call still owes (statuses, spill reruns, timers);
+  // run by the ray call, by dazim_sync / dazim_free / the next dazim_fmm_batch, whichever comes first (dz_fmm_finish).
+  std::function<int()> fmm_finish;
+  hipStream_t stream3 = nullptr;
+  hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr, ev_pre = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
   void *comm = nullptr;
   void (*comm_release)(dazim_ctx *) = nullptr;   // set by dazim_comm_init: dazim_destroy must not leak the communicator
   int nranks = 1, rank = 0;
@@ -97,6 +108,8 @@ static inline void dz_shard_even(int64_t n, int world, int rank, int64_t *lo, in
     if (r_ != ncclSuccess) return dz_fail(ctx, -2000 - (int)r_, "%s:%d %s -> %s", __FILE__, __LINE__, #call, ncclGetErrorString(r_)); \
   } while (0)
 int dz_aux_init(dazim_ctx *ctx);                  // creates the auxiliary stream and its events on first use
+int dz_async_init(dazim_ctx *ctx);                // ... the third stream and the events of an asynchronous eikonal call
+int dz_fmm_finish(dazim_ctx *ctx);                // completes a pending asynchronous eikonal call (no-op without one)
 int dz_join_aux(dazim_ctx *ctx);                  // main stream waits for what the auxiliary stream was given (no host wait)
 int dz_join_aux_if_touched(dazim_ctx *ctx, const void *dev, size_t bytes);   // ... only if [dev, dev + bytes) overlaps what it works on
 

@@ -995,6 +995,7 @@ extern "C" int dazim_dispersion_kernels(dazim_ctx *ctx, int nx, int ny, int nz, 
   DzBuf<float> vel;
   DzBuf<double> pv, svs, svp, srho;
   int rc;
+  if ((rc = dz_fmm_finish(ctx))) return rc; // (an asynchronous eikonal call nobody has collected)
   if ((rc = dz_join_aux(ctx))) return rc;   // (an earlier call's perturbed copies may still be running on the auxiliary stream)
   const size_t nk = (size_t)nz * kmax * ncol;
   if ((rc = vel.init(ctx, vel_u, (size_t)nz * ncol, true, false))) return rc;

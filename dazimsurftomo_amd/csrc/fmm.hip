@@ -65,6 +65,8 @@ struct FmmArgs {
   float *ttn, *ttnr;   // ttn nullable: the coarse fields stay in the kernel's own 4 x 4-tile layout (ttn_tiled) for the ray kernel
   unsigned *ttn_tiled; // [nfield][tiled nnx x nnz] finished fields (time bits of every node), field f at index tslot[f] (or f)
   const int *tslot;    // nullable.  Time-sliced batches: ttn_tiled IS rec_c and tslot the field's place in the queue -- nothing is copied
+  int *fdone;          // nullable (option fmm.async): [nfield] completion flags for a ray kernel that runs beside this launch -- 1 once the
+                       // field's times (and, long before, its refined outputs) are in memory, 2 if its band outgrew the heap (rerun pending)
   int *nstsr;
   dazim_refbox *boxes;
   int *status;
@@ -1325,6 +1327,13 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         for (int i = gl; i < nrec_c; i += GP) dst[i] = rec[i];
       }
     }
+    if (A.fdone) {   // release: every store of this wavefront (the field's words; the refined outputs went out with an earlier fence), then the flag
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (gl == 0) __hip_atomic_store(A.fdone + f, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto flag_overflow = [&](int f) {
+    if (A.fdone && gl == 0) __hip_atomic_store(A.fdone + f, 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   };
   int fastm = __builtin_amdgcn_readfirstlane(*A.vflag) == 0 ? A.fastm : 0;
   asm volatile("" : "+v"(fastm));   // (kept in a vector register: as a scalar it is spilled and comes back through v_readlane in every pop)
@@ -1403,6 +1412,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         FMM_ARGS_FRESH;
         cbar();
         if (ovf) {
+          flag_overflow(f);
           if (gl == 0) { A.status[f] = -2; A.ts_nodes[(size_t)q * CAP] = -1; }
         } else if (H.ntr == 0) {
           store_field(rec_c, f, false);
@@ -1624,6 +1634,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         FMM_ARGS_FRESH;
         cbar();
         if (ovf) {
+          flag_overflow(f);
           if (gl == 0) A.status[f] = -2;  // band outgrew the LDS heap: host reruns this field with SPILL
           if (ts && gl == 0) A.ts_nodes[(size_t)q * CAP] = -1;
         } else if (!ts || H.ntr == 0) {   // (time-sliced: only if the box left no band at all -- the later stages find nothing to do)
@@ -1646,7 +1657,8 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
 
 
 template <int CAP, class NT, bool HYB = false, int GPL = 16>
-int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::vector<int> &hs) {
+int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_status, std::shared_ptr<std::vector<int>> hsp, bool async,
+            std::function<int()> *finish_out) {
   constexpr int FPW = 64 / GPL;   // fields per wavefront of the fast kernel (the spill rerun keeps 16 lanes per field)
   int rc;
   void *p;
@@ -1804,12 +1816,25 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   const bool force_spill = ctx->opts.count("fmm.force_spill") && ctx->opts["fmm.force_spill"];
   if ((rc = dz_pinned(ctx, "fmm.host_status", (size_t)nfield * 4 + 64, &p))) return rc;
   int *hs_pin = (int *)p;
-  DzTimer t(ctx, "fmm");
-  std::vector<int> redo;
+  if ((rc = dz_async_init(ctx))) return rc;
   DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
+  if (A.fdone) DZ_HIP(hipMemsetAsync(A.fdone, 0, (size_t)nfield * 4, ctx->stream));
+  // (what a ray kernel on another stream must see complete before it starts: the gridder's velocity grids, the cleared flags)
+  DZ_HIP(hipEventRecord(ctx->ev_pre, ctx->stream));
+  DZ_HIP(hipEventRecord(ctx->ev_f0, ctx->stream));
   if (!force_spill) {
     hipLaunchKernelGGL((fmm_kernel<CAP, false, NT, HYB, GPL>), dim3(nwg), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
+  }
+  DZ_HIP(hipEventRecord(ctx->ev_f1, ctx->stream));
+  // ---- everything after the launch: statuses, spill reruns, timers.  At once, or -- option fmm.async -- when the ray call (or
+  // dazim_sync ...) asks for it, so that the ray kernel's count pass can be enqueued beside the launch ----
+  auto fin = [=]() mutable -> int {
+  int rc;
+  void *p;
+  std::vector<int> &hs = *hsp;
+  std::vector<int> redo;
+  if (!force_spill) {
     DZ_HIP(hipMemcpyAsync(hs_pin, d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(hs.data(), hs_pin, (size_t)nfield * 4);
@@ -1839,11 +1864,17 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     }
     hipLaunchKernelGGL((fmm_kernel<CAP, true, NT, false>), dim3(nwg2), dim3(64), 0, ctx->stream, A);
     DZ_HIP(hipGetLastError());
+    DZ_HIP(hipEventRecord(ctx->ev_f1, ctx->stream));
     DZ_HIP(hipMemcpyAsync(hs_pin, d_status, (size_t)nfield * 4, hipMemcpyDeviceToHost, ctx->stream));
     DZ_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(hs.data(), hs_pin, (size_t)nfield * 4);
   }
-  t.stop();
+  {
+    float ms = 0;
+    DZ_HIP(hipEventSynchronize(ctx->ev_f1));
+    DZ_HIP(hipEventElapsedTime(&ms, ctx->ev_f0, ctx->ev_f1));
+    ctx->ksec["fmm"] = ms * 1e-3;
+  }
   {
     unsigned long long &hp = *(unsigned long long *)(hs_pin + nfield + 2 - (nfield & 1));
     hp = 0;
@@ -1879,6 +1910,8 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
     DZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fmm_prof), z, sizeof z));
   }
 #endif
+  return 0;
+  };
   ctx->fields.tiled = keep_tiled ? A.ttn_tiled : nullptr;
   ctx->fields.tslot = keep_tiled ? A.tslot : nullptr;
   ctx->fields.nfield = nfield;
@@ -1886,6 +1919,10 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   ctx->fields.nnz = A.g.nnz;
   ctx->fields.stride = tile_records(A.g.nnx, A.g.nnz);
   ctx->fields.tsh = tile_shift(A.g.nnz);
+  ctx->fields.fdone = async ? A.fdone : nullptr;
+  ctx->ksec["fmm.async"] = async ? 1.0 : 0.0;
+  if (!async) return fin();
+  *finish_out = fin;
   return 0;
 }
 
@@ -1902,10 +1939,12 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
   if (kmax < 1 || nfield < 0 || !pv_u || (nfield > 0 && (!scx_u || !scz_u || !period_u)) || g.nnx > 32767 || g.nnz > 32767)
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "bad arguments to dazim_fmm_batch");
   DZ_HIP(hipSetDevice(ctx->device));
+  { const int rcf = dz_fmm_finish(ctx); if (rcf) return rcf; }   // (an earlier asynchronous call nobody has collected yet)
   struct Busy {   // (the multi-GB scratch of a time-sliced batch may be freed by dz_trim_caches when another call runs out of memory)
     dazim_ctx *c;
+    bool keep = false;
     explicit Busy(dazim_ctx *c_) : c(c_) { c->fmm_busy = true; }
-    ~Busy() { c->fmm_busy = false; }
+    ~Busy() { if (!keep) c->fmm_busy = false; }
   } busy(ctx);
   ctx->fields = dazim_ctx::TiledFields();   // (whatever an earlier call left for the ray kernel is gone: the scratch is reused)
   const size_t nn = (size_t)g.nnx * g.nnz, npv = (size_t)(g.nvz + 2) * (g.nvx + 2), nr = (size_t)RM * RM;
@@ -2000,13 +2039,24 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
       if ((rc = dz_scratch(ctx, "fmm.status", (size_t)nfield * 4, &p))) return rc;
       d_status = (int *)p;
     }
+    // Option fmm.async: return once the launch is enqueued (see dazim_ctx::fmm_finish).  Only when nothing of this call waits for
+    // the launch on the host: the coarse fields stay inside the library (ttn == NULL) and every array is device-resident.
+    const bool async = ctx->opts.count("fmm.async") && ctx->opts["fmm.async"] && !ttn_u && !pv.staged && !scx.staged && !scz.staged &&
+                       !period.staged && !veln.staged && !ttnr.staged && !nstsr.staged && !boxes.staged && !status.staged &&
+                       ttnr.dev && nstsr.dev && boxes.dev;
+    A0.fdone = nullptr;
+    if (async) {
+      if ((rc = dz_scratch(ctx, "fmm.fdone", (size_t)nfield * 4 + 16, &p))) return rc;
+      A0.fdone = (int *)p;
+    }
     // LDS heap slots per field: the narrow band of an N x M grid peaks near 3*max(N,M) entries (and the
     // 129 x 129 refined grid near 400); the smallest instantiation above that maximises the number of
     // fields in flight per CU.  A field whose band still outgrows it is redone by the spill kernel.
     int cap = 3 * (g.nnx > g.nnz ? g.nnx : g.nnz);
     if (cap < 3 * RM) cap = 3 * RM;
     if (ctx->opts.count("fmm.cap") && ctx->opts["fmm.cap"] > 0) cap = ctx->opts["fmm.cap"];
-    std::vector<int> hs(nfield);
+    auto hsp = std::make_shared<std::vector<int>>(nfield);
+    std::function<int()> fin;
     const bool small = g.nnx <= 256 && g.nnz <= 256;   // node id fits 16 bits
     bool use_hyb512 = cap > 512 && nfield > ctx->num_cu * 8 * FPW;
     if (ctx->opts.count("fmm.hyb512") && ctx->opts["fmm.hyb512"] == 1) use_hyb512 = true;
@@ -2026,39 +2076,51 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
     // levels (1.5 KB of LDS per field).  Grids with 16-bit node ids only.  Measurements: DESIGN.md section 4.
     const int gp8 = ctx->opts.count("fmm.gp8") ? ctx->opts["fmm.gp8"] : 0;
     if (gp8 && small && cap <= 768) {
-      if (gp8 == 2) rc = run_fmm<256, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
-      else if (cap <= 512) rc = run_fmm<512, unsigned short, false, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
-      else rc = run_fmm<512, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hs);
+      if (gp8 == 2) rc = run_fmm<256, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+      else if (cap <= 512) rc = run_fmm<512, unsigned short, false, 8>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+      else rc = run_fmm<512, unsigned short, true, 8>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     } else
-    if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    if (cap <= 64) rc = small ? run_fmm<64, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin) : run_fmm<64, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+    else if (cap <= 512) rc = small ? run_fmm<512, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin) : run_fmm<512, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     // grids of 171 .. 256 nodes a side (S-256) with more fields than the 768-slot heaps hold at once (8 workgroups of 4 per CU):
     // levels 1-9 in LDS + level 10 in HBM -- 12 workgroups per CU, a third wavefront per SIMD, and time slicing (run_fmm) keeps
     // them all busy to the end.  The 13 % of the fields whose band outgrows 511 entries pay for the HBM level (-17 % at equal
     // occupancy), so batches that fit the 768-slot heaps stay there.  Option fmm.hyb512 = 1 / 2 forces it on / off.
-    else if (cap <= 768 && small && use_hyb512) rc = run_fmm<512, unsigned short, true>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hs) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 768 && small && use_hyb512) rc = run_fmm<512, unsigned short, true>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+    else if (cap <= 768) rc = small ? run_fmm<768, unsigned short>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin) : run_fmm<768, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     // grids of 257 .. 682 nodes a side (S-512): levels 1-9 in LDS, levels 10 and 11 in HBM -- 16 KB of LDS per workgroup, ten
     // workgroups per CU instead of five.  These kernels wait on latencies (1.25 wavefronts per SIMD with 1024 LDS slots), so twice
     // the wavefronts for one or two more dependent memory accesses per pop is a good trade: 341 x 341 nodes 20.2 -> 31.3 k
     // fields/s against the all-LDS 1024-slot heap, S-512 7 950 -> 11 300 against levels 1-10 in LDS (same box, bit-identical).
     // (option fmm.hyb2 = 2: the forms below)
-    else if (cap <= 2048 && use_hyb2) rc = run_fmm<512, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 2048 && use_hyb2) rc = run_fmm<512, int, true>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+    else if (cap <= 1024) rc = run_fmm<1024, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     // (fmm.hyb2 = 2) grids of 342 .. 682 nodes a side: levels 1-10 in LDS + levels 11 (and, never reached there, 12) in HBM
-    else if (cap <= 2048 && !(ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"])) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (cap <= 2048 && !(ctx->opts.count("fmm.no_hybrid") && ctx->opts["fmm.no_hybrid"])) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     // grids above 682 nodes a side: levels 1-10 in LDS, 11 and 12 in HBM (bands up to 4 095 entries = 1 365 nodes a side without
     // the spill kernel, five workgroups per CU instead of the two of the all-LDS 2048-slot heap)
-    else if (use_hyb2) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else if (cap <= 1536) rc = run_fmm<1536, int>(ctx, A0, nfield, nn, nr, d_status, hs);
-    else rc = run_fmm<2048, int>(ctx, A0, nfield, nn, nr, d_status, hs);
+    else if (use_hyb2) rc = run_fmm<1024, int, true>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+    else if (cap <= 1536) rc = run_fmm<1536, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
+    else rc = run_fmm<2048, int>(ctx, A0, nfield, nn, nr, d_status, hsp, async, &fin);
     if (rc) return rc;
     // first failing field, like the reference's STOP
-    for (int i = 0; i < nfield; i++)
-      if (hs[i]) {
-        rc = dz_fail(ctx, hs[i], "field %d: source lies outside bounds of model", i);
-        break;
-      }
+    auto first_error = [ctx, hsp, nfield]() -> int {
+      const std::vector<int> &hs = *hsp;
+      for (int i = 0; i < nfield; i++)
+        if (hs[i]) return dz_fail(ctx, hs[i], "field %d: source lies outside bounds of model", i);
+      return 0;
+    };
+    if (async) {   // the launch is on its way: the rest when the ray call (or dazim_sync, dazim_free, the next eikonal call) asks for it
+      ctx->fmm_busy = true;
+      busy.keep = true;
+      ctx->fmm_finish = [ctx, fin, first_error]() -> int {
+        const int r = fin();
+        ctx->fmm_busy = false;
+        return r ? r : first_error();
+      };
+      return 0;
+    }
+    rc = first_error();
   }
   int rc2;
   if ((rc2 = veln.finish()) || (rc2 = ttn.finish()) || (rc2 = ttnr.finish()) || (rc2 = nstsr.finish()) ||

@@ -41,6 +41,12 @@ struct RayArgs {
   const int *tslot;
   int tsh;
   long fstride;
+  // beside an asynchronous eikonal launch (option fmm.async): a quad of rays waits until the fields it needs are finished (fdone[f] = 1);
+  // a field whose band overflowed (2: the host reruns it later) sends the quad to a second pass -- defer_mark[quad] = 1, which that
+  // pass (only_marked) walks
+  const int *fdone;
+  int *defer_mark;
+  int only_marked;
   const float *ttnr;       // [nfield][RM][RM]
   const int *nstsr;        // [nfield][RM][RM]
   const dazim_refbox *boxes;
@@ -213,7 +219,7 @@ __global__ void k_row_kernels(long n, int kmax, long ncol, const float *__restri
 // distance (a proxy for the number of steps of the ray) in the low `dbits`
 __global__ void k_ray_keys(long nray, const int *__restrict__ field, const float *__restrict__ scx, const float *__restrict__ scz,
                            const float *__restrict__ rcx, const float *__restrict__ rcz, float inv_dmax, int dbits,
-                           unsigned *__restrict__ keys, unsigned *__restrict__ iota) {
+                           unsigned *__restrict__ keys, unsigned *__restrict__ iota, const int *__restrict__ order) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nray) return;
   const int f = field[i];
@@ -221,7 +227,8 @@ __global__ void k_ray_keys(long nray, const int *__restrict__ field, const float
   const float d = sqrtf(dx * dx + dz * dz) * inv_dmax;
   const unsigned dmaxq = (1u << dbits) - 1u;
   unsigned q = d >= 1.0f ? dmaxq : (unsigned)(d * (float)dmaxq);
-  keys[i] = ((unsigned)f << dbits) | (dmaxq - q);          // longest rays of a field first
+  // (order: the fields' places in the eikonal launch's queue -- beside an asynchronous launch the rays come in the order their fields finish)
+  keys[i] = ((unsigned)(order ? order[f] : f) << dbits) | (dmaxq - q);          // longest rays of a field first
   iota[i] = (unsigned)i;
 }
 
@@ -308,6 +315,30 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     chunk = __shfl(chunk, 0);
     if (quad < 0) break;
     const long slot = quad * RPW + grp;
+    if (!EMIT && A.only_marked && !A.defer_mark[quad]) continue;
+    if (!EMIT && A.fdone) {
+      const int fq = slot < A.nray ? A.field[A.perm ? (long)A.perm[slot] : slot] : -1;
+      // Liveness does not rest on the eikonal launch's workgroups being resident: a quad that has waited a second (qcount[19] is
+      // then set for everybody) goes to the second pass instead, which runs after the eikonal call is complete.
+      int st = 1;
+      const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+      for (;;) {
+        st = fq >= 0 ? __hip_atomic_load(A.fdone + fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
+        if (__ballot(st == 0) == 0) break;
+        const bool late = __builtin_amdgcn_s_memrealtime() - t_wait0 > 100000000ull;
+        if (late || __hip_atomic_load(A.qcount + 19, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          if (late && lane == 0) __hip_atomic_store(A.qcount + 19, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (st == 0) st = 2;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(64);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the fields' words and refined outputs, written by another kernel on other XCDs
+      if (__ballot(st == 2) != 0) {
+        if (lane == 0) { A.defer_mark[quad] = 1; atomicAdd(&A.qcount[18], 1u); }
+        continue;
+      }
+    }
     if (slot >= A.nray) continue;
     const long ray = A.perm ? (long)A.perm[slot] : slot;
     const int f = A.field[ray];
@@ -828,6 +859,35 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       !srho_u || !dsurf_u || (nray > 0 && (!field_u || !rcx_u || !rcz_u)))
     return dz_fail(ctx, DAZIM_E_BAD_ARG, "dazim_rays_build_G: NULL array (the refined fields ttnr, nstsr and boxes of dazim_fmm_batch are required)");
   DZ_HIP(hipSetDevice(ctx->device));
+  // An asynchronous eikonal call (option fmm.async) is still marching: the count pass goes to the context's third stream, where its
+  // workgroups are dispatched as the eikonal launch's persistent workgroups leave and every quad of rays waits for its fields'
+  // completion flags -- the ray kernel fills the tail of the eikonal launch.  Only if nothing here has to wait on the host for the
+  // main stream (every array device-resident); otherwise the eikonal call is completed first.  (A pending gather of sharded
+  // dispersion tables -- dz_join_aux below -- runs on the third stream too, behind the perturbed copies it follows.)
+  bool overlap = (bool)ctx->fmm_finish && tiled && ctx->fields.fdone && nray > 0;
+  if (overlap)
+    for (const void *q : {(const void *)vels_u, (const void *)scx_u, (const void *)scz_u, (const void *)period_u, (const void *)veln_u,
+                          (const void *)ttnr_u, (const void *)nstsr_u, (const void *)boxes_u, (const void *)field_u, (const void *)rcx_u,
+                          (const void *)rcz_u, (const void *)svs_u, (const void *)svp_u, (const void *)srho_u, (const void *)dsurf_u,
+                          (const void *)kidx_u, (const void *)lsen_u})
+      if (q && !dz_is_device_ptr(q)) overlap = false;
+  if (!overlap) {
+    const int rcf = dz_fmm_finish(ctx);
+    if (rcf) return rcf;
+  }
+  struct StreamSwap {   // while the count pass is prepared and launched, "the context's stream" is the third stream
+    dazim_ctx *c; hipStream_t main; bool on = false;
+    void restore() { if (on) { c->stream = main; on = false; } }
+    ~StreamSwap() {
+      if (on) (void)hipStreamSynchronize(c->stream);   // (an early return: nothing of this call may still run when its buffers go)
+      restore();
+    }
+  } swap{ctx, ctx->stream};
+  if (overlap) {
+    DZ_HIP(hipStreamWaitEvent(ctx->stream3, ctx->ev_pre, 0));   // the velocity grids and the cleared flags, enqueued before the launch
+    ctx->stream = ctx->stream3;
+    swap.on = true;
+  }
   {   // the depth kernels may still be in the making on the auxiliary stream (dazim_dispersion_kernels with disp.async)
     const int rcj = dz_join_aux(ctx);
     if (rcj) return rcj;
@@ -875,6 +935,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     A.tslot = ctx->fields.tslot; A.tsh = ctx->fields.tsh; A.fstride = ctx->fields.stride;
   }
   ctx->ksec["rays.tiled_fields"] = tiled ? 1.0 : 0.0;
+  ctx->ksec["rays.overlap"] = overlap ? 1.0 : 0.0;
+  A.fdone = overlap ? ctx->fields.fdone : nullptr;
+  A.defer_mark = nullptr;
+  A.only_marked = 0;
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
   A.lsen = joint ? lsen.dev : nullptr;
   A.skern = nullptr;
@@ -1017,7 +1081,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       const float ex = (float)g.nnx * g.dnx, ez = (float)g.nnz * g.dnz;
       const float inv_dmax = 1.0f / sqrtf(ex * ex + ez * ez);
       hipLaunchKernelGGL(k_ray_keys, dim3((unsigned)((nray + 255) / 256)), dim3(256), 0, ctx->stream, (long)nray, field.dev, scx.dev,
-                         scz.dev, rcx.dev, rcz.dev, inv_dmax, dbits, k0, v0);
+                         scz.dev, rcx.dev, rcz.dev, inv_dmax, dbits, k0, v0, overlap ? A.tslot : (const int *)nullptr);
       size_t tb = 0;
       DZ_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, v1, (size_t)nray, 0, fbits + dbits, ctx->stream));
       void *tmp;
@@ -1030,9 +1094,47 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   A.qcount = (unsigned *)p;
   DZ_HIP(hipMemsetAsync(A.qcount, 0, 128, ctx->stream));
   int64_t nnz = 0;
+  double overlap_tail_s = 0.0;
+  if (overlap) {
+    const size_t nq = (size_t)((nray + RPW_MAX - 1) / RPW_MAX) + 8;
+    if ((rc = dz_scratch(ctx, "rays.defer", nq * 4, &p))) return rc;
+    A.defer_mark = (int *)p;
+    DZ_HIP(hipMemsetAsync(A.defer_mark, 0, nq * 4, ctx->stream));
+  }
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
   if (nray > 0 && (rc = launch(false, A, nwg))) return rc;
+  if (overlap) {
+    // the count pass is enqueued beside the eikonal launch.  Now the eikonal call's own end: statuses, spill reruns (main stream);
+    // then the count pass's end, and the quads that met a field waiting for its rerun.
+    DZ_HIP(hipEventRecord(ctx->ev_r1, ctx->stream));
+    swap.restore();
+    const int rcf = dz_fmm_finish(ctx);
+    DZ_HIP(hipStreamSynchronize(ctx->stream3));
+    if (rcf) return rcf;
+    unsigned ndef = 0;
+    DZ_HIP(hipMemcpyAsync(&ndef, A.qcount + 18, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DZ_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ksec["rays.deferred_quads"] = ndef;
+    {
+      unsigned gaveup = 0;
+      DZ_HIP(hipMemcpyAsync(&gaveup, A.qcount + 19, 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      ctx->ksec["rays.wait_timeout"] = gaveup;   // 1: some quad waited a second for its field (the rest went to the second pass)
+    }
+    A.fdone = nullptr;
+    if (ndef > 0) {
+      A.only_marked = 1;
+      DZ_HIP(hipMemsetAsync(A.qcount, 0, 32, ctx->stream));   // the count pass's task counters
+      if ((rc = launch(false, A, nwg))) return rc;
+      A.only_marked = 0;
+    }
+    // what the step pays for the rays: from the end of the eikonal launch on (the count pass's share beside it is free) = the
+    // count pass's remainder after that end + everything below
+    float ms_tail = 0;
+    if (hipEventElapsedTime(&ms_tail, ctx->ev_f1, ctx->ev_r1) == hipSuccess && ms_tail > 0) overlap_tail_s = ms_tail * 1e-3;
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+  }
   {  // exclusive scan of the row counts -> rowptr
     size_t tb = 0;
     DZ_HIP(rocprim::exclusive_scan(nullptr, tb, A.count, (long *)rowptr, 0l, (size_t)(m + 1), rocprim::plus<long>(), ctx->stream));
@@ -1072,6 +1174,10 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
     if (nray > 0 && (rc = launch(true, D, nwg))) return rc;
   }
   t.stop();
+  if (overlap) {
+    ctx->ksec["rays.after_fmm_count"] = overlap_tail_s;
+    ctx->ksec["rays"] += overlap_tail_s;
+  }
   // statuses: first failing ray is the reference's STOP
   std::vector<int> hs(nr1), hb(nr1);
   unsigned hq[2] = {0, 0};

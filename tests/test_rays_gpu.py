@@ -420,3 +420,82 @@ def test_rays_on_fields_kept_in_tiles_equal_rays_on_the_column_major_fields(ctx,
     import dazimsurftomo_amd as dz
     with pytest.raises(dz.DazimError):
         ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, vel, fields, scx, scz, per, ray_f, rx, rz, sen)
+
+
+@pytest.mark.parametrize("opts,joint", [({}, False), ({}, True), ({"fmm.ts": 1}, False), ({"fmm.ts": 1, "fmm.cap": 64}, False),
+                                        ({"fmm.force_spill": 1}, False)])
+def test_rays_beside_an_asynchronous_eikonal_launch_equal_the_synchronous_run(ctx, opts, joint):
+    """Round 6, option fmm.async: dazim_fmm_batch returns when its launch is enqueued, dazim_rays_build_G* puts its count pass on a
+    third stream where every quad of rays waits for its fields' completion flags (the ray kernel fills the tail of the eikonal
+    launch), and fields whose band overflowed send their quads to a second pass after the spill rerun.  G, predicted times and the
+    refined outputs must be the bits of the synchronous run -- one task per field, time-sliced, a heap too small for most fields
+    (flag 2 -> deferred quads), everything through the spill kernel."""
+    import torch
+    nx, ny, kmax = 17, 15, 3
+    depz = np.array([0.0, 10.0, 35.0, 60.0], np.float32)
+    t = np.array([8.0, 14.0, 22.0])
+    vel, scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods = build_case(nx, ny, depz, kmax, 9, 6, 3)
+    scx, scz, per, ray_f, rx, rz = flatten(scxf, sczf, rcxf, rczf, nrc1, nsrc1, periods)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_vel = T(vel)
+    pv, sen, _ = ctx.depthkernel(d_vel, depz, t, 2.0)
+    lsen = ctx.ti_kernels(d_vel, depz, t, 2.0, pv) if joint else None
+    d = [T(a) for a in (scx, scz, per, ray_f, rx, rz)]
+    g = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv.cpu().numpy(), scx, scz, per)["geom"]
+    nf = len(scx)
+    res = []
+    try:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for asyn in (0, 1):
+            ctx.set_option("fmm.async", asyn)
+            bufs = dict(veln=torch.empty((kmax, g.nnx, g.nnz), dtype=torch.float32, device="cuda"),
+                        ttnr=torch.zeros((nf, 129, 129), dtype=torch.float32, device="cuda"),
+                        nstsr=torch.zeros((nf, 129, 129), dtype=torch.int32, device="cuda"),
+                        boxes=torch.zeros((nf, 12), dtype=torch.int32, device="cuda"),
+                        status=torch.zeros((nf,), dtype=torch.int32, device="cuda"))
+            fields = ctx.fmm_batch(nx, ny, 30.0, 100.0, 0.25, 0.25, pv, d[0], d[1], d[2], keep_fields=True, **bufs)
+            G, tpred, nb = ctx.rays_build_G(nx, ny, 30.0, 100.0, 0.25, 0.25, d_vel, fields, d[0], d[1], d[2], d[3], d[4], d[5], sen, lsen=lsen)
+            assert ctx.stat("rays.overlap") == float(asyn) and ctx.stat("fmm.async") == float(asyn)
+            deferred = ctx.stat_or("rays.deferred_quads", 0.0) if asyn else 0.0
+            res.append((tpred.cpu().numpy(), G.to_coo(), nb, bufs["ttnr"].cpu().numpy(), bufs["nstsr"].cpu().numpy(), deferred, ctx.stat("fmm.spilled_fields")))
+            G.free()
+    finally:
+        ctx.set_option("fmm.async", 0)
+        for k in opts:
+            ctx.set_option(k, 0)
+    a, b = res
+    assert np.array_equal(a[0], b[0]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and a[0].min() > 0
+    for x, y in zip(a[1], b[1]):
+        assert np.array_equal(x, y)
+    assert a[6] == b[6]
+    if "fmm.cap" in opts:
+        assert b[6] > 0 and b[5] > 0          # fields did overflow, and their rays did take the second pass
+
+
+def test_asynchronous_eikonal_call_reports_its_error_when_collected(ctx):
+    """a source outside the grid: the asynchronous call has returned before anybody could know; the ray call (or dazim_sync) that
+    completes it returns the reference's STOP condition instead"""
+    import torch
+    import dazimsurftomo_amd as dz
+    nx = ny = 17
+    pv = torch.from_numpy(synth.phase_velocity_maps(nx, ny, 2)).cuda()
+    lat, lon = synth.stations(nx, ny, 26.5, 101.25, 0.25, 0.25, 4)
+    sx, sz = synth.radians(lat, lon)
+    sx = sx.copy(); sx[2] = np.float32(3.0)      # far outside
+    per = np.array([1, 1, 2, 2], np.int32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    g = dz.geometry(nx, ny, 26.5, 101.25, 0.25, 0.25)
+    bufs = dict(veln=torch.empty((2, g.nnx, g.nnz), dtype=torch.float32, device="cuda"), ttnr=torch.zeros((4, 129, 129), dtype=torch.float32, device="cuda"),
+                nstsr=torch.zeros((4, 129, 129), dtype=torch.int32, device="cuda"), boxes=torch.zeros((4, 12), dtype=torch.int32, device="cuda"),
+                status=torch.zeros((4,), dtype=torch.int32, device="cuda"))
+    ctx.set_option("fmm.async", 1)
+    try:
+        ctx.fmm_batch(nx, ny, 26.5, 101.25, 0.25, 0.25, pv, T(sx), T(sz), T(per), keep_fields=True, **bufs)   # returns: nothing known yet
+        assert ctx.stat("fmm.async") == 1.0
+        with pytest.raises(dz.DazimError) as e:
+            ctx.sync()
+        assert e.value.code == dz.DAZIM_E_SOURCE_OUTSIDE
+        ctx.sync()                                   # collected: the context is usable again
+    finally:
+        ctx.set_option("fmm.async", 0)

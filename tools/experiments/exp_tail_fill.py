@@ -1,4 +1,4 @@
-"""Experiment (round 4): would the ray kernel's count pass fit beside the eikonal kernel?  Two contexts, two host threads, S-256
+"""Experiment (round 6, after round 4's exp_overlap_rays.py): does the ray kernel fill the TAIL of the eikonal launch?  Two contexts, two host threads, S-256
 workload of bench.py: context A marches the batch with fmm.wg_per_cu = WPC (room left on every CU), context B traces the rays of a
 previously computed copy of the fields with rays.wg_per_cu = R, started DELAY ms after the eikonal launch."""
 import os, sys, threading, time
@@ -48,20 +48,16 @@ def main():
     tf12 = min(wall(lambda: fmm(ca, ba)) for _ in range(2))
     tr16 = min(wall(lambda: rays(cb, fields_b)) for _ in range(2))
     print(f"alone: fmm (12 wg/cu) {tf12*1e3:.1f} ms, rays (default occupancy) {tr16*1e3:.1f} ms, sum {1e3*(tf12+tr16):.1f}", flush=True)
-    for wpc in (11, 10):
-        ca.set_option("fmm.wg_per_cu", wpc)
-        tf = min(wall(lambda: fmm(ca, ba)) for _ in range(2))
-        for r in (2, 4):
-            cb.set_option("rays.wg_per_cu", r)
-            tr = min(wall(lambda: rays(cb, fields_b)) for _ in range(2))
-            for delay in (0.0, 0.1):
-                def both():
-                    th = threading.Thread(target=lambda: fmm(ca, ba)); th.start()
-                    if delay: time.sleep(delay)
-                    rays(cb, fields_b); th.join()
-                tb = min(wall(both) for _ in range(3))
-                print(f"fmm.wg_per_cu={wpc} rays.wg_per_cu={r} delay={delay*1e3:.0f} ms: fmm alone {tf*1e3:.1f}, rays alone {tr*1e3:.1f}, both {tb*1e3:.1f} ms "
-                      f"(kernel fmm {ca.kernel_seconds('fmm')*1e3:.1f}, rays {cb.kernel_seconds('rays')*1e3:.1f})", flush=True)
-
+    # round 6: NO room reserved -- the eikonal launch takes every slot (12 workgroups per CU), the ray kernel's workgroups are
+    # dispatched as the eikonal ones leave: pure tail filling.  If the pair is not clearly shorter than the sum, a ray kernel that
+    # waits for per-field completion flags inside one step has nothing to win.
+    for delay in (0.02, 0.10, 0.15, 0.18):
+        def both():
+            th = threading.Thread(target=lambda: fmm(ca, ba)); th.start()
+            time.sleep(delay)
+            rays(cb, fields_b); th.join()
+        tb = sorted(wall(both) for _ in range(4))
+        print(f"full occupancy, rays launched {delay*1e3:.0f} ms after the eikonal kernel: both {tb[0]*1e3:.1f} / {tb[1]*1e3:.1f} ms against the sum {1e3*(tf12+tr16):.1f} "
+              f"(kernel fmm {ca.kernel_seconds('fmm')*1e3:.1f}, rays {cb.kernel_seconds('rays')*1e3:.1f})", flush=True)
 
 main()
