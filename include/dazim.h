@@ -142,6 +142,10 @@ int dazim_ti_kernels(dazim_ctx *ctx, int nx, int ny, int nz, const float *vel, c
  *  boxes      [nfield] out, nullable
  *  status     [nfield] out, nullable: DAZIM_OK or DAZIM_E_SOURCE_OUTSIDE per field; the call
  *             returns the first non-zero status (the reference STOPs there)                    */
+/* ttn nullable (round 6): the coarse fields then stay inside the library, in the eikonal kernel's own layout, for the
+ * dazim_rays_build_G* call that follows with ttn = NULL -- the reference's CalSurfG returns no field either (inv/CalSurfG.f90:909-912).
+ * With option "fmm.async" = 1 on top (and every array device-resident) the call returns when its launch is enqueued; the ray call
+ * that follows runs beside the launch's tail and collects this call's statuses and errors (docs/OPTIONS.md).                     */
 int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float gozd, float dvxd, float dvzd,
                     int kmax, const double *pv, int nfield, const float *scx, const float *scz,
                     const int *period_idx, float *veln, float *ttn, float *ttnr, int *nstsr,

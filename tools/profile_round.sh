@@ -1,5 +1,6 @@
 #!/bin/bash
 # The measurement passes behind profiles/ (run on the GPU box from the repo root): tools/profile_round.sh <tag>
+#   (counter passes run with DAZIM_FMM_ASYNC=0: one kernel at a time, per-kernel counters; the trace and the bench line with the default)
 #   1. two counter passes (FETCH_SIZE, WRITE_SIZE; counters only)  -> gpurun_out/pmc_<tag>.md + profiles/pmc_traffic_<workload>.json
 #      (bench.py quotes `traffic` from that json while the kernel sources are the ones it was measured on)
 #   2. rocprofv3 --kernel-trace --stats of a 3-step run            -> gpurun_out/kstats_<tag>.md
@@ -12,8 +13,8 @@ root=$PWD
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$tag -- python $root/bench.py --workload $wl --no-cpu --steps 1 --warmup 0 > $out/pmc_fetch_$tag.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$tag -- python $root/bench.py --workload $wl --no-cpu --steps 1 --warmup 0 > $out/pmc_write_$tag.log 2>&1
+DAZIM_FMM_ASYNC=0 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$tag -- python $root/bench.py --workload $wl --no-cpu --steps 1 --warmup 0 > $out/pmc_fetch_$tag.log 2>&1
+DAZIM_FMM_ASYNC=0 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$tag -- python $root/bench.py --workload $wl --no-cpu --steps 1 --warmup 0 > $out/pmc_write_$tag.log 2>&1
 cd $root
 python tools/pmc_summary.py $out/pmc_fetch_$tag $out/pmc_write_$tag --json $out/pmc_traffic_$tag.json --tag $tag --workload $wl --fields $fields > $out/pmc_$tag.md
 cp $out/pmc_traffic_$tag.json $root/profiles/pmc_traffic_$wl.json

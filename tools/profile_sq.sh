@@ -9,7 +9,7 @@ root=$PWD
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
+DAZIM_FMM_ASYNC=0 timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
   --output-format csv -d $out/pmc_sq_$tag -- python $root/bench.py --workload $wl --no-cpu --steps 1 --warmup 0 > $out/pmc_sq_$tag.log 2>&1
 cd $root
 python tools/sq_summary.py $out/pmc_sq_$tag --json $out/sq_counters_$tag.json --tag $tag --workload $wl --fields $fields > $out/sq_$tag.md
