@@ -865,6 +865,12 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   // main stream (every array device-resident); otherwise the eikonal call is completed first.  (A pending gather of sharded
   // dispersion tables -- dz_join_aux below -- runs on the third stream too, behind the perturbed copies it follows.)
   bool overlap = (bool)ctx->fmm_finish && tiled && ctx->fields.fdone && nray > 0;
+  // (a pending gather of sharded dispersion tables would run on the third stream too -- dz_join_aux below --: fine with the file
+  // transport, whose collectives are host-staged; an RCCL communicator is kept to ONE stream, the main one, so with RCCL the
+  // eikonal call is completed first.  Option comm.gather_stream3 = 1 lifts that.)
+  if (overlap && ctx->aux_epilogue && ctx->comm && ((DzComm *)ctx->comm)->nccl &&
+      !(ctx->opts.count("comm.gather_stream3") && ctx->opts["comm.gather_stream3"]))
+    overlap = false;
   if (overlap)
     for (const void *q : {(const void *)vels_u, (const void *)scx_u, (const void *)scz_u, (const void *)period_u, (const void *)veln_u,
                           (const void *)ttnr_u, (const void *)nstsr_u, (const void *)boxes_u, (const void *)field_u, (const void *)rcx_u,
