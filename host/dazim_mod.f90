@@ -49,8 +49,8 @@ module dazim_mod
   ! .true. (the reference's behaviour): CalSurfG / CalSurfGAnisoJoint fill the caller's dense GVs (GGc, GGs), dall x nparpi each
   logical, save :: dazim_fill_dense = .true.
   ! device buffers of the eikonal fields, kept between calls of dazim_assemble_G (one per outer iteration, same sizes)
-  type(c_ptr), save :: fld_ptr(9) = c_null_ptr
-  integer(c_size_t), save :: fld_bytes(9) = 0
+  type(c_ptr), save :: fld_ptr(20) = c_null_ptr
+  integer(c_size_t), save :: fld_bytes(20) = 0
 
   type, bind(C) :: dazim_refbox
     integer(c_int) :: vnl, vnr, vnt, vnb, nnxr, nnzr, isx, isz
@@ -174,6 +174,9 @@ module dazim_mod
       integer(c_int64_t) :: nnz
     end function
     integer(c_int) function dazim_memcpy_h2d(ctx, dst, src, bytes) bind(C, name="dazim_memcpy_h2d")
+      import; type(c_ptr), value :: ctx, dst, src; integer(c_size_t), value :: bytes
+    end function
+    integer(c_int) function dazim_memcpy_d2h(ctx, dst, src, bytes) bind(C, name="dazim_memcpy_d2h")
       import; type(c_ptr), value :: ctx, dst, src; integer(c_size_t), value :: bytes
     end function
     integer(c_int) function dazim_malloc(ctx, p, bytes) bind(C, name="dazim_malloc")
@@ -699,9 +702,19 @@ contains
     real(c_float), pointer :: dvel(:)
     real(c_double), pointer :: dsvs(:), dsvp(:), dsrho(:)
     integer(c_size_t) :: nkb
-    real, allocatable :: scx(:), scz(:), rcx(:), rcz(:)
-    integer, allocatable :: per(:), kidx(:), fray(:)
+    real, allocatable, target :: scx(:), scz(:), rcx(:), rcz(:)
+    integer, allocatable, target :: per(:), kidx(:), fray(:)
     type(c_ptr) :: d_veln, d_ttn, d_ttnr, d_nstsr, d_box
+    ! the lists and tables of the two calls below on the device as well: with every argument device-resident the eikonal call may
+    ! return when its launch is enqueued (option fmm.async) and the ray call's count pass runs beside the launch's tail
+    type(c_ptr) :: p_pv, p_scx, p_scz, p_per, p_kidx, p_fray, p_rcx, p_rcz, p_dsurf, p_lsen
+    real(c_double), pointer :: dpv(:)
+    real(c_float), pointer :: dscx(:), dscz(:), drcx(:), drcz(:), ddsurf(:), dlsen(:)
+    integer(c_int), pointer :: dper(:), dkidx(:), dfray(:)
+    real, allocatable, target :: dsurf_h(:)
+    real*8, allocatable, target :: pv_h(:, :)
+    real, allocatable, target :: lsen_h(:)
+    integer :: nlsen
     integer :: nfield, nray, k, s, r, f, nnx, nnz
     integer(c_int) :: nfail, nb
     integer(c_int64_t) :: nnz64
@@ -757,16 +770,43 @@ contains
     call field_buffer(3, int(129*129, c_size_t)*nfield*4, d_ttnr)
     call field_buffer(4, int(129*129, c_size_t)*nfield*4, d_nstsr)
     call field_buffer(5, int(48, c_size_t)*nfield, d_box)
-    call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, pv, nfield, scx, scz, per, &
+    allocate (pv_h(nx*ny, kmaxRc), dsurf_h(max(nray, 1)))
+    pv_h = pv
+    call upload(10, c_loc(pv_h), int(nx, c_size_t)*ny*kmaxRc*8, p_pv)
+    call upload(11, c_loc(scx), int(nfield, c_size_t)*4, p_scx)
+    call upload(12, c_loc(scz), int(nfield, c_size_t)*4, p_scz)
+    call upload(13, c_loc(per), int(nfield, c_size_t)*4, p_per)
+    call upload(14, c_loc(kidx), int(nfield, c_size_t)*4, p_kidx)
+    call upload(15, c_loc(fray), int(max(nray, 1), c_size_t)*4, p_fray)
+    call upload(16, c_loc(rcx), int(max(nray, 1), c_size_t)*4, p_rcx)
+    call upload(17, c_loc(rcz), int(max(nray, 1), c_size_t)*4, p_rcz)
+    call field_buffer(18, int(max(nray, 1), c_size_t)*4, p_dsurf)
+    call c_f_pointer(p_pv, dpv, [nx*ny*kmaxRc]); call c_f_pointer(p_scx, dscx, [nfield]); call c_f_pointer(p_scz, dscz, [nfield])
+    call c_f_pointer(p_per, dper, [nfield]); call c_f_pointer(p_kidx, dkidx, [nfield]); call c_f_pointer(p_fray, dfray, [max(nray, 1)])
+    call c_f_pointer(p_rcx, drcx, [max(nray, 1)]); call c_f_pointer(p_rcz, drcz, [max(nray, 1)]); call c_f_pointer(p_dsurf, ddsurf, [max(nray, 1)])
+    if (joint) then
+      nlsen = nx*ny*kmaxRc*(nz - 1)
+      allocate (lsen_h(nlsen))
+      lsen_h(1:nlsen) = lsen(1:nlsen)
+      call upload(19, c_loc(lsen_h), int(nlsen, c_size_t)*4, p_lsen)
+      call c_f_pointer(p_lsen, dlsen, [nlsen])
+    end if
+    call check(dazim_set_option(dazim_handle, 'fmm.async'//c_null_char, 1_c_int), 'option')
+    call check(dazim_fmm_batch(dazim_handle, nx, ny, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dpv, nfield, dscx, dscz, dper, &
                                d_veln, d_ttn, d_ttnr, d_nstsr, d_box, c_null_ptr), 'CalSurfG/travel')
     if (joint) then
-      call check(dazim_rays_build_G_joint(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, scx, scz, &
-                                    per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
-                                    dsvs, dsvp, dsrho, lsen, dsurf, G, nnz64, nb), 'CalSurfGAnisoJoint/rpathsAzim')
+      call check(dazim_rays_build_G_joint(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, dscx, dscz, &
+                                    dper, dkidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), dfray, drcx, drcz, &
+                                    dsvs, dsvp, dsrho, dlsen, ddsurf, G, nnz64, nb), 'CalSurfGAnisoJoint/rpathsAzim')
     else
-      call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, scx, scz, &
-                                    per, kidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), fray, rcx, rcz, &
-                                    dsvs, dsvp, dsrho, dsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+      call check(dazim_rays_build_G(dazim_handle, nx, ny, nz, goxdf, gozdf, dvxdf, dvzdf, kmaxRc, dvel, nfield, dscx, dscz, &
+                                    dper, dkidx, d_veln, d_ttn, d_ttnr, d_nstsr, d_box, int(nray, c_int64_t), dfray, drcx, drcz, &
+                                    dsvs, dsvp, dsrho, ddsurf, G, nnz64, nb), 'CalSurfG/rpaths')
+    end if
+    call check(dazim_set_option(dazim_handle, 'fmm.async'//c_null_char, 0_c_int), 'option')   ! (the handle is shared: only these calls)
+    if (nray > 0) then
+      call check(dazim_memcpy_d2h(dazim_handle, c_loc(dsurf_h), p_dsurf, int(nray, c_size_t)*4), 'CalSurfG/dsurf')
+      dsurf(1:nray) = dsurf_h(1:nray)
     end if
     nar = int(nnz64)
     if (nb >= 1) write (6, *) nb, ' ray path along the boundary, dangerous!!'   ! :1410
@@ -775,6 +815,16 @@ contains
     dazim_dev_seconds(3) = dazim_dev_seconds(3) + t_ti
     dazim_dev_seconds(4) = dazim_dev_seconds(4) + max(dazim_last_kernel_seconds(dazim_handle, 'fmm'//c_null_char), 0.0_c_double)
     dazim_dev_seconds(5) = dazim_dev_seconds(5) + max(dazim_last_kernel_seconds(dazim_handle, 'rays'//c_null_char), 0.0_c_double)
+  end subroutine
+
+  ! device buffer q holding a copy of `bytes` bytes of host memory
+  subroutine upload(q, host, bytes, p)
+    integer, intent(in) :: q
+    type(c_ptr), intent(in) :: host
+    integer(c_size_t), intent(in) :: bytes
+    type(c_ptr), intent(out) :: p
+    call field_buffer(q, bytes, p)
+    if (bytes > 0) call check(dazim_memcpy_h2d(dazim_handle, p, host, bytes), 'upload')
   end subroutine
 
   ! device buffer q of at least `bytes` bytes, reused from the previous call when it is large enough
