@@ -487,8 +487,9 @@ int dazim_dispersion_kernels_sharded(dazim_ctx *ctx, int nx, int ny, int nz, con
   // that waiting for this rank's copies costs less than the ray kernel beside the eikonal tail brings: an RCCL communicator is
   // kept to the main stream, where a deferred gather would sit behind the whole eikonal launch and keep the ray call from
   // starting beside it (rays.hip).  The same decision on every rank: options and rank count are the ranks' own.
-  const bool gather_now = c->nccl && c->nranks >= 4 && ctx->opts.count("fmm.async") && ctx->opts["fmm.async"] &&
-                          !(ctx->opts.count("comm.gather_stream3") && ctx->opts["comm.gather_stream3"]);
+  const bool gather_now = (c->nccl && c->nranks >= 4 && ctx->opts.count("fmm.async") && ctx->opts["fmm.async"] &&
+                           !(ctx->opts.count("comm.gather_stream3") && ctx->opts["comm.gather_stream3"])) ||
+                          (ctx->opts.count("comm.gather_now") && ctx->opts["comm.gather_now"]);   // (test knob: the same path over files)
   const bool defer = !gather_now && !svs.staged && !svp.staged && !srho.staged && ctx->opts.count("disp.async") && ctx->opts["disp.async"];
   if (defer) {
     if (!ctx->aux_pending) {   // nothing of this rank on the auxiliary stream: an event that is already complete

@@ -46,8 +46,10 @@ def test_model_tables_sharded_over_ranks_are_bit_identical(tmp_path, world, ny):
     assert sorted(os.listdir(comm_dir)) == []                          # the communicator leaves its directory as it found it
 
 
-def run_bench(tmp_path, tag, world, args, port):
+def run_bench(tmp_path, tag, world, args, port, opts=""):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if opts:
+        env["DAZIM_OPTS"] = opts
     dump = str(tmp_path / tag)
     common = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "1", "--warmup", "0", "--no-cpu", "--dump", dump] + args
     if world == 1:
@@ -63,8 +65,8 @@ def run_bench(tmp_path, tag, world, args, port):
     return json.loads(lines[0]), [np.load(f"{dump}.{r}.npz") for r in range(world)]
 
 
-@pytest.mark.parametrize("workload,world,sources", [("s512", 8, 40), ("s128", 4, 60)])
-def test_bench_strong_scaling_n_ranks_against_one_rank(tmp_path, workload, world, sources):
+@pytest.mark.parametrize("workload,world,sources,opts", [("s512", 8, 40, ""), ("s128", 4, 60, ""), ("s128", 4, 60, "comm.gather_now=1")])
+def test_bench_strong_scaling_n_ranks_against_one_rank(tmp_path, workload, world, sources, opts):
     """BASELINE config 5's shape (s512, strong scaling, eight ranks; reduced source count) and a four-rank S-128, every rank on the one
     GPU: the eight-rank run must reproduce the one-rank run of the same field list -- the dispersion tables (sharded by model rows,
     joined inside the library) and every ray's predicted time bit for bit (each is computed by exactly one rank with the same
@@ -72,7 +74,10 @@ def test_bench_strong_scaling_n_ranks_against_one_rank(tmp_path, workload, world
     order instead of one pass over all rows)."""
     args = ["--workload", workload, "--scaling", "strong", "--sources", str(sources), "--receivers", "12"]
     d1, r1 = run_bench(tmp_path, "one", 1, args, 0)
-    dn, rn = run_bench(tmp_path, "many", world, args, 29640 + world)
+    # (opts "comm.gather_now=1": the sharded depth-kernel tables gathered at once instead of behind the perturbed copies -- what
+    # the library does by itself over RCCL from four ranks on, so that the ray call may run beside the asynchronous eikonal launch)
+    dn, rn = run_bench(tmp_path, "many", world, args, 29640 + world + (7 if opts else 0), opts)
+    assert dn["rays_beside_eikonal_tail"] is True
     assert dn["n_gpus"] == world and dn["lsmr"]["rccl_nranks"] == world and dn["lsmr"]["collectives_per_iteration"] == 1
     assert dn["lsmr"]["collective"].startswith("all-gather") and dn["dispersion"].startswith("model rows sharded over the ranks inside the library")
     assert dn["lsmr_iterations"] == d1["lsmr_iterations"] == 20
