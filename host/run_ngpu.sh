@@ -2,7 +2,8 @@
 # DAzimSurfTomo_amd on N GPUs of one node, one process per GPU:   host/run_ngpu.sh N [para.in]   (from the directory with the inputs)
 # Every rank reads the same inputs from its own copy of the directory (rank<r>/), takes its share of the (period, source) fields
 # (host/dazim_main.f90, dazim_ranks_init) and joins one RCCL communicator whose id rank 0 leaves in comm/; the row-sharded LSMR
-# runs inside the library with one grouped all-reduce per iteration.  All ranks write the same output files; rank0/ holds them.
+# runs inside the library with one collective per iteration (an all-gather, summed in rank order); each rank computes its block of the
+# dispersion tables.  All ranks write the same output files; rank0/ holds them.
 # DAZIM_TRANSPORT=files runs every rank on GPU 0 with the collectives staged through comm/ (tests; a one-GPU box).
 set -e
 n=${1:?number of GPUs}
