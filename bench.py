@@ -661,8 +661,11 @@ def main():
         ctx.set_option("fmm.async", 1)
     last = {}
 
+    step_ms, tw0 = [], [0.0]
+
     def step():
         tw[0] = time.perf_counter()
+        tw0[0] = tw[0]
         pv, sen, nfail = ctx.depthkernel(d_vel, DEPZ, PERIODS, MINTHK, pv=d_pv, sen=d_sen, sharded=shard_disp)
         stats["disp_s"] = ctx.kernel_seconds("disp")            # (disp.async: the column curves; the copies overlap what follows)
         lap("depthkernel")
@@ -677,6 +680,13 @@ def main():
         stats["fmm_ts_stages"], stats["fmm_wg_per_cu"] = ctx.kernel_seconds("fmm.ts_stages"), ctx.kernel_seconds("fmm.wg_per_cu")
         stats["fmm_field_pops"] = ctx.kernel_seconds("fmm.field_pops")
         stats["rays_overlap"] = ctx.kernel_seconds("rays.overlap") > 0
+        if stats["rays_overlap"]:   # (passes of the count kernel beside / after the eikonal launch, this step)
+            stats["rays_passes"] = int(max(ctx.kernel_seconds("rays.passes"), 0))
+        step_ms.append((time.perf_counter() - tw0[0]) * 1e3)
+        if step_ms[-1] >= max(step_ms):
+            stats["slowest_forward"] = {"step": len(step_ms), "ms": step_ms[-1], "fmm_s": stats["fmm_s"], "rays_s": ctx.kernel_seconds("rays"),
+                                        "rays_after_fmm_count_s": ctx.kernel_seconds("rays.after_fmm_count"), "passes": ctx.kernel_seconds("rays.passes"),
+                                        "left_by_first_pass": ctx.kernel_seconds("rays.deferred_quads"), "spilled": ctx.kernel_seconds("fmm.spilled_fields")}
         stats["rays_s"] = ctx.kernel_seconds("rays")
         stats["disp_two_streams"] = disp_async and ctx.kernel_seconds("disp.async") > 0   # (the library declines where it does not pay)
         if stats["disp_two_streams"]:
@@ -865,7 +875,9 @@ def main():
                                             "auxiliary stream beside the eikonal kernel (start to end of that stream's work)"}
                                    if stats.get("disp_two_streams") else {"async": False}),
             "fmm_fields_per_s_kernel": nfield / stats["fmm_s"],
-            "rays_beside_eikonal_tail": bool(stats.get("rays_overlap")),   # option fmm.async: rays_s = what follows the eikonal launch's end
+            "rays_beside_eikonal_tail": bool(stats.get("rays_overlap")),
+            "rays_passes_last_step": stats.get("rays_passes", 0),
+            "forward_ms_per_step_max": max(step_ms[-a.steps:]) if step_ms else None, "slowest_forward": stats.get("slowest_forward"),   # (host wall up to the end of the ray call, slowest timed step)   # option fmm.async: rays_s = what follows the eikonal launch's end
             "fmm_schedule": {"workgroups_per_cu": int(stats["fmm_wg_per_cu"]), "time_sliced_coarse_stages": int(stats["fmm_ts_stages"]),
                              "note": "0 stages = every field marched by one workgroup from start to end (batch fits the resident slots)"},
             "lsmr_iterations": stats["lsmr_itn"], "dispersion_root_failures": stats["nfail"],

@@ -222,6 +222,8 @@ int dz_async_init(dazim_ctx *ctx) {
   DZ_HIP(hipEventCreateWithFlags(&ctx->ev_pre, hipEventDisableTiming));
   DZ_HIP(hipEventCreate(&ctx->ev_r0));
   DZ_HIP(hipEventCreate(&ctx->ev_r1));
+  DZ_HIP(hipHostMalloc((void **)&ctx->hprog, 64, hipHostMallocMapped));
+  memset(ctx->hprog, 0, 64);
   return 0;
 }
 int dz_fmm_finish(dazim_ctx *ctx) {
@@ -329,6 +331,7 @@ void dazim_destroy(dazim_ctx *ctx) {
   if (ctx->stream3) {
     for (hipEvent_t e : {ctx->ev_f0, ctx->ev_f1, ctx->ev_pre, ctx->ev_r0, ctx->ev_r1}) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream3);
+    if (ctx->hprog) (void)hipHostFree(ctx->hprog);
   }
   if (ctx->stream2) {
     (void)hipEventDestroy(ctx->ev_fork);

@@ -63,13 +63,18 @@ struct dazim_ctx {
     const int *tslot = nullptr;
     int nfield = 0, nnx = 0, nnz = 0, stride = 0, tsh = 0;
     const int *fdone = nullptr;   // asynchronous eikonal call: per field 0 = still marching, 1 = finished, 2 = band overflow (rerun pending)
+    unsigned nwg = 0;                    // workgroups of that launch
+    volatile unsigned *hprog = nullptr;  // host-mapped: tasks handed out so far per XCD range of the asynchronous launch, of total_tasks:
+    unsigned total_tasks = 0;            // the ray call launches its count pass when the queue is nearly empty (not before: see rays.hip)
   } fields;
-  // Option fmm.async (with ttn == NULL and device-resident arguments): dazim_fmm_batch returns when its launch is enqueued, and the
-  // dazim_rays_build_G* call that follows starts its count pass on a third stream -- its workgroups are dispatched as the eikonal
-  // launch's persistent workgroups leave, and each ray waits for its field's completion flag: the ray kernel fills the TAIL of the
-  // eikonal launch (profiles/r6_tail_fill.md).  fmm_finish = what the eikonal call still owes (statuses, spill reruns, timers);
-  // run by the ray call, by dazim_sync / dazim_free / the next dazim_fmm_batch, whichever comes first (dz_fmm_finish).
+  // Option fmm.async (with ttn == NULL, device-resident arguments and a time-sliced batch): dazim_fmm_batch returns when its launch
+  // is enqueued, and the dazim_rays_build_G* call that follows runs its count pass on a third stream as non-blocking passes over
+  // the quads of rays whose fields' completion flags are set -- its workgroups are dispatched as the eikonal launch's persistent
+  // workgroups leave: the ray kernel fills the TAIL of the eikonal launch (profiles/r6_tail_fill.md).  fmm_finish = what the
+  // eikonal call still owes (statuses, spill reruns, timers); run by the ray call, by dazim_sync / dazim_free / a copy / the next
+  // eikonal or dispersion call, whichever comes first (dz_fmm_finish).
   std::function<int()> fmm_finish;
+  unsigned *hprog = nullptr;           // pinned, device-visible: 8 progress words of an asynchronous eikonal launch (dz_async_init)
   hipStream_t stream3 = nullptr;
   hipEvent_t ev_f0 = nullptr, ev_f1 = nullptr, ev_pre = nullptr, ev_r0 = nullptr, ev_r1 = nullptr;
   void *comm = nullptr;

@@ -65,6 +65,7 @@ struct FmmArgs {
   float *ttn, *ttnr;   // ttn nullable: the coarse fields stay in the kernel's own 4 x 4-tile layout (ttn_tiled) for the ray kernel
   unsigned *ttn_tiled; // [nfield][tiled nnx x nnz] finished fields (time bits of every node), field f at index tslot[f] (or f)
   const int *tslot;    // nullable.  Time-sliced batches: ttn_tiled IS rec_c and tslot the field's place in the queue -- nothing is copied
+  unsigned *hprog;     // nullable (option fmm.async): host-mapped progress words, one per XCD range: tasks handed out so far
   int *fdone;          // nullable (option fmm.async): [nfield] completion flags for a ray kernel that runs beside this launch -- 1 once the
                        // field's times (and, long before, its refined outputs) are in memory, 2 if its band outgrew the heap (rerun pending)
   int *nstsr;
@@ -1358,6 +1359,7 @@ __global__ __launch_bounds__(64) FMM_WPE_ATTR void fmm_kernel(FmmArgs A_) {
         const unsigned nbr = (c1 - c0) / fpw;                       // batches of this range; tasks: stage-major
         const unsigned b = c0 < c1 ? atomicAdd(&A.counter[chunk], 1u) : 0xffffffffu;
         if (b < nbr * (unsigned)nstage) {
+          if (A.hprog && (b & 15u) == 15u) __hip_atomic_store(A.hprog + chunk, b + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           const unsigned stg = b / nbr;
           found = c0 + (b - stg * nbr) * fpw;
           s_stage = stg;
@@ -1819,6 +1821,19 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   if ((rc = dz_async_init(ctx))) return rc;
   DZ_HIP(hipMemsetAsync(A.counter, 0, 256, ctx->stream));
   if (A.fdone) DZ_HIP(hipMemsetAsync(A.fdone, 0, (size_t)nfield * 4, ctx->stream));
+  A.hprog = nullptr;
+  unsigned total_tasks = 0;
+  if (A.fdone && ctx->hprog) {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->hprog, 0) == hipSuccess && dp) {
+      for (int c = 0; c < 8; c++) ctx->hprog[c] = 0;
+      A.hprog = (unsigned *)dp;
+      const unsigned nq = ((unsigned)nfield + (unsigned)A.fpw - 1) / (unsigned)A.fpw;
+      for (unsigned c = 0; c < 8; c++) total_tasks += ((nq * (c + 1) >> 3) - (nq * c >> 3)) * (unsigned)A.ts_nstage;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   // (what a ray kernel on another stream must see complete before it starts: the gridder's velocity grids, the cleared flags)
   DZ_HIP(hipEventRecord(ctx->ev_pre, ctx->stream));
   DZ_HIP(hipEventRecord(ctx->ev_f0, ctx->stream));
@@ -1919,7 +1934,13 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   ctx->fields.nnz = A.g.nnz;
   ctx->fields.stride = tile_records(A.g.nnx, A.g.nnz);
   ctx->fields.tsh = tile_shift(A.g.nnz);
+  // (a batch that fits the resident slots has no tail worth filling -- its workgroups all end together -- and a ray pass beside it
+  // would only wait: such a call completes at once)
+  async = async && ts && A.hprog != nullptr;
   ctx->fields.fdone = async ? A.fdone : nullptr;
+  ctx->fields.nwg = (unsigned)nwg;
+  ctx->fields.hprog = A.hprog ? ctx->hprog : nullptr;
+  ctx->fields.total_tasks = total_tasks;
   ctx->ksec["fmm.async"] = async ? 1.0 : 0.0;
   if (!async) return fin();
   *finish_out = fin;
@@ -2110,7 +2131,7 @@ extern "C" int dazim_fmm_batch(dazim_ctx *ctx, int nx, int ny, float goxd, float
         if (hs[i]) return dz_fail(ctx, hs[i], "field %d: source lies outside bounds of model", i);
       return 0;
     };
-    if (async) {   // the launch is on its way: the rest when the ray call (or dazim_sync, dazim_free, the next eikonal call) asks for it
+    if (fin) {   // the launch is on its way: the rest when the ray call (or dazim_sync, dazim_free, the next eikonal call) asks for it
       ctx->fmm_busy = true;
       busy.keep = true;
       ctx->fmm_finish = [ctx, fin, first_error]() -> int {

@@ -12,6 +12,8 @@
 // kk) by a count pass, an exclusive scan and an emit pass that reuses the saved cell lists -- no atomics, so G
 // is reproducible.  fp32 without FMA like the reference.
 #include <cmath>
+#include <chrono>
+#include <unistd.h>
 
 #include "dazim_internal.h"
 
@@ -41,12 +43,12 @@ struct RayArgs {
   const int *tslot;
   int tsh;
   long fstride;
-  // beside an asynchronous eikonal launch (option fmm.async): a quad of rays waits until the fields it needs are finished (fdone[f] = 1);
-  // a field whose band overflowed (2: the host reruns it later) sends the quad to a second pass -- defer_mark[quad] = 1, which that
-  // pass (only_marked) walks
+  // beside an asynchronous eikonal launch (option fmm.async): defer_mark[quad] != 0 = not traced yet; a pass traces the marked quads
+  // whose fields are finished (fdone[f] = 1; 0 still marching, 2 band overflow: the host reruns the field first) and unmarks them
   const int *fdone;
   int *defer_mark;
-  int only_marked;
+  int max_quads;           // > 0: a workgroup leaves after tracing that many quads
+  int sweeps;              // > 1: the pass offers every quad of a range that many times (see the queue of rays_kernel)
   const float *ttnr;       // [nfield][RM][RM]
   const int *nstsr;        // [nfield][RM][RM]
   const dazim_refbox *boxes;
@@ -72,7 +74,8 @@ struct RayArgs {
                            // distance, so that the rays marching in lockstep in one wavefront have similar lengths (speed only:
                            // everything a ray produces is stored under its own index)
   unsigned *qcount;        // [16] task counters of the two passes (8 ranges each, one per XCD); [16] rays whose cell list outgrew
-                           // the LDS capacity (full-grid sweep), [17] rays whose list outgrew LK (traced again by the emit pass)
+                           // the LDS capacity (full-grid sweep), [17] rays whose list outgrew LK (traced again by the emit pass);
+                           // [18] quads a pass beside an asynchronous eikonal launch left for a later pass
   float2 *pts;             // option rays.keep_paths: [nray][pcap] ray-path points (colatitude, longitude in rad) as the reference's
   int *npts;               //   rgx/rgz(1:nrp) (receiver first, source last; fwd/rpathsAzim.f90:221-380); npts = nrp, or -1 if > pcap
   int pcap;
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
   const int nxcd = (gridDim.x % 8 == 0) ? 8 : 1;
   unsigned *qcnt = A.qcount + (EMIT ? 8 : 0);
   int chunk = (int)(blockIdx.x % nxcd);
+  int traced = 0;
   for (;;) {
     RAYS_ARGS_FRESH;
     long quad = -1;
@@ -308,6 +312,12 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
           quad = lo + b;
           break;
         }
+        // (a pass beside the eikonal launch sweeps its range several times: a quad whose field was not finished when a workgroup
+        // came by is offered again to the workgroups that arrive later -- no waiting, only A.sweeps cheap looks per quad)
+        if (!EMIT && A.sweeps > 1 && lo < hi && b < (hi - lo) * A.sweeps) {
+          quad = lo + b % (hi - lo);
+          break;
+        }
         chunk = (chunk + 1) % nxcd;
       }
     }
@@ -315,29 +325,24 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
     chunk = __shfl(chunk, 0);
     if (quad < 0) break;
     const long slot = quad * RPW + grp;
-    if (!EMIT && A.only_marked && !A.defer_mark[quad]) continue;
-    if (!EMIT && A.fdone) {
-      const int fq = slot < A.nray ? A.field[A.perm ? (long)A.perm[slot] : slot] : -1;
-      // Liveness does not rest on the eikonal launch's workgroups being resident: a quad that has waited a second (qcount[19] is
-      // then set for everybody) goes to the second pass instead, which runs after the eikonal call is complete.
-      int st = 1;
-      const unsigned long long t_wait0 = __builtin_amdgcn_s_memrealtime();   // 100 MHz
-      for (;;) {
-        st = fq >= 0 ? __hip_atomic_load(A.fdone + fq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1;
-        if (__ballot(st == 0) == 0) break;
-        const bool late = __builtin_amdgcn_s_memrealtime() - t_wait0 > 100000000ull;
-        if (late || __hip_atomic_load(A.qcount + 19, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          if (late && lane == 0) __hip_atomic_store(A.qcount + 19, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (st == 0) st = 2;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(64);
+    if (!EMIT && A.defer_mark) {
+      // Beside an asynchronous eikonal launch the count pass is a sequence of short NON-BLOCKING passes over the quads that are
+      // still marked: a quad is traced (and unmarked) if the fields of all its rays are finished, left for a later pass otherwise,
+      // and a workgroup leaves after max_quads of them.  A ray workgroup NEVER waits for the other kernel: waiting wavefronts were
+      // seen to hold the whole chip while the eikonal launch stood still (4 071 of 4 096 ray workgroups resident and waiting, 19
+      // eikonal workgroups gone, for as long as the wait was allowed to last: profiles/r6_tail_fill.md) -- which launch's
+      // wavefronts are resident is the hardware scheduler's business, and nothing here may depend on it.
+      if (!A.defer_mark[quad]) continue;                      // traced by an earlier pass
+      if (A.fdone) {
+        // (ACQUIRE: the load invalidates this XCD's cached copy of the flag -- the XCDs' L2s are not coherent with each other)
+        const int fq = slot < A.nray ? A.field[A.perm ? (long)A.perm[slot] : slot] : -1;
+        const int st = fq >= 0 ? __hip_atomic_load(A.fdone + fq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : 1;
+        if (__ballot(st != 1) != 0) continue;                 // a field still marching (0) or waiting for its spill rerun (2)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the fields' words and refined outputs, written by another kernel on other XCDs
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the fields' words and refined outputs, written by another kernel on other XCDs
-      if (__ballot(st == 2) != 0) {
-        if (lane == 0) { A.defer_mark[quad] = 1; atomicAdd(&A.qcount[18], 1u); }
-        continue;
-      }
+      if (A.max_quads > 0 && traced >= A.max_quads) break;    // this pass's share is done (the quad stays marked)
+      traced++;
+      if (lane == 0) { A.defer_mark[quad] = 0; atomicAdd(&A.qcount[18], 1u); }
     }
     if (slot >= A.nray) continue;
     const long ray = A.perm ? (long)A.perm[slot] : slot;
@@ -944,7 +949,8 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   ctx->ksec["rays.overlap"] = overlap ? 1.0 : 0.0;
   A.fdone = overlap ? ctx->fields.fdone : nullptr;
   A.defer_mark = nullptr;
-  A.only_marked = 0;
+  A.max_quads = 0;
+  A.sweeps = 1;
   A.nstsr = nstsr.dev; A.boxes = boxes.dev; A.vels = vels.dev; A.svs = svs.dev; A.svp = svp.dev; A.srho = srho.dev;
   A.lsen = joint ? lsen.dev : nullptr;
   A.skern = nullptr;
@@ -1109,37 +1115,81 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
   }
   DzTimer t(ctx, "rays");
   DZ_HIP(hipMemsetAsync(A.count, 0, (size_t)(m + 1) * 8, ctx->stream));
-  if (nray > 0 && (rc = launch(false, A, nwg))) return rc;
-  if (overlap) {
-    // the count pass is enqueued beside the eikonal launch.  Now the eikonal call's own end: statuses, spill reruns (main stream);
-    // then the count pass's end, and the quads that met a field waiting for its rerun.
-    DZ_HIP(hipEventRecord(ctx->ev_r1, ctx->stream));
+  if (!overlap) {
+    if (nray > 0 && (rc = launch(false, A, nwg))) return rc;
+  } else {
+    // ---- the count pass beside the eikonal launch's tail: a sequence of NON-BLOCKING passes on the third stream ----
+    // A pass traces every quad of rays whose fields are finished and marks the others; the host launches the next pass a moment
+    // later for the marked ones, and a last one after the eikonal call is complete (spill reruns included).  The first pass goes
+    // out when the eikonal launch's task queue is nearly empty (the kernel reports the tasks it has handed out through
+    // host-mapped words): from then on its workgroups leave and the passes' workgroups take their slots.  No ray workgroup ever
+    // waits for the eikonal kernel, so nothing depends on which launch's wavefronts the hardware keeps resident.
+    const auto t_poll0 = std::chrono::steady_clock::now();
+    auto fmm_over = [&]() {
+      const bool over = hipEventQuery(ctx->ev_f1) == hipSuccess;
+      if (!over) (void)hipGetLastError();
+      return over;
+    };
+    if (ctx->fields.hprog && ctx->fields.total_tasks > 0) {
+      const unsigned total = ctx->fields.total_tasks, slack = ctx->fields.nwg / 4 + 8 * 16;
+      const unsigned want = total > slack ? total - slack : 0;
+      for (;;) {
+        unsigned have = 0;
+        for (int c = 0; c < 8; c++) have += ctx->fields.hprog[c];
+        if (have >= want || fmm_over()) break;
+        if (std::chrono::steady_clock::now() - t_poll0 > std::chrono::seconds(120)) break;
+        usleep(50);
+      }
+    }
+    const unsigned nquad_all = (unsigned)((nray + RPW_MAX - 1) / RPW_MAX);
+    unsigned pending = nquad_all, *h_traced = nullptr;
+    { void *hp; if ((rc = dz_pinned(ctx, "rays.host_pending", 64, &hp))) return rc; h_traced = (unsigned *)hp; }
+    DZ_HIP(hipMemsetAsync(A.defer_mark, 1, (size_t)nquad_all * 4, ctx->stream));   // every quad marked (any non-zero value)
+    int npass = 0;
+    bool collected = false, ev0_set = false;
+    unsigned left_by_first = 0;
+    int rcf = 0;
+    while (pending > 0) {
+      const bool last = fmm_over();
+      if (last && !collected) {   // the eikonal call's own end: statuses, spill reruns (main stream), before the pass that needs every field
+        swap.restore();
+        rcf = dz_fmm_finish(ctx);
+        collected = true;
+        if (rcf) break;
+        if (npass == 0) (void)hipEventRecord(ctx->ev_r1, ctx->stream);   // (nothing ran beside the launch)
+        (void)hipEventRecord(ctx->ev0, ctx->stream);                     // what follows the eikonal launch's end is what the step pays
+        ev0_set = true;
+      }
+      long nwg_pass = nwg;
+      A.max_quads = 0;
+      A.sweeps = collected ? 1 : 6;
+      if (collected) A.fdone = nullptr;
+      DZ_HIP(hipMemsetAsync(A.qcount, 0, 32, ctx->stream));        // the count pass's task counters
+      if ((rc = launch(false, A, nwg_pass))) return rc;
+      if (!collected) DZ_HIP(hipEventRecord(ctx->ev_r1, ctx->stream));
+      DZ_HIP(hipMemcpyAsync(h_traced, A.qcount + 18, 4, hipMemcpyDeviceToHost, ctx->stream));
+      DZ_HIP(hipStreamSynchronize(ctx->stream));
+      const unsigned before = pending;
+      pending = collected ? 0u : nquad_all - *h_traced;
+      if (npass == 0) left_by_first = pending;
+      npass++;
+      if (pending > 0 && pending == before) usleep(100);   // (nothing was ready: let a few more fields finish)
+    }
     swap.restore();
-    const int rcf = dz_fmm_finish(ctx);
+    if (!collected) rcf = dz_fmm_finish(ctx);
     DZ_HIP(hipStreamSynchronize(ctx->stream3));
     if (rcf) return rcf;
-    unsigned ndef = 0;
-    DZ_HIP(hipMemcpyAsync(&ndef, A.qcount + 18, 4, hipMemcpyDeviceToHost, ctx->stream));
-    DZ_HIP(hipStreamSynchronize(ctx->stream));
-    ctx->ksec["rays.deferred_quads"] = ndef;
-    {
-      unsigned gaveup = 0;
-      DZ_HIP(hipMemcpyAsync(&gaveup, A.qcount + 19, 4, hipMemcpyDeviceToHost, ctx->stream));
-      DZ_HIP(hipStreamSynchronize(ctx->stream));
-      ctx->ksec["rays.wait_timeout"] = gaveup;   // 1: some quad waited a second for its field (the rest went to the second pass)
-    }
+    ctx->ksec["rays.passes"] = npass;
+    ctx->ksec["rays.deferred_quads"] = left_by_first;   // quads the first pass had to leave (fields still marching, or waiting for their rerun)
     A.fdone = nullptr;
-    if (ndef > 0) {
-      A.only_marked = 1;
-      DZ_HIP(hipMemsetAsync(A.qcount, 0, 32, ctx->stream));   // the count pass's task counters
-      if ((rc = launch(false, A, nwg))) return rc;
-      A.only_marked = 0;
-    }
-    // what the step pays for the rays: from the end of the eikonal launch on (the count pass's share beside it is free) = the
-    // count pass's remainder after that end + everything below
+    A.defer_mark = nullptr;
+    A.max_quads = 0;
+    A.sweeps = 1;
+    // what the step pays for the rays: from the end of the eikonal launch on (the passes' share beside it is free) = the last
+    // pass beside the launch, as far as it outlasted it, + everything below
     float ms_tail = 0;
     if (hipEventElapsedTime(&ms_tail, ctx->ev_f1, ctx->ev_r1) == hipSuccess && ms_tail > 0) overlap_tail_s = ms_tail * 1e-3;
-    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    if (!ev0_set) (void)hipEventRecord(ctx->ev0, ctx->stream);
   }
   {  // exclusive scan of the row counts -> rowptr
     size_t tb = 0;
