@@ -341,8 +341,14 @@ __global__ __launch_bounds__(64, AZIM ? 2 : DZ_RAYS_MINW) void rays_kernel(RayAr
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // the fields' words and refined outputs, written by another kernel on other XCDs
       }
       if (A.max_quads > 0 && traced >= A.max_quads) break;    // this pass's share is done (the quad stays marked)
+      // claim the quad: a pass offers it several times, perhaps to workgroups on different XCDs, whose L2s do not see each other's
+      // plain stores -- the exchange is a device-scope atomic, exactly one workgroup gets the 1
+      int mine = 0;
+      if (lane == 0) mine = __hip_atomic_exchange(A.defer_mark + quad, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mine = __shfl(mine, 0);
+      if (!mine) continue;
       traced++;
-      if (lane == 0) { A.defer_mark[quad] = 0; atomicAdd(&A.qcount[18], 1u); }
+      if (lane == 0) atomicAdd(&A.qcount[18], 1u);
     }
     if (slot >= A.nray) continue;
     const long ray = A.perm ? (long)A.perm[slot] : slot;
@@ -1131,7 +1137,9 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       return over;
     };
     if (ctx->fields.hprog && ctx->fields.total_tasks > 0) {
-      const unsigned total = ctx->fields.total_tasks, slack = ctx->fields.nwg / 4 + 8 * 16;
+      unsigned slack = ctx->fields.nwg / 4 + 8 * 16;
+      if (ctx->opts.count("rays.start_slack") && ctx->opts["rays.start_slack"] > 0) slack = (unsigned)ctx->opts["rays.start_slack"];   // (tuning)
+      const unsigned total = ctx->fields.total_tasks;
       const unsigned want = total > slack ? total - slack : 0;
       for (;;) {
         unsigned have = 0;
@@ -1153,6 +1161,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       const bool last = fmm_over();
       if (last && !collected) {   // the eikonal call's own end: statuses, spill reruns (main stream), before the pass that needs every field
         swap.restore();
+        DZ_HIP(hipStreamSynchronize(ctx->stream3));   // (the preparation and the passes so far ran there: the last pass runs on the main stream)
         rcf = dz_fmm_finish(ctx);
         collected = true;
         if (rcf) break;
@@ -1162,7 +1171,7 @@ static int rays_build_impl(dazim_ctx *ctx, int nx, int ny, int nz, float goxd, f
       }
       long nwg_pass = nwg;
       A.max_quads = 0;
-      A.sweeps = collected ? 1 : 6;
+      A.sweeps = collected ? 1 : (ctx->opts.count("rays.sweeps") && ctx->opts["rays.sweeps"] > 0 ? ctx->opts["rays.sweeps"] : 3);   // (measured: 1 -> 300-302 ms, 2-4 -> 297.6-299.6, 6 -> 301-302, 12 -> 305.6, 32 -> 319.6: every look costs)
       if (collected) A.fdone = nullptr;
       DZ_HIP(hipMemsetAsync(A.qcount, 0, 32, ctx->stream));        // the count pass's task counters
       if ((rc = launch(false, A, nwg_pass))) return rc;
