@@ -1936,7 +1936,9 @@ int run_fmm(dazim_ctx *ctx, FmmArgs A, int nfield, size_t nn, size_t nr, int *d_
   ctx->fields.tsh = tile_shift(A.g.nnz);
   // (a batch that fits the resident slots has no tail worth filling -- its workgroups all end together -- and a ray pass beside it
   // would only wait: such a call completes at once)
-  async = async && ts && A.hprog != nullptr;
+  // ... and with eight coarse stages (the two-level hybrid heaps of the 257..682-node grids: S-512) the tail is a ninth of a field's
+  // march: the ray passes beside it only stretch the launch by what they save afterwards (3.00 s either way) -- not there
+  async = async && ts && A.hprog != nullptr && nseg <= 4;
   ctx->fields.fdone = async ? A.fdone : nullptr;
   ctx->fields.nwg = (unsigned)nwg;
   ctx->fields.hprog = A.hprog ? ctx->hprog : nullptr;
